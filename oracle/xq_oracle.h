@@ -1,0 +1,106 @@
+/* TEST INFRASTRUCTURE — CPU oracle, never shipped, never on the product path.
+ *
+ * Plain-C restatement of the reference's self-play + DQN hot path (Qervas/cn_chess_ai @ 2024-10-20).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - rules engine (chessboard.cpp): PINNED — checked against the real reference compiled unmodified
+ *     (oracle/_ref/xqref) through tests/golden/ref_trace.npz, ref_validmat.npz and live cross-checks.
+ *   - chessai.cpp pieces (state one-hot, evaluateBoard, action scan order): restatement, pinned by the
+ *     known answers SURVEY.md records from the reference run (Appendix B move list, E18 reward values)
+ *     and — for the scan order — by the real getValidMoves() per-square lists.
+ *   - NN (dqn.cu / dqn.cpp): restatement only — dqn.cu needs nvcc/CUDA headers that this image lacks, so the
+ *     reference NN cannot be built here without stand-ins: "parity unpinned" by execution; pinned only by the
+ *     structural known answers in SURVEY.md (offsets, parameter counts, file size).
+ */
+#ifndef XQ_ORACLE_H
+#define XQ_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* piece code: 0 empty; 1..7 = red General,Advisor,Elephant,Horse,Chariot,Cannon,Soldier (chessboard.h:8-10);
+ * 8..14 = the same black.  code-1 is the one-hot plane of chessai.cpp:278-282. */
+enum { XQO_RED = 0, XQO_BLACK = 1, XQO_NONE = 2 };
+enum { XQO_MAX_MOVES = 128, XQO_MAX_LAYERS = 8 };
+
+typedef struct {
+    uint8_t sq[90];          /* board[row*9+col] (chessboard.h:61) */
+    int32_t moveCount;       /* chessboard.h:62 */
+    int32_t currentPlayer;   /* chessboard.h:64 */
+    int32_t redScore, blackScore; /* chessboard.h:76-77 */
+} xqo_board;
+
+/* ---- rules engine: chessboard.cpp ---- */
+void xqo_reset(xqo_board* b);                                              /* :8-29, :95-102 */
+int  xqo_is_valid_move(const xqo_board* b, int fr, int fc, int tr, int tc); /* :66-93, :328-440 */
+int  xqo_get_valid_moves(const xqo_board* b, int row, int col, int* out_sq);/* :112-283, ordered; returns n */
+int  xqo_move_piece(xqo_board* b, int fr, int fc, int tr, int tc);          /* :38-64; returns captured code (0: none/invalid) */
+int  xqo_check_game_over(const xqo_board* b);                               /* :286-309 */
+int  xqo_get_winner(const xqo_board* b);                                    /* :312-320 */
+
+/* ---- agent side: chessai.cpp ---- */
+int  xqo_all_valid_actions(const xqo_board* b, int player, uint16_t* codes);/* :347-368; code = from*90+to; returns n (may exceed 128: only first 128 stored) */
+int  xqo_state_indices(const xqo_board* b, int* idx);                       /* :268-289; ascending one-hot indices, returns count */
+void xqo_state_repr(const xqo_board* b, double* state1260);                 /* :268-289 */
+int  xqo_evaluate_board(const xqo_board* b, int color, int moveCount);      /* :311-345 */
+
+/* ---- DQN::selectAction, dqn.cpp:24-56, with the two rand() results injected ---- */
+int  xqo_select_action(const double* q, int nq, const uint16_t* codes, int n,
+                       int rand1, int rand2, int rand_max, double eps);     /* returns index into codes, -1 if n==0 (upstream throws) */
+
+/* ---- NeuralNetwork, dqn.cu.  sizes[0..nsizes-1]; w,b flat in the reference layout (dqn.cu:112-140) ---- */
+size_t xqo_nn_num_weights(const int* sizes, int nsizes);
+size_t xqo_nn_num_biases(const int* sizes, int nsizes);
+int  xqo_nn_forward(const int* sizes, int nsizes, const double* w, const double* b,
+                    const double* in, double* out);                         /* dqn.cu:184-195,199-260 (bias added last) */
+/* mode 0 = bug-compatible (dqn.cu:323-467 as written), mode 1 = textbook backprop.
+ * Returns 0, or -1 if mode 0 is undefined upstream for this topology (out-of-bounds reads). */
+int  xqo_nn_backprop(const int* sizes, int nsizes, double* w, double* b,
+                     const double* in, const double* target, double lr, int mode);
+/* Same deltas as xqo_nn_backprop but ACCUMULATES  gw += delta (x) a,  gb += delta  without touching w,b: the build-defined
+ * minibatch rule is  w -= lr*scale*sum_b(grad_b)  with every grad_b taken at the pre-update weights. */
+int  xqo_nn_accum_grad(const int* sizes, int nsizes, const double* w, const double* b,
+                       const double* in, const double* target, int mode, double* gw, double* gb);
+/* activations of every layer for one input with the 7-arg kernel order (bias first): acts = concat(a_1..a_nL) */
+int  xqo_nn_forward_all(const int* sizes, int nsizes, const double* w, const double* b, const double* in, double* acts);
+
+/* ---- TD target of chessai.cpp:122-128 for one transition (online net) ---- */
+int  xqo_td_target(const int* sizes, int nsizes, const double* w, const double* b,
+                   const double* state, const double* next_state, int action_to, double reward, int done,
+                   double gamma, double* targetQ /* L[last] */);
+
+/* ---- ChessAI::train loop body, chessai.cpp:90-167, one episode; rand() replaced by a seeded LCG ---- */
+typedef struct {
+    int32_t steps, winner, redScore, blackScore, moveCount, target_syncs;
+} xqo_episode_stats;
+int  xqo_train_episode(const int* sizes, int nsizes, double* w, double* b, double lr, double gamma, double eps,
+                       uint64_t* rng_state, int mode, xqo_episode_stats* st);
+int  xqo_rand(uint64_t* rng_state);  /* 31-bit LCG standing in for the time-seeded C rand() */
+
+/* ---- counter-based RNG used by the build's batched self-play (build-defined; Philox4x32-10) ---- */
+void xqo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* ---- build-defined batched self-play step (DESIGN.md "VecEnv semantics"), one game.
+ * q90 == NULL: uniform-random policy.  Returns chosen index or -1 when the side to move has no action. ---- */
+typedef struct {
+    int32_t action_code;   /* from*90+to, -1 if none */
+    int32_t n_moves;
+    int32_t reward;        /* evaluateBoard(mover, post-move count) */
+    uint8_t done;          /* chessai.cpp:119 */
+    uint8_t terminated;    /* episode ended (checkGameOver or no action) -> board was reset */
+    uint8_t winner;        /* getWinner() at termination, else XQO_NONE */
+    uint8_t explored;
+    int32_t redScore, blackScore, moveCount;  /* values at termination / after the move */
+} xqo_step_out;
+void xqo_selfplay_step(xqo_board* b, const float* q90, uint64_t seed, uint32_t game_id, uint32_t step_id,
+                       uint32_t eps_u32, xqo_step_out* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
