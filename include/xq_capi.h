@@ -1,0 +1,246 @@
+/* xq_capi.h — C ABI of libxqhip.so, the MI355X-native (gfx950) batched Xiangqi self-play + DQN hot path.
+ *
+ * This is the drop-in boundary for the training path of Qervas/cn_chess_ai (reference @ 2024-10-20).  The reference
+ * has no FFI layer: its boundary is the C++ class surface ChessBoard / ChessAI / DQN / NeuralNetwork.  Every entry
+ * point below names the reference interface it replaces (file:line into the reference tree); the C++ facade in
+ * include/xq/ rebuilds those classes on top of this ABI, and INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions
+ *   - opaque handles, plain pointers and sizes, no C++ or torch types;
+ *   - every function returns an xq_status (0 = ok) and never throws; xq_last_error() gives the message of the last
+ *     failure on the calling thread;
+ *   - pointers named *_host are caller-owned host memory, *_dev are device (HBM) pointers on the handle's device;
+ *   - each handle runs on ONE hipStream_t (passed as void*; NULL = a stream the handle creates); calls are
+ *     asynchronous on that stream unless they return data to the host, in which case they synchronise that stream;
+ *   - handles are not thread-safe; one GPU per process (one rank per GPU under torch.distributed / RCCL).
+ *
+ * Encodings
+ *   - square  s = row*9 + col, rows 0..9 (Red home rows 0-4, Red moves +row: chessboard.cpp:12-28), cols 0..8;
+ *   - piece code: 0 empty, 1..7 = Red General,Advisor,Elephant,Horse,Chariot,Cannon,Soldier, 8..14 = Black
+ *     (PieceType/PieceColor, chessboard.h:8-14; code-1 is the one-hot plane of chessai.cpp:278-282);
+ *   - action code = from*90 + to  (Action{from,to}, action.h:4-11);
+ *   - colours: 0 Red, 1 Black, 2 None (PieceColor, chessboard.h:12-14).
+ */
+#ifndef XQ_CAPI_H
+#define XQ_CAPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    XQ_OK = 0,
+    XQ_ERR_INVALID_ARGUMENT = 1,  /* std::invalid_argument upstream (dqn.cu:17-19,200,324-329) */
+    XQ_ERR_RUNTIME = 2,           /* std::runtime_error upstream: device error (dqn.h:16-24), empty action list (dqn.cpp:26-28) */
+    XQ_ERR_NO_DEVICE = 3,         /* no gfx950 device / HIP runtime unusable: the product path has NO CPU fallback */
+    XQ_ERR_IO = 4,                /* model file open/read/write failure or layer mismatch (dqn.cpp:80,115,147) */
+    XQ_ERR_UNDEFINED_UPSTREAM = 5 /* bug-compatible backprop requested for a topology where the reference reads out of bounds */
+} xq_status;
+
+enum { XQ_MAX_MOVES = 128, XQ_BOARD_WORDS = 12, XQ_MAX_LAYERS = 8 };
+
+const char* xq_last_error(void);
+int xq_version(void);
+/* Device plumbing (replaces the implicit cudaMalloc/cudaDeviceSynchronize device of dqn.cu). */
+int xq_device_count(int* n);
+int xq_set_device(int device);
+int xq_stream_synchronize(void* hip_stream);
+/* HIP-event timing on a given stream, for bench.py's roofline leg (ms between the two records). */
+int xq_event_create(void** ev);
+int xq_event_destroy(void* ev);
+int xq_event_record(void* ev, void* hip_stream);
+int xq_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * xq_env — thousands of ChessBoard instances resident in HBM (chessboard.h:35-78), one wavefront per board.
+ * HBM layout per game: board = 12 x u32 (90 squares x 4 bit), meta = 4 x u32
+ *   {moveCount | player<<16, redScore | blackScore<<16, plies played by this slot (RNG counter), episodes finished}.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct xq_env xq_env;
+
+/* ChessBoard::ChessBoard() x n_games (chessboard.cpp:4-6).  game ids are first_game_id .. +n_games-1 (RNG streams). */
+int xq_env_create(int n_games, uint64_t seed, uint32_t first_game_id, void* hip_stream, xq_env** out);
+int xq_env_destroy(xq_env* env);
+int xq_env_num_games(const xq_env* env, int* n);
+/* ChessBoard::reset() on every game (chessboard.cpp:95-102); also zeroes the RNG counters and episode counts. */
+int xq_env_reset(xq_env* env);
+/* Test/interop access to the state (no upstream analogue: upstream board is private).  boards90: [n][90] piece codes;
+ * meta4: [n][4] = moveCount, currentPlayer, redScore, blackScore (chessboard.h:62-77). */
+int xq_env_set_state(xq_env* env, int first, int n, const uint8_t* boards90_host, const int32_t* meta4_host);
+int xq_env_get_state(xq_env* env, int first, int n, uint8_t* boards90_host, int32_t* meta4_host);
+/* ChessAI::getAllValidActions(player) for every game (chessai.cpp:347-368 over chessboard.cpp:112-283): canonical
+ * order (from ascending, then generator order).  player: 0 Red, 1 Black, -1 = each game's side to move.
+ * codes: [n_games][128] u16 action codes, counts: [n_games]. */
+int xq_env_legal_moves(xq_env* env, int player, uint16_t* codes_host, int32_t* counts_host);
+int xq_env_legal_moves_dev(xq_env* env, int player, uint16_t* codes_dev, int32_t* counts_dev);
+/* ChessBoard::isValidMove for all 90x90 (from,to) pairs of game g (chessboard.cpp:66-93,328-440): valid8100[f*90+t]. */
+int xq_env_valid_matrix(xq_env* env, int game, uint8_t* valid8100_host);
+
+/* Per-game result of one ply.  Mirrors what chessai.cpp:113-119,146-162 derives after movePiece(). */
+typedef struct {
+    int32_t action;      /* action code played, -1 if the side to move had no action (chessai.cpp:100-103) */
+    int32_t n_moves;     /* size of the legal list the action was chosen from (0 for xq_env_step) */
+    int32_t reward;      /* evaluateBoard(mover, post-move count), chessai.cpp:311-345 */
+    uint8_t captured;    /* piece code movePiece() returned (chessboard.cpp:38-64); 0 = none or invalid move */
+    uint8_t valid;       /* 0: movePiece() rejected the move — no state change */
+    uint8_t done;        /* checkGameOver() || moveCount+1 >= 200 (chessai.cpp:119) */
+    uint8_t terminated;  /* episode ended: checkGameOver() (chessboard.cpp:286-309) or no action; board was auto-reset */
+    uint8_t winner;      /* getWinner() (chessboard.cpp:312-320) when terminated, else 2 */
+    uint8_t explored;    /* epsilon branch taken (dqn.cpp:31-34) */
+    uint16_t move_count; /* getMoveCount() after the move (before auto-reset) */
+    int16_t red_score, black_score; /* getRedScore()/getBlackScore() after the move (before auto-reset) */
+} xq_step_result;
+
+/* ChessBoard::movePiece with caller-chosen actions (chessboard.cpp:38-64) + evaluateBoard + checkGameOver, per game.
+ * actions: [n_games] action codes (any int; out-of-board / invalid => rejected, no state change).
+ * auto_reset != 0: a game whose checkGameOver() became true is reset (the `for episode` loop of chessai.cpp:89-90). */
+int xq_env_step(xq_env* env, const int32_t* actions_host, int auto_reset, xq_step_result* results_host);
+
+/* One self-play ply for every game, fully on device: legal moves (LDS) -> epsilon-greedy DQN::selectAction
+ * (dqn.cpp:24-56; q90_dev = tanh Q-values of outputs 0..89 per game, row stride q_stride floats; NULL = uniform random
+ * policy) -> movePiece -> evaluateBoard -> done -> auto-reset.  rand() is replaced by Philox4x32-10
+ * (ctr = {ply counter of the slot, 0, game id, 0}, key = seed): explore iff r0 < eps_u32, index = r1 % n.
+ * results_dev: optional [n_games] xq_step_result in HBM; replay: optional ring that receives the transition. */
+typedef struct xq_replay xq_replay;
+int xq_env_selfplay_step(xq_env* env, const float* q90_dev, int q_stride, uint32_t eps_u32,
+                         xq_step_result* results_dev, xq_replay* replay);
+/* Convenience for tests: same, copying results to the host. */
+int xq_env_selfplay_step_host(xq_env* env, const float* q90_host, uint32_t eps_u32, xq_step_result* results_host);
+
+/* Episode reporting — the gameCompleted(game, redScore, blackScore) signal (chessai.h:35, chessai.cpp:162). */
+typedef struct {
+    uint32_t game_id, episode;   /* episode = 1-based count for that game slot (signal's `gameNumber`) */
+    int16_t red_score, black_score;
+    uint16_t move_count;
+    uint8_t winner, reserved;
+} xq_episode_record;
+/* Drains up to max_records finished-episode records (oldest first); *n_out = number written, *total = episodes so far. */
+int xq_env_drain_episodes(xq_env* env, xq_episode_record* records_host, int max_records, int* n_out, uint64_t* total);
+/* totals since create/reset: [0] plies, [1] episodes, [2] red wins, [3] black wins, [4] captures, [5] explored plies */
+int xq_env_counters(xq_env* env, uint64_t counters6_host[6]);
+const uint32_t* xq_env_boards_dev(const xq_env* env);   /* [n_games][12] packed boards in HBM */
+const uint32_t* xq_env_meta_dev(const xq_env* env);     /* [n_games][4] */
+
+/* ------------------------------------------------------------------------------------------------------------
+ * xq_replay — ReplayBuffer of N7's 5-tuple (state, action.to, reward, nextState, done), dqn.cpp:157-172.
+ * Not in the reference (SURVEY §8b "New"): ring in HBM, states stored as packed boards (48 B), never as 1260 floats.
+ * ---------------------------------------------------------------------------------------------------------- */
+int xq_replay_create(int capacity, uint64_t seed, void* hip_stream, xq_replay** out);
+int xq_replay_destroy(xq_replay* r);
+int xq_replay_size(xq_replay* r, int* size, int* capacity, uint64_t* total_pushed);
+/* push(s, a, r, s', done) for n transitions given as 90-byte boards on the host (tests / interop). */
+int xq_replay_push_host(xq_replay* r, int n, const uint8_t* boards90, const int32_t* action_to, const float* reward,
+                        const uint8_t* done, const uint8_t* next_boards90);
+/* sample(B): uniform with replacement, Philox(ctr = {draw, 0, sample call #, 1}, key = seed) % size.
+ * Returns the chosen slots; xq_dqn_train_replay consumes them on device. */
+int xq_replay_sample(xq_replay* r, int batch, int32_t* slots_host /* optional */);
+int xq_replay_get(xq_replay* r, int slot, uint8_t* board90, int32_t* action_to, float* reward, uint8_t* done,
+                  uint8_t* next_board90);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * xq_dqn — DQN (dqn.h:97-116) = qNetwork + targetNetwork (NeuralNetwork, dqn.h:42-95, dqn.cu), fp32 on MFMA.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct xq_dqn xq_dqn;
+
+enum { XQ_NET_ONLINE = 0, XQ_NET_TARGET = 1 };
+enum { XQ_BACKPROP_REFERENCE = 0,  /* bug-compatible hidden delta, dqn.cu:406-423 as written */
+       XQ_BACKPROP_TEXTBOOK = 1 };
+enum { XQ_TD_ONLINE_NET = 0,       /* max Q(s') from the ONLINE net — what ChessAI::train does (chessai.cpp:126-127) */
+       XQ_TD_TARGET_NET = 1 };     /* max Q(s') from the target net — DQN::train (dqn.cpp:166-167) */
+
+/* DQN::DQN(layerSizes, lr, gamma) (dqn.cpp:12-20) -> NeuralNetwork ctor (dqn.cu:14-57): W ~ U(-0.05,0.05) from a
+ * seeded generator, biases 0; target = copy of online.  layer_sizes[0] must be 1260 for the board-input fast path;
+ * any sizes work through the dense-state entry points. */
+int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, double gamma, uint64_t seed,
+                  void* hip_stream, xq_dqn** out);
+int xq_dqn_destroy(xq_dqn* d);
+int xq_dqn_num_params(const xq_dqn* d, size_t* n_weights, size_t* n_biases);
+/* host_weights / host_biases in the REFERENCE flat layout (row-major [out][in] per layer, layers concatenated,
+ * dqn.cu:112-140), fp64 like upstream.  set = copyToDevice() (dqn.cu:480-485), get = copyFromDevice() (:487-492). */
+int xq_dqn_set_params(xq_dqn* d, int which_net, const double* weights_host, const double* biases_host);
+int xq_dqn_get_params(xq_dqn* d, int which_net, double* weights_host, double* biases_host);
+/* DQN::getQValues / NeuralNetwork::forward (dqn.cpp:65-68, dqn.cu:199-260) for n dense states [n][layer_sizes[0]]
+ * -> q [n][layer_sizes[last]], fp64 at the boundary like upstream (computed in fp32). */
+int xq_dqn_forward(xq_dqn* d, int which_net, const double* states_host, int n, double* q_host);
+/* Same for n packed boards already in HBM ([n][12] u32): the one-hot of chessai.cpp:268-289 is never materialised.
+ * q_dev: [n][ldq] fp32, first `n_out` outputs per row (n_out <= layer_sizes[last]). */
+int xq_dqn_forward_boards_dev(xq_dqn* d, int which_net, const uint32_t* boards_dev, int n, int n_out,
+                              float* q_dev, int ldq);
+/* DQN::backpropagate(state, target, lr) / NeuralNetwork::backpropagate (dqn.cpp:59-62, dqn.cu:323-467) for a batch of
+ * n (state, target) pairs: gradients of all n samples are taken at the pre-update weights, summed, scaled by
+ * grad_scale and applied once (n = 1, grad_scale = 1 is exactly the upstream call).  mode = XQ_BACKPROP_*. */
+int xq_dqn_backpropagate(xq_dqn* d, const double* states_host, const double* targets_host, int n,
+                         double learning_rate, double grad_scale, int mode);
+/* DQN::updateTargetNetwork() (dqn.cpp:71-73) — copies the TRAINED device weights (upstream copies stale host
+ * vectors; documented divergence). */
+int xq_dqn_update_target(xq_dqn* d);
+/* DQN::saveModel / loadModel (dqn.cpp:76-154): raw LE fp64 weights, raw fp64 biases, BE u64 count, BE i32 sizes. */
+int xq_dqn_save_model(xq_dqn* d, const char* path);
+int xq_dqn_load_model(xq_dqn* d, const char* path);
+
+/* The TD step of ChessAI::train (chessai.cpp:122-131) / DQN::train (dqn.cpp:157-172) on a batch of transitions held
+ * in HBM:  y = done ? r : r + gamma * max_k Q_net(s')[k]  (max over ALL outputs);  target = Q(s) with entry
+ * action.to replaced by y;  backprop of 0.5*|Q(s)-target|^2.  Split in two so a multi-GPU caller can all-reduce
+ * the gradient buffer in between:
+ *   xq_dqn_td_grads  : forward + deltas + gradient reduction over the batch  -> compact gradient buffer (HBM)
+ *   xq_dqn_apply_grads: params -= lr * grad_scale * grads
+ * boards/next_boards: [n][12] u32, optionally gathered through slots_dev ([n] row indices, NULL = identity).
+ * td_net = XQ_TD_*.  loss_out_dev: optional, sum over the batch of 0.5*(Q(s,a)-y)^2. */
+int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards_dev, const uint32_t* next_boards_dev,
+                    const int32_t* action_to_dev, const float* reward_dev, const uint8_t* done_dev,
+                    const int32_t* slots_dev, int n, int td_net, int mode);
+int xq_dqn_apply_grads(xq_dqn* d, double learning_rate, double grad_scale);
+/* The flat gradient buffer xq_dqn_td_grads fills (fp32, *n_floats long) — what RCCL all-reduces over xGMI. */
+int xq_dqn_grad_buffer(xq_dqn* d, float** grads_dev, size_t* n_floats);
+/* Convenience: sample-free TD update straight from a replay ring (slots from the last xq_replay_sample). */
+int xq_dqn_td_grads_replay(xq_dqn* d, xq_replay* r, int batch, int td_net, int mode);
+/* Host-buffer TD step for tests: n transitions as 90-byte boards. Returns Q(s,a) and y per sample if non-NULL. */
+int xq_dqn_td_update_host(xq_dqn* d, int n, const uint8_t* boards90, const uint8_t* next_boards90,
+                          const int32_t* action_to, const float* reward, const uint8_t* done, int td_net, int mode,
+                          double learning_rate, double grad_scale, float* q_sa_out, float* y_out);
+/* Sum-of-squared TD error of the last xq_dqn_td_grads (synchronises). */
+int xq_dqn_last_loss(xq_dqn* d, double* loss);
+/* Per-kernel HIP-event timing of the last td_grads/forward call sequence, for bench.py (name -> ms, launches). */
+typedef struct { char name[48]; float ms; int launches; double flops; double bytes; } xq_kernel_stat;
+int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_stats, int* n_stats);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * xq_trainer — the ChessAI::train() loop (chessai.cpp:85-170) for n_games boards at once, on device.
+ *   collect : Q(s)[0..89] for every game -> xq_env_selfplay_step -> transitions into the replay ring
+ *   learn   : sample minibatch -> xq_dqn_td_grads  [caller may all-reduce xq_dqn_grad_buffer] -> apply
+ *   target sync every target_sync_interval learn steps (chessai.cpp:140 uses moveCount % 100).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct xq_trainer xq_trainer;
+typedef struct {
+    int n_games;
+    int layer_sizes[XQ_MAX_LAYERS + 1];
+    int n_sizes;
+    double learning_rate, gamma, epsilon;   /* chessai.h:48-49, chessai.cpp:106 */
+    int replay_capacity;                    /* 0 => on-policy: learn on the n_games transitions just collected (reference semantics) */
+    int minibatch;                          /* transitions per learn step (<= replay capacity; on-policy: n_games) */
+    int td_net;                             /* XQ_TD_* */
+    int backprop_mode;                      /* XQ_BACKPROP_* */
+    int target_sync_interval;               /* learn steps between updateTargetNetwork(); 0 = never */
+    int mean_gradient;                      /* 1: grad_scale = 1/(minibatch*world), 0: sum (grad_scale = 1) */
+    uint64_t seed;
+    uint32_t first_game_id;
+} xq_trainer_config;
+
+int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer** out);
+int xq_trainer_destroy(xq_trainer* t);
+int xq_trainer_env(xq_trainer* t, xq_env** env);
+int xq_trainer_dqn(xq_trainer* t, xq_dqn** dqn);
+int xq_trainer_replay(xq_trainer* t, xq_replay** replay);
+int xq_trainer_collect(xq_trainer* t);                       /* one ply in every game */
+int xq_trainer_learn_grads(xq_trainer* t);                   /* sample + gradients into the grad buffer */
+int xq_trainer_learn_apply(xq_trainer* t, int world_size);   /* SGD apply (+ target sync bookkeeping) */
+int xq_trainer_step(xq_trainer* t, int n_iterations);        /* collect + learn_grads + learn_apply, n times (single GPU) */
+int xq_trainer_counters(xq_trainer* t, uint64_t* env_steps, uint64_t* updates, uint64_t* episodes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XQ_CAPI_H */
