@@ -134,6 +134,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise XqError(3, f"{LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "or `make -C cn_chess_ai_amd/csrc`; there is no CPU fallback")
+    # torch bundles its own libamdhip64.so.7; importing it FIRST makes libxqhip bind to that same runtime instance
+    # (one HIP runtime per process: two instances cannot both own the GPU, and torch.distributed/RCCL must see the
+    # very allocations this library makes).  Without torch the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol

@@ -1,23 +1,850 @@
-// TEMPORARY stub — replaced by the real implementation
+// xq_dqn.hip — DQN = online + target NeuralNetwork on the CDNA4 matrix cores (fp32), batched.
+//
+// Reference: include/dqn.h:42-116, src/dqn.cpp, src/dqn.cu (fp64, batch 1, one thread per output neuron, a
+// cudaMalloc/H2D/launch/sync/D2H round trip per layer).  Here the whole TD step of a minibatch stays in HBM:
+//   layer 0      : the 1260-wide one-hot input (chessai.cpp:268-289) is never built — rows of W0^T are gathered by
+//                  (square, piece) straight from the packed board (<= 32 rows of 1 KB per sample, L2-resident);
+//   hidden / Q   : xq_gemm.cuh MFMA GEMMs with fused bias+tanh;
+//   max_a' Q(s') : the 8100-wide output GEMM never writes Q — its epilogue reduces max(z) per row (tanh is monotone);
+//   backward     : the TD target equals Q(s) except at action.to < 90 (chessai.cpp:122-128), so the output delta
+//                  lives in columns 0..95: delta GEMM with K = 96, weight-gradient GEMM with M = 96;
+//   layer-0 grad : one-hot^T x delta as an MFMA GEMM whose A operand is decoded from the packed boards on the fly;
+//   reductions over the batch are split-K into slabs + an ordered slab sum: bitwise reproducible, no float atomics.
+// Device parameter layout (one flat fp32 buffer per net): [W0^T (L0 x L1)] [W_1 .. W_out, reference layout
+// row-major [out][in], concatenated] [b_0 .. b_out].  Keeping layers >= 1 in the reference's flat order lets the
+// bug-compatible hidden delta (dqn.cu:406-423 as written: wrong stride, reads across layer boundaries) be expressed
+// as the same GEMM with a different base/leading dimension.
 #include "xq_internal.h"
-using namespace xq;
-extern "C" {
-int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, double gamma, uint64_t seed, void* hip_stream, xq_dqn** out) { return fail(XQ_ERR_RUNTIME, "xq_dqn_create: not implemented yet"); }
-int xq_dqn_destroy(xq_dqn* d) { return fail(XQ_ERR_RUNTIME, "xq_dqn_destroy: not implemented yet"); }
-int xq_dqn_num_params(const xq_dqn* d, size_t* n_weights, size_t* n_biases) { return fail(XQ_ERR_RUNTIME, "xq_dqn_num_params: not implemented yet"); }
-int xq_dqn_set_params(xq_dqn* d, int which_net, const double* weights_host, const double* biases_host) { return fail(XQ_ERR_RUNTIME, "xq_dqn_set_params: not implemented yet"); }
-int xq_dqn_get_params(xq_dqn* d, int which_net, double* weights_host, double* biases_host) { return fail(XQ_ERR_RUNTIME, "xq_dqn_get_params: not implemented yet"); }
-int xq_dqn_forward(xq_dqn* d, int which_net, const double* states_host, int n, double* q_host) { return fail(XQ_ERR_RUNTIME, "xq_dqn_forward: not implemented yet"); }
-int xq_dqn_forward_boards_dev(xq_dqn* d, int which_net, const uint32_t* boards_dev, int n, int n_out, float* q_dev, int ldq) { return fail(XQ_ERR_RUNTIME, "xq_dqn_forward_boards_dev: not implemented yet"); }
-int xq_dqn_backpropagate(xq_dqn* d, const double* states_host, const double* targets_host, int n, double learning_rate, double grad_scale, int mode) { return fail(XQ_ERR_RUNTIME, "xq_dqn_backpropagate: not implemented yet"); }
-int xq_dqn_update_target(xq_dqn* d) { return fail(XQ_ERR_RUNTIME, "xq_dqn_update_target: not implemented yet"); }
-int xq_dqn_save_model(xq_dqn* d, const char* path) { return fail(XQ_ERR_RUNTIME, "xq_dqn_save_model: not implemented yet"); }
-int xq_dqn_load_model(xq_dqn* d, const char* path) { return fail(XQ_ERR_RUNTIME, "xq_dqn_load_model: not implemented yet"); }
-int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards_dev, const uint32_t* next_boards_dev, const int32_t* action_to_dev, const float* reward_dev, const uint8_t* done_dev, const int32_t* slots_dev, int n, int td_net, int mode) { return fail(XQ_ERR_RUNTIME, "xq_dqn_td_grads: not implemented yet"); }
-int xq_dqn_apply_grads(xq_dqn* d, double learning_rate, double grad_scale) { return fail(XQ_ERR_RUNTIME, "xq_dqn_apply_grads: not implemented yet"); }
-int xq_dqn_grad_buffer(xq_dqn* d, float** grads_dev, size_t* n_floats) { return fail(XQ_ERR_RUNTIME, "xq_dqn_grad_buffer: not implemented yet"); }
-int xq_dqn_td_grads_replay(xq_dqn* d, xq_replay* r, int batch, int td_net, int mode) { return fail(XQ_ERR_RUNTIME, "xq_dqn_td_grads_replay: not implemented yet"); }
-int xq_dqn_td_update_host(xq_dqn* d, int n, const uint8_t* boards90, const uint8_t* next_boards90, const int32_t* action_to, const float* reward, const uint8_t* done, int td_net, int mode, double learning_rate, double grad_scale, float* q_sa_out, float* y_out) { return fail(XQ_ERR_RUNTIME, "xq_dqn_td_update_host: not implemented yet"); }
-int xq_dqn_last_loss(xq_dqn* d, double* loss) { return fail(XQ_ERR_RUNTIME, "xq_dqn_last_loss: not implemented yet"); }
-int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_stats, int* n_stats) { return fail(XQ_ERR_RUNTIME, "xq_dqn_kernel_stats: not implemented yet"); }
+#include "xq_gemm.cuh"
+
+#include <algorithm>
+#include <cmath>
+#include <random>
+
+struct xq_dqn {
+    int ns = 0, nl = 0;
+    int L[XQ_MAX_LAYERS + 1] = {0};
+    size_t nw = 0, nb = 0;
+    size_t wo[XQ_MAX_LAYERS] = {0}, bo[XQ_MAX_LAYERS] = {0};
+    double lr = 1e-3, gamma = 0.99;
+    uint64_t seed = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float* params[2] = {nullptr, nullptr};
+    // workspaces sized for `cap` samples
+    int cap = 0;
+    float* acts[XQ_MAX_LAYERS] = {nullptr};     // online hidden activations a_{l+1} = tanh(z_l), l = 0..nl-2
+    float* tacts[2] = {nullptr, nullptr};       // ping-pong chain for s' / inference
+    float* deltas[XQ_MAX_LAYERS] = {nullptr};   // delta_l of hidden layer l
+    float* d2 = nullptr;                        // [cap][96] output delta, columns 0..95
+    float* q90 = nullptr;                       // [cap][96]
+    float* partial = nullptr;                   // row-max partials
+    float* qsa = nullptr;
+    float* yv = nullptr;
+    float* lossv = nullptr;
+    int last_n = 0;
+    // gradients
+    float* grads_td = nullptr;  size_t n_grads_td = 0;
+    size_t g_w0 = 0, g_wh[XQ_MAX_LAYERS] = {0}, g_wout = 0, g_bh[XQ_MAX_LAYERS] = {0}, g_bout = 0;
+    float* grads_full = nullptr;
+    float* slabs = nullptr;  size_t slabs_cap = 0;
+    // dense API scratch
+    float* xdense = nullptr;  size_t xdense_cap = 0;
+    float* qfull = nullptr;   size_t qfull_cap = 0;
+    float* tfull = nullptr;   size_t tfull_cap = 0;
+    uint32_t* hb = nullptr;   size_t hb_cap = 0;     // host-batch staging: boards, next boards
+    int32_t* ha = nullptr; float* hr = nullptr; uint8_t* hd = nullptr;
+    xq::Profiler prof;
+
+    float* w0t(int net) const { return params[net]; }
+    float* wrest(int net) const { return params[net] + (size_t)L[0] * L[1]; }     // layers 1.. in reference flat order
+    float* wl(int net, int l) const { return l == 0 ? w0t(net) : wrest(net) + (wo[l] - wo[1]); }
+    float* bl(int net, int l) const { return params[net] + nw + bo[l]; }
+    int nout() const { return L[nl]; }
+    int hlast() const { return L[nl - 1]; }
+};
+
+namespace xq {
+
+Profiler* dqn_profiler(xq_dqn* d) { return &d->prof; }
+hipStream_t dqn_stream(xq_dqn* d) { return d->stream; }
+
+struct ProfScope {
+    Profiler& p; hipStream_t s; int h; double flops, bytes;
+    ProfScope(xq_dqn* d, const char* name, double fl, double by) : p(d->prof), s(d->stream), flops(fl), bytes(by) { h = p.begin(name, s); }
+    ~ProfScope() { p.end(h, s, flops, bytes); }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------
+
+// Layer 0 from packed boards: a_1 = tanh(b_0 + sum over occupied squares of W0^T[sq*14 + piece-1][:]).
+// One wave per sample; ascending square order = the reference's i-ascending accumulation with the zeros skipped.
+__global__ __launch_bounds__(256) void l0_forward_kernel(const uint32_t* __restrict__ boards, const int32_t* __restrict__ slots,
+                                                         int n, const float* __restrict__ W0T, const float* __restrict__ b0,
+                                                         int H, float* __restrict__ out) {
+    __shared__ int rows[4][96];
+    const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int b = (int)blockIdx.x * 4 + wid;
+    if (b >= n) return;
+    const int srow = slots ? slots[b] : b;
+    const uint32_t* bw = boards + (long long)srow * kBoardWords;
+    const int s0 = lane, s1 = 64 + lane;
+    const uint32_t n0 = (bw[s0 >> 3] >> (4 * (s0 & 7))) & 15u;
+    const uint32_t n1 = s1 < kSquares ? (bw[s1 >> 3] >> (4 * (s1 & 7))) & 15u : 0u;
+    const unsigned long long m0 = __ballot(n0 != 0), m1 = __ballot(n1 != 0);
+    const int c0 = __popcll(m0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (n0) rows[wid][__popcll(m0 & below)] = s0 * 14 + (int)n0 - 1;
+    if (n1) rows[wid][c0 + __popcll(m1 & below)] = s1 * 14 + (int)n1 - 1;
+    const int cnt = c0 + __popcll(m1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* o = out + (long long)b * H;
+    if ((H & 3) == 0) {
+        for (int col = lane * 4; col < H; col += 256) {
+            float4 acc = *reinterpret_cast<const float4*>(b0 + col);
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {
+                const float4 w0 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i] * H + col);
+                const float4 w1 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i + 1] * H + col);
+                const float4 w2 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i + 2] * H + col);
+                const float4 w3 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i + 3] * H + col);
+                acc.x = ((acc.x + w0.x) + w1.x) + w2.x + w3.x;
+                acc.y = ((acc.y + w0.y) + w1.y) + w2.y + w3.y;
+                acc.z = ((acc.z + w0.z) + w1.z) + w2.z + w3.z;
+                acc.w = ((acc.w + w0.w) + w1.w) + w2.w + w3.w;
+            }
+            for (; i < cnt; ++i) {
+                const float4 w = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i] * H + col);
+                acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
+            }
+            *reinterpret_cast<float4*>(o + col) = make_float4(tanhf(acc.x), tanhf(acc.y), tanhf(acc.z), tanhf(acc.w));
+        }
+    } else {
+        for (int col = lane; col < H; col += 64) {
+            float acc = b0[col];
+            for (int i = 0; i < cnt; ++i) acc += W0T[(long long)rows[wid][i] * H + col];
+            o[col] = tanhf(acc);
+        }
+    }
 }
+
+// TD target + output delta for one sample per wave (chessai.cpp:122-128 + outputLayerDeltaKernel dqn.cu:288-295).
+__global__ __launch_bounds__(256) void td_delta_kernel(int n, const int32_t* __restrict__ slots,
+                                                       const int32_t* __restrict__ action_to, const float* __restrict__ reward,
+                                                       const uint8_t* __restrict__ done, const float* __restrict__ a_last, int H,
+                                                       const float* __restrict__ w_out, const float* __restrict__ b_out,
+                                                       const float* __restrict__ partial, int n_partial, float gamma,
+                                                       float* __restrict__ d2, float* __restrict__ qsa, float* __restrict__ yv,
+                                                       float* __restrict__ lossv) {
+    const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int b = (int)blockIdx.x * 4 + wid;
+    if (b >= n) return;
+    const int s = slots ? slots[b] : b;
+    const int a = action_to[s];
+    float delta = 0.f, q = 0.f, y = 0.f;
+    if (a >= 0 && a < 96) {
+        float z = 0.f;
+        const float* wr = w_out + (long long)a * H;
+        const float* ar = a_last + (long long)b * H;
+        for (int i = lane; i < H; i += 64) z += wr[i] * ar[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+        z += b_out[a];
+        float zm = -__builtin_inff();
+        for (int t = lane; t < n_partial; t += 64) zm = fmaxf(zm, partial[(long long)t * n + b]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) zm = fmaxf(zm, __shfl_xor(zm, off, 64));
+        q = tanhf(z);
+        const float r = reward[s];
+        y = done[s] ? r : r + gamma * tanhf(zm);       // max_k tanh(z_k) = tanh(max_k z_k)
+        delta = (q - y) * (1.f - q * q);               // (a - target) * (1 - tanh(z)^2)
+    }
+    float* row = d2 + (long long)b * 96;
+    row[lane] = lane == a ? delta : 0.f;
+    if (lane < 32) row[64 + lane] = (64 + lane) == a ? delta : 0.f;
+    if (lane == 0) {
+        qsa[b] = q; yv[b] = y;
+        lossv[b] = (a >= 0 && a < 96) ? 0.5f * (q - y) * (q - y) : 0.f;
+    }
+}
+
+// dense output delta (general DQN::backpropagate target): d = (q - t) * (1 - q^2)
+__global__ void out_delta_dense_kernel(const float* __restrict__ q, const float* __restrict__ t, long long total, float* __restrict__ d) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float a = q[i];
+        d[i] = (a - t[i]) * (1.f - a * a);
+    }
+}
+
+// column sums of X[n][C] (bias gradients): partial[z][c] over row chunk z
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long long ld, int n, int C, int rows_per,
+                                                             float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int tx = (int)(threadIdx.x & 63), ty = (int)(threadIdx.x >> 6);
+    const int c = (int)blockIdx.x * 64 + tx;
+    const int r0 = (int)blockIdx.y * rows_per, r1 = min(n, r0 + rows_per);
+    float s = 0.f;
+    if (c < C)
+        for (int r = r0 + ty; r < r1; r += 4) s += X[(long long)r * ld + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) partial[(long long)blockIdx.y * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+// out[i] = sum_z slabs[z*stride + i], z ascending (deterministic)
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs, long long stride, long long len, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < nslabs; ++z) s += slabs[(long long)z * stride + i];
+        out[i] = s;
+    }
+}
+
+struct SegTable {
+    float* dst[16];
+    const float* src[16];
+    long long len[16];
+    int nseg;
+};
+// SGD: dst -= alpha * src per segment (updateWeightsBiasesKernel dqn.cu:310-319, batched form)
+__global__ void sgd_segments_kernel(SegTable t, float alpha) {
+    const int sgm = (int)blockIdx.y;
+    if (sgm >= t.nseg) return;
+    float* d = t.dst[sgm];
+    const float* s = t.src[sgm];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < t.len[sgm]; i += (long long)gridDim.x * blockDim.x)
+        d[i] -= alpha * s[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------------------------------------------
+static inline int vec_ok(const void* p, long long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }
+
+template <int AL, int BL, int EPI>
+static int launch_gemm(xq_dqn* d, GemmArgs g, int splits, const char* name, int* used_splits = nullptr) {
+    if (used_splits) *used_splits = 0;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "empty GEMM %s (%d x %d x %d)", name, g.M, g.N, g.K);
+    g.a_vec = (AL == L_ONEHOT) ? 0 : vec_ok(g.A, g.lda);
+    g.b_vec = vec_ok(g.B, g.ldb);
+    if (splits < 1) splits = 1;
+    g.k_chunk = round_up((g.K + splits - 1) / splits, GBK);
+    splits = (g.K + g.k_chunk - 1) / g.k_chunk;
+    if (splits < 1) splits = 1;
+    dim3 grid((g.M + GBM - 1) / GBM, (g.N + GBN - 1) / GBN, splits);
+    ProfScope ps(d, name, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI>), grid, dim3(256), 0, d->stream, g);
+    XQ_HIP(hipGetLastError());
+    if (used_splits) *used_splits = splits;
+    return XQ_OK;
+}
+#define XQ_GEMM(expr) XQ_TRY(expr)
+
+static int ensure_slabs(xq_dqn* d, size_t floats) {
+    if (floats <= d->slabs_cap) return XQ_OK;
+    if (d->slabs) { XQ_HIP(hipStreamSynchronize(d->stream)); XQ_HIP(hipFree(d->slabs)); }
+    XQ_HIP(hipMalloc(&d->slabs, floats * sizeof(float)));
+    d->slabs_cap = floats;
+    return XQ_OK;
+}
+
+static int grow(float** p, size_t* cap, size_t floats, hipStream_t s) {
+    if (floats <= *cap) return XQ_OK;
+    if (*p) { XQ_HIP(hipStreamSynchronize(s)); XQ_HIP(hipFree(*p)); }
+    XQ_HIP(hipMalloc(p, floats * sizeof(float)));
+    *cap = floats;
+    return XQ_OK;
+}
+
+static int ensure_capacity(xq_dqn* d, int n) {
+    if (n <= d->cap) return XQ_OK;
+    XQ_HIP(hipStreamSynchronize(d->stream));
+    const size_t cap = (size_t)n;
+    int maxh = 0;
+    for (int l = 0; l + 1 < d->nl; ++l) maxh = std::max(maxh, d->L[l + 1]);
+    for (int l = 0; l + 1 < d->nl; ++l) {
+        if (d->acts[l]) XQ_HIP(hipFree(d->acts[l]));
+        if (d->deltas[l]) XQ_HIP(hipFree(d->deltas[l]));
+        XQ_HIP(hipMalloc(&d->acts[l], cap * d->L[l + 1] * sizeof(float)));
+        XQ_HIP(hipMalloc(&d->deltas[l], cap * d->L[l + 1] * sizeof(float)));
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (d->tacts[i]) XQ_HIP(hipFree(d->tacts[i]));
+        XQ_HIP(hipMalloc(&d->tacts[i], cap * (size_t)maxh * sizeof(float)));
+    }
+    const int ntn = (d->nout() + GBN - 1) / GBN;
+    float** bufs[] = {&d->d2, &d->q90, &d->partial, &d->qsa, &d->yv, &d->lossv};
+    const size_t sizes[] = {cap * 96, cap * 96, cap * (size_t)ntn * 2, cap, cap, cap};
+    for (int i = 0; i < 6; ++i) {
+        if (*bufs[i]) XQ_HIP(hipFree(*bufs[i]));
+        XQ_HIP(hipMalloc(bufs[i], sizes[i] * sizeof(float)));
+    }
+    d->cap = n;
+    return XQ_OK;
+}
+
+// a_1 .. a_{nl-1} for n packed boards; outs[l] receives a_{l+1}
+static int chain_boards(xq_dqn* d, int net, const uint32_t* boards, const int32_t* slots, int n, float* const* outs) {
+    if (d->L[0] != kStateSize) return fail(XQ_ERR_INVALID_ARGUMENT, "board input needs layer_sizes[0] == 1260 (got %d)", d->L[0]);
+    {
+        const int H = d->L[1];
+        ProfScope ps(d, "l0_forward_gather", 2.0 * n * 32 * H, (double)n * (48 + 32.0 * H * 4 + H * 4));
+        hipLaunchKernelGGL(l0_forward_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, boards, slots, n, d->w0t(net),
+                           d->bl(net, 0), H, outs[0]);
+        XQ_HIP(hipGetLastError());
+    }
+    for (int l = 1; l + 1 < d->nl; ++l) {
+        GemmArgs g; memset(&g, 0, sizeof g);
+        g.M = n; g.N = d->L[l + 1]; g.K = d->L[l];
+        g.A = outs[l - 1]; g.lda = d->L[l];
+        g.B = d->wl(net, l); g.ldb = d->L[l];
+        g.C = outs[l]; g.ldc = d->L[l + 1];
+        g.bias = d->bl(net, l);
+        XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH>(d, g, 1, "gemm_hidden_fwd")));
+    }
+    return XQ_OK;
+}
+
+// Q head on the first n_out outputs: q[m][0..n_out) = tanh(W_out[0:n_out] a_last + b_out)
+static int q_head(xq_dqn* d, int net, const float* a_last, int n, int n_out, float* q, int ldq, const char* name) {
+    GemmArgs g; memset(&g, 0, sizeof g);
+    g.M = n; g.N = n_out; g.K = d->hlast();
+    g.A = a_last; g.lda = d->hlast();
+    g.B = d->wl(net, d->nl - 1); g.ldb = d->hlast();
+    g.C = q; g.ldc = ldq;
+    g.bias = d->bl(net, d->nl - 1);
+    XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH>(d, g, 1, name)));
+    return XQ_OK;
+}
+
+int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride) {
+    XQ_TRY(ensure_capacity(d, n));
+    if (d->nout() < 96) return fail(XQ_ERR_INVALID_ARGUMENT, "self-play select needs >= 96 outputs");
+    float* outs[XQ_MAX_LAYERS];
+    for (int l = 0; l + 1 < d->nl; ++l) outs[l] = d->acts[l];
+    XQ_TRY(chain_boards(d, XQ_NET_ONLINE, boards_dev, nullptr, n, outs));
+    XQ_TRY(q_head(d, XQ_NET_ONLINE, outs[d->nl - 2], n, 96, d->q90, 96, "gemm_q90_select"));
+    *q90_dev = d->q90;
+    *q_stride = 96;
+    return XQ_OK;
+}
+
+// conditions under which dqn.cu:406-423 as written stays inside its buffers (same as oracle/xq_oracle.c)
+static int check_reference_topology(const xq_dqn* d) {
+    for (int l = d->nl - 2; l >= 0; --l) {
+        const int inputSize = d->L[l + 1], outputSize = d->L[l];
+        if (d->L[l + 2] < inputSize || outputSize < d->L[l + 1] ||
+            d->wo[l + 1] + (size_t)(inputSize - 1) * outputSize + (size_t)(d->L[l + 1] - 1) >= d->nw)
+            return fail(XQ_ERR_UNDEFINED_UPSTREAM,
+                        "bug-compatible backprop reads out of bounds upstream for this topology (layer %d)", l);
+    }
+    return XQ_OK;
+}
+
+// hidden deltas l = nl-2 .. 0 from the output-side delta `dnext` ([n][ld_next], only the first k_nz columns can be
+// non-zero).  reference mode: delta_l = (dnext[:, :L[l+1]] x View) * (1-a^2), View[i][idx] = Wflat[wo[l+1] + i*L[l] + idx];
+// textbook: View[k][idx] = W_{l+1}[k][idx], k < L[l+2].
+static int hidden_deltas(xq_dqn* d, int n, const float* dnext, int ld_next, int k_nz, int mode) {
+    const float* up = dnext;
+    int ld_up = ld_next, nz = k_nz;
+    for (int l = d->nl - 2; l >= 0; --l) {
+        GemmArgs g; memset(&g, 0, sizeof g);
+        g.M = n; g.N = d->L[l + 1];
+        const int kfull = (mode == XQ_BACKPROP_REFERENCE) ? d->L[l + 1] : d->L[l + 2];
+        g.K = std::min(kfull, nz);
+        g.A = up; g.lda = ld_up;
+        g.B = d->wrest(XQ_NET_ONLINE) + (d->wo[l + 1] - d->wo[1]);
+        g.ldb = (mode == XQ_BACKPROP_REFERENCE) ? d->L[l] : d->L[l + 1];
+        g.C = d->deltas[l]; g.ldc = d->L[l + 1];
+        g.H = d->acts[l]; g.ldh = d->L[l + 1];
+        XQ_GEMM((launch_gemm<L_KCONTIG, L_MCONTIG, EPI_DELTA>(d, g, 1, "gemm_hidden_delta")));
+        up = d->deltas[l]; ld_up = d->L[l + 1]; nz = d->L[l + 1];
+    }
+    return XQ_OK;
+}
+
+static int pick_splits(int M, int N, int K) {
+    const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
+    int s = (512 + tiles - 1) / tiles;
+    s = std::min(s, std::max(1, K / 64));
+    return std::max(1, std::min(s, 256));
+}
+
+// dst[M][N] = sum over the batch: A(m,k) B(k,n), split-K slabs + ordered reduction
+template <int AL>
+static int grad_gemm(xq_dqn* d, GemmArgs g, float* dst, const char* name) {
+    int splits = pick_splits(g.M, g.N, g.K);
+    const long long len = (long long)g.M * g.N;
+    if (splits > 1) {
+        XQ_TRY(ensure_slabs(d, (size_t)splits * (size_t)len));
+        g.C = d->slabs; g.ldc = g.N; g.slab_stride = len;
+    } else {
+        g.C = dst; g.ldc = g.N; g.slab_stride = 0;
+    }
+    int used = 0;
+    XQ_TRY((launch_gemm<AL, L_MCONTIG, EPI_STORE>(d, g, splits, name, &used)));
+    if (splits > 1) {
+        ProfScope ps(d, "reduce_slabs", (double)used * len, 4.0 * (used + 1) * len);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)std::min<long long>((len + 255) / 256, 2048)), dim3(256), 0,
+                           d->stream, d->slabs, used, len, len, dst);
+        XQ_HIP(hipGetLastError());
+    }
+    return XQ_OK;
+}
+
+static int bias_grad(xq_dqn* d, const float* X, long long ld, int n, int C, float* dst) {
+    const int R = std::max(1, std::min(64, n / 64));
+    const int rows_per = (n + R - 1) / R;
+    XQ_TRY(ensure_slabs(d, (size_t)R * C));
+    ProfScope ps(d, "bias_grad_colsum", (double)n * C, 4.0 * n * C);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, R), dim3(256), 0, d->stream, X, ld, n, C, rows_per, d->slabs);
+    XQ_HIP(hipGetLastError());
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((C + 255) / 256), dim3(256), 0, d->stream, d->slabs, R, (long long)C,
+                       (long long)C, dst);
+    XQ_HIP(hipGetLastError());
+    return XQ_OK;
+}
+
+static int sgd_apply(xq_dqn* d, const SegTable& t, double alpha) {
+    long long mx = 0;
+    for (int i = 0; i < t.nseg; ++i) mx = std::max(mx, t.len[i]);
+    const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>((mx + 255) / 256, 1024));
+    ProfScope ps(d, "sgd_apply", 0, 0);
+    hipLaunchKernelGGL(sgd_segments_kernel, dim3(bx, t.nseg), dim3(256), 0, d->stream, t, (float)alpha);
+    XQ_HIP(hipGetLastError());
+    return XQ_OK;
+}
+
+static void layout_td_grads(xq_dqn* d) {
+    size_t off = 0;
+    d->g_w0 = off; off += (size_t)d->L[0] * d->L[1];
+    for (int l = 1; l + 1 < d->nl; ++l) { d->g_wh[l] = off; off += (size_t)d->L[l] * d->L[l + 1]; }
+    d->g_wout = off; off += (size_t)96 * d->hlast();
+    for (int l = 0; l + 1 < d->nl; ++l) { d->g_bh[l] = off; off += (size_t)d->L[l + 1]; }
+    d->g_bout = off; off += 96;
+    d->n_grads_td = off;
+}
+
+}  // namespace xq
+
+using namespace xq;
+
+// =================================================================================================================
+// C ABI — dqn
+// =================================================================================================================
+extern "C" {
+
+int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, double gamma, uint64_t seed, void* hip_stream,
+                  xq_dqn** out) {
+    if (!out || !layer_sizes) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_create: null pointer");
+    if (n_sizes < 2) return fail(XQ_ERR_INVALID_ARGUMENT, "NeuralNetwork must have at least two layers (input and output).");
+    if (n_sizes < 3 || n_sizes > XQ_MAX_LAYERS + 1)
+        return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn supports 1..%d hidden layers (got %d sizes)", XQ_MAX_LAYERS - 1, n_sizes);
+    for (int i = 0; i < n_sizes; ++i)
+        if (layer_sizes[i] <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "layer size must be positive");
+    int c = 0;
+    XQ_TRY(xq_device_count(&c));
+    if (c == 0) return fail(XQ_ERR_NO_DEVICE, "no HIP device: libxqhip has no CPU fallback");
+    xq_dqn* d = new xq_dqn();
+    d->ns = n_sizes; d->nl = n_sizes - 1;
+    for (int i = 0; i < n_sizes; ++i) d->L[i] = layer_sizes[i];
+    for (int l = 0; l < d->nl; ++l) {                       // offsets, dqn.cu:125-140
+        d->wo[l] = d->nw; d->bo[l] = d->nb;
+        d->nw += (size_t)d->L[l] * d->L[l + 1];
+        d->nb += (size_t)d->L[l + 1];
+    }
+    d->lr = learning_rate; d->gamma = gamma; d->seed = seed;
+    if (hip_stream) d->stream = (hipStream_t)hip_stream;
+    else { XQ_HIP(hipStreamCreate(&d->stream)); d->own_stream = true; }
+    for (int i = 0; i < 2; ++i) XQ_HIP(hipMalloc(&d->params[i], (d->nw + d->nb) * sizeof(float)));
+    layout_td_grads(d);
+    XQ_HIP(hipMalloc(&d->grads_td, d->n_grads_td * sizeof(float)));
+    XQ_HIP(hipMemsetAsync(d->grads_td, 0, d->n_grads_td * sizeof(float), d->stream));
+    // initializeHostWeightsAndBiases (dqn.cu:96-123): U(-0.05, 0.05) in [layer][out][in] order, biases 0
+    std::vector<double> w(d->nw), b(d->nb, 0.0);
+    std::mt19937_64 gen(seed);
+    std::uniform_real_distribution<double> dis(-0.05, 0.05);
+    for (size_t i = 0; i < d->nw; ++i) w[i] = dis(gen);
+    *out = d;
+    XQ_TRY(xq_dqn_set_params(d, XQ_NET_ONLINE, w.data(), b.data()));
+    return xq_dqn_update_target(d);                          // DQN ctor, dqn.cpp:18
+}
+
+int xq_dqn_destroy(xq_dqn* d) {
+    if (!d) return XQ_OK;
+    hipStreamSynchronize(d->stream);
+    for (int i = 0; i < 2; ++i) { hipFree(d->params[i]); hipFree(d->tacts[i]); }
+    for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts[l]); hipFree(d->deltas[l]); }
+    hipFree(d->d2); hipFree(d->q90); hipFree(d->partial); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
+    hipFree(d->grads_td); hipFree(d->grads_full); hipFree(d->slabs); hipFree(d->xdense); hipFree(d->qfull); hipFree(d->tfull);
+    hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
+    d->prof.collect();
+    if (d->own_stream) hipStreamDestroy(d->stream);
+    delete d;
+    return XQ_OK;
+}
+
+int xq_dqn_num_params(const xq_dqn* d, size_t* nw, size_t* nb) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    if (nw) *nw = d->nw;
+    if (nb) *nb = d->nb;
+    return XQ_OK;
+}
+
+int xq_dqn_set_params(xq_dqn* d, int net, const double* w, const double* b) {
+    if (!d || !w || !b || net < 0 || net > 1) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_set_params: bad argument");
+    std::vector<float> p(d->nw + d->nb);
+    const int L0 = d->L[0], L1 = d->L[1];
+    for (int j = 0; j < L1; ++j)
+        for (int i = 0; i < L0; ++i) p[(size_t)i * L1 + j] = (float)w[(size_t)j * L0 + i];     // W0 [out][in] -> W0^T
+    for (size_t i = d->wo[1]; i < d->nw; ++i) p[i] = (float)w[i];
+    for (size_t i = 0; i < d->nb; ++i) p[d->nw + i] = (float)b[i];
+    XQ_HIP(hipStreamSynchronize(d->stream));
+    XQ_HIP(hipMemcpy(d->params[net], p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+    return XQ_OK;
+}
+
+int xq_dqn_get_params(xq_dqn* d, int net, double* w, double* b) {
+    if (!d || net < 0 || net > 1) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_get_params: bad argument");
+    std::vector<float> p(d->nw + d->nb);
+    XQ_HIP(hipStreamSynchronize(d->stream));
+    XQ_HIP(hipMemcpy(p.data(), d->params[net], p.size() * sizeof(float), hipMemcpyDeviceToHost));
+    const int L0 = d->L[0], L1 = d->L[1];
+    if (w) {
+        for (int j = 0; j < L1; ++j)
+            for (int i = 0; i < L0; ++i) w[(size_t)j * L0 + i] = (double)p[(size_t)i * L1 + j];
+        for (size_t i = d->wo[1]; i < d->nw; ++i) w[i] = (double)p[i];
+    }
+    if (b) for (size_t i = 0; i < d->nb; ++i) b[i] = (double)p[d->nw + i];
+    return XQ_OK;
+}
+
+int xq_dqn_update_target(xq_dqn* d) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    ProfScope ps(d, "target_sync_copy", 0, 8.0 * (d->nw + d->nb));
+    XQ_HIP(hipMemcpyAsync(d->params[1], d->params[0], (d->nw + d->nb) * sizeof(float), hipMemcpyDeviceToDevice, d->stream));
+    return XQ_OK;
+}
+
+// dense-state chain: a_1 via GEMM against W0^T; outs as in chain_boards
+static int chain_dense(xq_dqn* d, int net, const float* x, int n, float* const* outs) {
+    GemmArgs g; memset(&g, 0, sizeof g);
+    g.M = n; g.N = d->L[1]; g.K = d->L[0];
+    g.A = x; g.lda = d->L[0];
+    g.B = d->w0t(net); g.ldb = d->L[1];
+    g.C = outs[0]; g.ldc = d->L[1];
+    g.bias = d->bl(net, 0);
+    XQ_GEMM((launch_gemm<L_KCONTIG, L_MCONTIG, EPI_BIAS_TANH>(d, g, 1, "gemm_l0_dense_fwd")));
+    for (int l = 1; l + 1 < d->nl; ++l) {
+        GemmArgs h; memset(&h, 0, sizeof h);
+        h.M = n; h.N = d->L[l + 1]; h.K = d->L[l];
+        h.A = outs[l - 1]; h.lda = d->L[l];
+        h.B = d->wl(net, l); h.ldb = d->L[l];
+        h.C = outs[l]; h.ldc = d->L[l + 1];
+        h.bias = d->bl(net, l);
+        XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH>(d, h, 1, "gemm_hidden_fwd")));
+    }
+    return XQ_OK;
+}
+
+static int upload_dense(xq_dqn* d, const double* src, size_t count, float** dev, size_t* cap) {
+    XQ_TRY(grow(dev, cap, count, d->stream));
+    std::vector<float> tmp(count);
+    for (size_t i = 0; i < count; ++i) tmp[i] = (float)src[i];
+    XQ_HIP(hipStreamSynchronize(d->stream));
+    XQ_HIP(hipMemcpy(*dev, tmp.data(), count * sizeof(float), hipMemcpyHostToDevice));
+    return XQ_OK;
+}
+
+int xq_dqn_forward(xq_dqn* d, int net, const double* states, int n, double* q_host) {
+    if (!d || !states || !q_host || n <= 0 || net < 0 || net > 1)
+        return fail(XQ_ERR_INVALID_ARGUMENT, "Input size does not match network input layer size.");
+    XQ_TRY(ensure_capacity(d, n));
+    XQ_TRY(upload_dense(d, states, (size_t)n * d->L[0], &d->xdense, &d->xdense_cap));
+    XQ_TRY(grow(&d->qfull, &d->qfull_cap, (size_t)n * d->nout(), d->stream));
+    float* outs[XQ_MAX_LAYERS];
+    for (int l = 0; l + 1 < d->nl; ++l) outs[l] = d->acts[l];
+    XQ_TRY(chain_dense(d, net, d->xdense, n, outs));
+    XQ_TRY(q_head(d, net, outs[d->nl - 2], n, d->nout(), d->qfull, d->nout(), "gemm_q_full"));
+    std::vector<float> q((size_t)n * d->nout());
+    XQ_HIP(hipMemcpyAsync(q.data(), d->qfull, q.size() * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+    XQ_HIP(hipStreamSynchronize(d->stream));
+    for (size_t i = 0; i < q.size(); ++i) q_host[i] = (double)q[i];
+    return XQ_OK;
+}
+
+int xq_dqn_forward_boards_dev(xq_dqn* d, int net, const uint32_t* boards_dev, int n, int n_out, float* q_dev, int ldq) {
+    if (!d || !boards_dev || !q_dev || n <= 0 || net < 0 || net > 1 || n_out <= 0 || n_out > d->nout() || ldq < n_out)
+        return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_forward_boards_dev: bad argument");
+    XQ_TRY(ensure_capacity(d, n));
+    float* outs[XQ_MAX_LAYERS];
+    for (int l = 0; l + 1 < d->nl; ++l) outs[l] = d->acts[l];
+    XQ_TRY(chain_boards(d, net, boards_dev, nullptr, n, outs));
+    return q_head(d, net, outs[d->nl - 2], n, n_out, q_dev, ldq, n_out <= 96 ? "gemm_q90_select" : "gemm_q_full");
+}
+
+int xq_dqn_backpropagate(xq_dqn* d, const double* states, const double* targets, int n, double lr, double grad_scale, int mode) {
+    if (!d || !states || !targets || n <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "Input size does not match network input layer size.");
+    if (mode != XQ_BACKPROP_REFERENCE && mode != XQ_BACKPROP_TEXTBOOK) return fail(XQ_ERR_INVALID_ARGUMENT, "bad backprop mode");
+    if (mode == XQ_BACKPROP_REFERENCE) XQ_TRY(check_reference_topology(d));
+    XQ_TRY(ensure_capacity(d, n));
+    const int NO = d->nout();
+    XQ_TRY(upload_dense(d, states, (size_t)n * d->L[0], &d->xdense, &d->xdense_cap));
+    XQ_TRY(upload_dense(d, targets, (size_t)n * NO, &d->tfull, &d->tfull_cap));
+    XQ_TRY(grow(&d->qfull, &d->qfull_cap, (size_t)n * NO, d->stream));
+    if (!d->grads_full) XQ_HIP(hipMalloc(&d->grads_full, (d->nw + d->nb) * sizeof(float)));
+    float* outs[XQ_MAX_LAYERS];
+    for (int l = 0; l + 1 < d->nl; ++l) outs[l] = d->acts[l];
+    XQ_TRY(chain_dense(d, XQ_NET_ONLINE, d->xdense, n, outs));
+    XQ_TRY(q_head(d, XQ_NET_ONLINE, outs[d->nl - 2], n, NO, d->qfull, NO, "gemm_q_full"));
+    const long long total = (long long)n * NO;
+    hipLaunchKernelGGL(out_delta_dense_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
+                       d->stream, d->qfull, d->tfull, total, d->tfull);      // delta overwrites the target buffer
+    XQ_HIP(hipGetLastError());
+    const float* dout = d->tfull;
+    XQ_TRY(hidden_deltas(d, n, dout, NO, NO, mode));
+    // gradients, full layout = parameter layout
+    float* gw = d->grads_full;
+    float* gb = d->grads_full + d->nw;
+    {   // layer 0: gW0^T[in][out] = X^T delta_0
+        GemmArgs g; memset(&g, 0, sizeof g);
+        g.M = d->L[0]; g.N = d->L[1]; g.K = n;
+        g.A = d->xdense; g.lda = d->L[0];
+        g.B = d->deltas[0]; g.ldb = d->L[1];
+        XQ_TRY((grad_gemm<L_MCONTIG>(d, g, gw, "gemm_grad_l0_dense")));
+        XQ_TRY(bias_grad(d, d->deltas[0], d->L[1], n, d->L[1], gb + d->bo[0]));
+    }
+    for (int l = 1; l < d->nl; ++l) {   // gW_l[out][in] = delta_l^T a_l
+        const float* dl = (l == d->nl - 1) ? dout : d->deltas[l];
+        const int ldd = (l == d->nl - 1) ? NO : d->L[l + 1];
+        GemmArgs g; memset(&g, 0, sizeof g);
+        g.M = d->L[l + 1]; g.N = d->L[l]; g.K = n;
+        g.A = dl; g.lda = ldd;
+        g.B = d->acts[l - 1]; g.ldb = d->L[l];
+        XQ_TRY((grad_gemm<L_MCONTIG>(d, g, gw + d->wo[l], "gemm_grad_dense")));
+        XQ_TRY(bias_grad(d, dl, ldd, n, d->L[l + 1], gb + d->bo[l]));
+    }
+    SegTable t; memset(&t, 0, sizeof t);
+    t.nseg = 1; t.dst[0] = d->params[0]; t.src[0] = d->grads_full; t.len[0] = (long long)(d->nw + d->nb);
+    XQ_TRY(sgd_apply(d, t, lr * grad_scale));
+    XQ_HIP(hipStreamSynchronize(d->stream));
+    return XQ_OK;
+}
+
+int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boards, const int32_t* action_to,
+                    const float* reward, const uint8_t* done, const int32_t* slots, int n, int td_net, int mode) {
+    if (!d || !boards || !next_boards || !action_to || !reward || !done || n <= 0)
+        return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_td_grads: bad argument");
+    if (td_net != XQ_TD_ONLINE_NET && td_net != XQ_TD_TARGET_NET) return fail(XQ_ERR_INVALID_ARGUMENT, "bad td_net");
+    if (mode != XQ_BACKPROP_REFERENCE && mode != XQ_BACKPROP_TEXTBOOK) return fail(XQ_ERR_INVALID_ARGUMENT, "bad backprop mode");
+    if (d->nout() < 96) return fail(XQ_ERR_INVALID_ARGUMENT, "TD path needs >= 96 outputs (action.to indexes outputs 0..89)");
+    if (mode == XQ_BACKPROP_REFERENCE) XQ_TRY(check_reference_topology(d));
+    XQ_TRY(ensure_capacity(d, n));
+    const int nl = d->nl, Hl = d->hlast(), NO = d->nout();
+    // 1. s' chain on the TD net, row max of the full output layer (never written to HBM)
+    float* touts[XQ_MAX_LAYERS];
+    for (int l = 0; l + 1 < nl; ++l) touts[l] = d->tacts[l & 1];
+    XQ_TRY(chain_boards(d, td_net, next_boards, slots, n, touts));
+    const int ntn = (NO + GBN - 1) / GBN;
+    {
+        GemmArgs g; memset(&g, 0, sizeof g);
+        g.M = n; g.N = NO; g.K = Hl;
+        g.A = touts[nl - 2]; g.lda = Hl;
+        g.B = d->wl(td_net, nl - 1); g.ldb = Hl;
+        g.bias = d->bl(td_net, nl - 1);
+        g.partial = d->partial;
+        XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_ROWMAX>(d, g, 1, "gemm_qmax_rowmax")));
+    }
+    // 2. s chain on the online net (activations kept)
+    float* outs[XQ_MAX_LAYERS];
+    for (int l = 0; l + 1 < nl; ++l) outs[l] = d->acts[l];
+    XQ_TRY(chain_boards(d, XQ_NET_ONLINE, boards, slots, n, outs));
+    // 3. Q(s, a), target, output delta
+    {
+        ProfScope ps(d, "td_target_delta", 2.0 * n * Hl, (double)n * (Hl * 8 + ntn * 8 + 96 * 4));
+        hipLaunchKernelGGL(td_delta_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, n, slots, action_to, reward, done,
+                           outs[nl - 2], Hl, d->wl(XQ_NET_ONLINE, nl - 1), d->bl(XQ_NET_ONLINE, nl - 1), d->partial, ntn * 2,
+                           (float)d->gamma, d->d2, d->qsa, d->yv, d->lossv);
+        XQ_HIP(hipGetLastError());
+    }
+    d->last_n = n;
+    // 4. hidden deltas
+    XQ_TRY(hidden_deltas(d, n, d->d2, 96, 96, mode));
+    // 5. gradients (compact layout)
+    float* G = d->grads_td;
+    {   // output layer rows 0..95
+        GemmArgs g; memset(&g, 0, sizeof g);
+        g.M = 96; g.N = Hl; g.K = n;
+        g.A = d->d2; g.lda = 96;
+        g.B = outs[nl - 2]; g.ldb = Hl;
+        XQ_TRY((grad_gemm<L_MCONTIG>(d, g, G + d->g_wout, "gemm_grad_out96")));
+        XQ_TRY(bias_grad(d, d->d2, 96, n, 96, G + d->g_bout));
+    }
+    for (int l = nl - 2; l >= 1; --l) {
+        GemmArgs g; memset(&g, 0, sizeof g);
+        g.M = d->L[l + 1]; g.N = d->L[l]; g.K = n;
+        g.A = d->deltas[l]; g.lda = d->L[l + 1];
+        g.B = outs[l - 1]; g.ldb = d->L[l];
+        XQ_TRY((grad_gemm<L_MCONTIG>(d, g, G + d->g_wh[l], "gemm_grad_hidden")));
+        XQ_TRY(bias_grad(d, d->deltas[l], d->L[l + 1], n, d->L[l + 1], G + d->g_bh[l]));
+    }
+    {   // layer 0: one-hot^T x delta_0, A decoded from the packed boards
+        GemmArgs g; memset(&g, 0, sizeof g);
+        g.M = d->L[0]; g.N = d->L[1]; g.K = n;
+        g.boards = boards; g.slots = slots;
+        g.A = nullptr; g.lda = 0;
+        g.B = d->deltas[0]; g.ldb = d->L[1];
+        XQ_TRY((grad_gemm<L_ONEHOT>(d, g, G + d->g_w0, "gemm_grad_l0_onehot")));
+        XQ_TRY(bias_grad(d, d->deltas[0], d->L[1], n, d->L[1], G + d->g_bh[0]));
+    }
+    return XQ_OK;
+}
+
+int xq_dqn_apply_grads(xq_dqn* d, double lr, double grad_scale) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    SegTable t; memset(&t, 0, sizeof t);
+    const float* G = d->grads_td;
+    int k = 0;
+    t.dst[k] = d->w0t(0); t.src[k] = G + d->g_w0; t.len[k] = (long long)d->L[0] * d->L[1]; ++k;
+    for (int l = 1; l + 1 < d->nl; ++l) { t.dst[k] = d->wl(0, l); t.src[k] = G + d->g_wh[l]; t.len[k] = (long long)d->L[l] * d->L[l + 1]; ++k; }
+    t.dst[k] = d->wl(0, d->nl - 1); t.src[k] = G + d->g_wout; t.len[k] = 96LL * d->hlast(); ++k;
+    // hidden biases are contiguous in both layouts
+    t.dst[k] = d->bl(0, 0); t.src[k] = G + d->g_bh[0]; t.len[k] = (long long)(d->bo[d->nl - 1]); ++k;
+    t.dst[k] = d->bl(0, d->nl - 1); t.src[k] = G + d->g_bout; t.len[k] = 96; ++k;
+    t.nseg = k;
+    return sgd_apply(d, t, lr * grad_scale);
+}
+
+int xq_dqn_grad_buffer(xq_dqn* d, float** grads_dev, size_t* n_floats) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    if (grads_dev) *grads_dev = d->grads_td;
+    if (n_floats) *n_floats = d->n_grads_td;
+    return XQ_OK;
+}
+
+int xq_dqn_td_grads_replay(xq_dqn* d, xq_replay* r, int batch, int td_net, int mode) {
+    if (!d || !r) return fail(XQ_ERR_INVALID_ARGUMENT, "null handle");
+    const int32_t* slots = nullptr;
+    if (batch > 0) {
+        if (r->last_batch != batch || !r->slots_dev) return fail(XQ_ERR_INVALID_ARGUMENT, "call xq_replay_sample(batch) first");
+        slots = r->slots_dev;
+    } else {
+        batch = r->size;       // identity over the filled part of the ring (on-policy use)
+    }
+    if (batch <= 0) return fail(XQ_ERR_RUNTIME, "replay is empty");
+    return xq_dqn_td_grads(d, r->dev.boards, r->dev.next_boards, r->dev.action_to, r->dev.reward, r->dev.done, slots, batch,
+                           td_net, mode);
+}
+
+int xq_dqn_td_update_host(xq_dqn* d, int n, const uint8_t* boards90, const uint8_t* next_boards90, const int32_t* action_to,
+                          const float* reward, const uint8_t* done, int td_net, int mode, double lr, double grad_scale,
+                          float* q_sa_out, float* y_out) {
+    if (!d || n <= 0 || !boards90 || !next_boards90 || !action_to || !reward || !done)
+        return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_td_update_host: bad argument");
+    if ((size_t)n > d->hb_cap) {
+        XQ_HIP(hipStreamSynchronize(d->stream));
+        hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
+        XQ_HIP(hipMalloc(&d->hb, (size_t)n * 2 * kBoardWords * sizeof(uint32_t)));
+        XQ_HIP(hipMalloc(&d->ha, (size_t)n * sizeof(int32_t)));
+        XQ_HIP(hipMalloc(&d->hr, (size_t)n * sizeof(float)));
+        XQ_HIP(hipMalloc(&d->hd, (size_t)n));
+        d->hb_cap = (size_t)n;
+    }
+    std::vector<uint32_t> w((size_t)n * 2 * kBoardWords);
+    for (int i = 0; i < n; ++i) {
+        pack_board(boards90 + (size_t)i * 90, &w[(size_t)i * kBoardWords]);
+        pack_board(next_boards90 + (size_t)i * 90, &w[((size_t)n + i) * kBoardWords]);
+    }
+    XQ_HIP(hipStreamSynchronize(d->stream));
+    XQ_HIP(hipMemcpy(d->hb, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    XQ_HIP(hipMemcpy(d->ha, action_to, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    XQ_HIP(hipMemcpy(d->hr, reward, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    XQ_HIP(hipMemcpy(d->hd, done, (size_t)n, hipMemcpyHostToDevice));
+    XQ_TRY(xq_dqn_td_grads(d, d->hb, d->hb + (size_t)n * kBoardWords, d->ha, d->hr, d->hd, nullptr, n, td_net, mode));
+    XQ_TRY(xq_dqn_apply_grads(d, lr, grad_scale));
+    XQ_HIP(hipStreamSynchronize(d->stream));
+    if (q_sa_out) XQ_HIP(hipMemcpy(q_sa_out, d->qsa, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (y_out) XQ_HIP(hipMemcpy(y_out, d->yv, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return XQ_OK;
+}
+
+int xq_dqn_last_loss(xq_dqn* d, double* loss) {
+    if (!d || !loss) return fail(XQ_ERR_INVALID_ARGUMENT, "null pointer");
+    std::vector<float> v((size_t)std::max(d->last_n, 0));
+    XQ_HIP(hipStreamSynchronize(d->stream));
+    if (!v.empty()) XQ_HIP(hipMemcpy(v.data(), d->lossv, v.size() * sizeof(float), hipMemcpyDeviceToHost));
+    double s = 0;
+    for (float x : v) s += x;
+    *loss = s;
+    return XQ_OK;
+}
+
+int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_stats, int* n_stats) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    XQ_HIP(hipStreamSynchronize(d->stream));
+    d->prof.collect();
+    int n = 0;
+    if (stats && n_stats) {
+        for (size_t i = 0; i < d->prof.cats.size() && n < max_stats; ++i, ++n) {
+            const Profiler::Cat& c = d->prof.cats[i];
+            memset(&stats[n], 0, sizeof stats[n]);
+            strncpy(stats[n].name, c.name, sizeof stats[n].name - 1);
+            stats[n].ms = c.ms; stats[n].launches = c.launches; stats[n].flops = c.flops; stats[n].bytes = c.bytes;
+        }
+    }
+    if (n_stats) *n_stats = n;
+    if (enable >= 0) {
+        if ((enable != 0) != d->prof.enabled || enable == 2) d->prof.reset();   // 2 = enable and clear
+        d->prof.enabled = enable != 0;
+    }
+    return XQ_OK;
+}
+
+// DQN::saveModel / loadModel, dqn.cpp:76-154
+static void put_be(FILE* f, uint64_t v, int bytes) { for (int i = bytes - 1; i >= 0; --i) fputc((int)((v >> (8 * i)) & 0xFF), f); }
+static bool get_be(FILE* f, uint64_t* v, int bytes) {
+    uint64_t x = 0;
+    for (int i = 0; i < bytes; ++i) { int c = fgetc(f); if (c == EOF) return false; x = (x << 8) | (uint64_t)(c & 0xFF); }
+    *v = x;
+    return true;
+}
+
+int xq_dqn_save_model(xq_dqn* d, const char* path) {
+    if (!d || !path) return fail(XQ_ERR_INVALID_ARGUMENT, "null pointer");
+    std::vector<double> w(d->nw), b(d->nb);
+    XQ_TRY(xq_dqn_get_params(d, XQ_NET_ONLINE, w.data(), b.data()));
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(XQ_ERR_IO, "Unable to open file for saving model.");
+    bool ok = fwrite(w.data(), sizeof(double), w.size(), f) == w.size();       // raw (little-endian host) fp64
+    ok = ok && fwrite(b.data(), sizeof(double), b.size(), f) == b.size();
+    put_be(f, (uint64_t)d->ns, 8);                                             // QDataStream: big-endian quint64
+    for (int i = 0; i < d->ns; ++i) put_be(f, (uint64_t)(uint32_t)d->L[i], 4); // big-endian qint32
+    ok = ok && !ferror(f);
+    fclose(f);
+    return ok ? XQ_OK : fail(XQ_ERR_IO, "Error writing weights to model file.");
+}
+
+int xq_dqn_load_model(xq_dqn* d, const char* path) {
+    if (!d || !path) return fail(XQ_ERR_INVALID_ARGUMENT, "null pointer");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(XQ_ERR_IO, "Unable to open file for loading model.");
+    std::vector<double> w(d->nw), b(d->nb);
+    bool ok = fread(w.data(), sizeof(double), w.size(), f) == w.size();
+    ok = ok && fread(b.data(), sizeof(double), b.size(), f) == b.size();
+    if (!ok) { fclose(f); return fail(XQ_ERR_IO, "Error reading weights from model file."); }
+    uint64_t cnt = 0;
+    ok = get_be(f, &cnt, 8);
+    std::vector<int> sizes;
+    for (uint64_t i = 0; ok && i < cnt && i < 64; ++i) { uint64_t v; ok = get_be(f, &v, 4); sizes.push_back((int)(uint32_t)v); }
+    fclose(f);
+    bool same = ok && cnt == (uint64_t)d->ns;
+    for (int i = 0; same && i < d->ns; ++i) same = sizes[i] == d->L[i];
+    if (!same) return fail(XQ_ERR_IO, "Layer sizes in the model file do not match the current network architecture.");
+    return xq_dqn_set_params(d, XQ_NET_ONLINE, w.data(), b.data());           // qNetwork only, like upstream (:153)
+}
+
+}  // extern "C"

@@ -51,6 +51,57 @@ struct xq_env {
 };
 
 namespace xq {
+
+// HIP-event profiler: brackets individual launches on the handle's stream (bench.py roofline leg).  Disabled = free.
+struct Profiler {
+    struct Cat { char name[48]; double flops = 0, bytes = 0; int launches = 0; float ms = 0; };
+    struct Rec { int cat; hipEvent_t a, b; };
+    bool enabled = false;
+    std::vector<Cat> cats;
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    int cat_id(const char* name) {
+        for (size_t i = 0; i < cats.size(); ++i) if (!strcmp(cats[i].name, name)) return (int)i;
+        Cat c; memset(c.name, 0, sizeof c.name); strncpy(c.name, name, sizeof c.name - 1);
+        cats.push_back(c);
+        return (int)cats.size() - 1;
+    }
+    hipEvent_t get_event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    int begin(const char* name, hipStream_t s) {
+        if (!enabled) return -1;
+        Rec r; r.cat = cat_id(name); r.a = get_event(); r.b = get_event();
+        (void)hipEventRecord(r.a, s);
+        recs.push_back(r);
+        return (int)recs.size() - 1;
+    }
+    void end(int h, hipStream_t s, double flops, double bytes) {
+        if (h < 0) return;
+        (void)hipEventRecord(recs[h].b, s);
+        Cat& c = cats[recs[h].cat];
+        c.flops += flops; c.bytes += bytes; c.launches += 1;
+    }
+    void collect() {
+        for (auto& r : recs) {
+            float ms = 0;
+            (void)hipEventSynchronize(r.b);
+            (void)hipEventElapsedTime(&ms, r.a, r.b);
+            cats[r.cat].ms += ms;
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        recs.clear();
+    }
+    void reset() { collect(); cats.clear(); }
+    ~Profiler() { collect(); for (auto e : pool) (void)hipEventDestroy(e); }
+};
+
+// dqn-side entry points used by the trainer (defined in xq_dqn.hip)
+Profiler* dqn_profiler(xq_dqn* d);
+int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride);
+hipStream_t dqn_stream(xq_dqn* d);
+
 // env-side launchers used by the trainer
 int env_selfplay_launch(xq_env* env, const float* q90_dev, int q_stride, uint32_t eps_u32, xq_step_result* results_dev,
                         xq_replay* replay);

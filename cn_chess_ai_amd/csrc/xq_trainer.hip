@@ -1,15 +1,127 @@
-// TEMPORARY stub — replaced by the real implementation
+// xq_trainer.hip — the ChessAI::train() loop (reference chessai.cpp:85-170) for n_games boards at once, on device.
+//
+// Per iteration (one ply in every game + one minibatch update):
+//   collect : Q(s)[0..89] of every game (selectAction reads q[action.to] only, dqn.cpp:47) -> fused self-play
+//             kernel (legal moves in LDS, epsilon-greedy select, movePiece, evaluateBoard, done, auto-reset) ->
+//             transition written straight into the replay ring;
+//   learn   : sample -> TD gradients (xq_dqn_td_grads) -> [caller all-reduces the gradient buffer over RCCL] -> SGD;
+//   target  : updateTargetNetwork() every target_sync_interval updates (chessai.cpp:140 uses moveCount % 100).
+// No host round trip inside an iteration; everything is queued on one HIP stream.
 #include "xq_internal.h"
+
+struct xq_trainer {
+    xq_trainer_config cfg;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    xq_env* env = nullptr;
+    xq_dqn* dqn = nullptr;
+    xq_replay* replay = nullptr;
+    uint64_t env_steps = 0, updates = 0;
+    uint32_t eps_u32 = 0;
+};
+
 using namespace xq;
+
 extern "C" {
-int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer** out) { return fail(XQ_ERR_RUNTIME, "xq_trainer_create: not implemented yet"); }
-int xq_trainer_destroy(xq_trainer* t) { return fail(XQ_ERR_RUNTIME, "xq_trainer_destroy: not implemented yet"); }
-int xq_trainer_env(xq_trainer* t, xq_env** env) { return fail(XQ_ERR_RUNTIME, "xq_trainer_env: not implemented yet"); }
-int xq_trainer_dqn(xq_trainer* t, xq_dqn** dqn) { return fail(XQ_ERR_RUNTIME, "xq_trainer_dqn: not implemented yet"); }
-int xq_trainer_replay(xq_trainer* t, xq_replay** replay) { return fail(XQ_ERR_RUNTIME, "xq_trainer_replay: not implemented yet"); }
-int xq_trainer_collect(xq_trainer* t) { return fail(XQ_ERR_RUNTIME, "xq_trainer_collect: not implemented yet"); }
-int xq_trainer_learn_grads(xq_trainer* t) { return fail(XQ_ERR_RUNTIME, "xq_trainer_learn_grads: not implemented yet"); }
-int xq_trainer_learn_apply(xq_trainer* t, int world_size) { return fail(XQ_ERR_RUNTIME, "xq_trainer_learn_apply: not implemented yet"); }
-int xq_trainer_step(xq_trainer* t, int n_iterations) { return fail(XQ_ERR_RUNTIME, "xq_trainer_step: not implemented yet"); }
-int xq_trainer_counters(xq_trainer* t, uint64_t* env_steps, uint64_t* updates, uint64_t* episodes) { return fail(XQ_ERR_RUNTIME, "xq_trainer_counters: not implemented yet"); }
+
+int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer** out) {
+    if (!cfg || !out) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_trainer_create: null pointer");
+    if (cfg->n_games <= 0 || cfg->n_sizes < 3 || cfg->n_sizes > XQ_MAX_LAYERS + 1)
+        return fail(XQ_ERR_INVALID_ARGUMENT, "xq_trainer_create: bad n_games / layer sizes");
+    if (cfg->replay_capacity != 0 && cfg->replay_capacity < cfg->n_games)
+        return fail(XQ_ERR_INVALID_ARGUMENT, "replay_capacity must be 0 (on-policy) or >= n_games");
+    if (cfg->replay_capacity != 0 && cfg->minibatch <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "minibatch must be > 0");
+    xq_trainer* t = new xq_trainer();
+    t->cfg = *cfg;
+    if (hip_stream) t->stream = (hipStream_t)hip_stream;
+    else { XQ_HIP(hipStreamCreate(&t->stream)); t->own_stream = true; }
+    XQ_TRY(xq_env_create(cfg->n_games, cfg->seed, cfg->first_game_id, t->stream, &t->env));
+    XQ_TRY(xq_dqn_create(cfg->layer_sizes, cfg->n_sizes, cfg->learning_rate, cfg->gamma, cfg->seed ^ 0x9E3779B97F4A7C15ull,
+                         t->stream, &t->dqn));
+    const int cap = cfg->replay_capacity > 0 ? cfg->replay_capacity : cfg->n_games;
+    XQ_TRY(xq_replay_create(cap, cfg->seed + 0x1234567ull + cfg->first_game_id, t->stream, &t->replay));
+    const double e = cfg->epsilon < 0 ? 0 : cfg->epsilon;
+    const double v = e * 4294967296.0;
+    t->eps_u32 = v >= 4294967295.0 ? 4294967295u : (uint32_t)v;
+    *out = t;
+    return XQ_OK;
 }
+
+int xq_trainer_destroy(xq_trainer* t) {
+    if (!t) return XQ_OK;
+    hipStreamSynchronize(t->stream);
+    xq_env_destroy(t->env);
+    xq_dqn_destroy(t->dqn);
+    xq_replay_destroy(t->replay);
+    if (t->own_stream) hipStreamDestroy(t->stream);
+    delete t;
+    return XQ_OK;
+}
+
+int xq_trainer_env(xq_trainer* t, xq_env** e) { if (!t || !e) return fail(XQ_ERR_INVALID_ARGUMENT, "null"); *e = t->env; return XQ_OK; }
+int xq_trainer_dqn(xq_trainer* t, xq_dqn** d) { if (!t || !d) return fail(XQ_ERR_INVALID_ARGUMENT, "null"); *d = t->dqn; return XQ_OK; }
+int xq_trainer_replay(xq_trainer* t, xq_replay** r) { if (!t || !r) return fail(XQ_ERR_INVALID_ARGUMENT, "null"); *r = t->replay; return XQ_OK; }
+
+int xq_trainer_collect(xq_trainer* t) {
+    if (!t) return fail(XQ_ERR_INVALID_ARGUMENT, "null trainer");
+    float* q90 = nullptr;
+    int stride = 0;
+    XQ_TRY(dqn_q90_boards(t->dqn, t->env->boards, t->env->n, &q90, &stride));
+    if (t->cfg.replay_capacity == 0) {           // on-policy: the ring is exactly one batch, refilled every ply
+        t->replay->write_pos = 0;
+        t->replay->size = 0;
+    }
+    Profiler* p = dqn_profiler(t->dqn);
+    const int h = p->begin("env_selfplay_step", t->stream);
+    XQ_TRY(env_selfplay_launch(t->env, q90, stride, t->eps_u32, nullptr, t->replay));
+    // algorithmic HBM bytes per game and ply: board+meta in/out (2*(48+16)), Q row 360, transition 48+48+4+4+1
+    p->end(h, t->stream, 0.0, (double)t->env->n * (2.0 * (48 + 16) + 360 + 105));
+    t->env_steps += (uint64_t)t->env->n;
+    return XQ_OK;
+}
+
+int xq_trainer_learn_grads(xq_trainer* t) {
+    if (!t) return fail(XQ_ERR_INVALID_ARGUMENT, "null trainer");
+    int batch = 0;
+    if (t->cfg.replay_capacity > 0) {
+        batch = t->cfg.minibatch;
+        XQ_TRY(xq_replay_sample(t->replay, batch, nullptr));
+    }
+    return xq_dqn_td_grads_replay(t->dqn, t->replay, batch, t->cfg.td_net, t->cfg.backprop_mode);
+}
+
+int xq_trainer_learn_apply(xq_trainer* t, int world_size) {
+    if (!t || world_size < 1) return fail(XQ_ERR_INVALID_ARGUMENT, "bad argument");
+    const int batch = t->cfg.replay_capacity > 0 ? t->cfg.minibatch : t->cfg.n_games;
+    const double scale = t->cfg.mean_gradient ? 1.0 / ((double)batch * world_size) : 1.0;
+    XQ_TRY(xq_dqn_apply_grads(t->dqn, t->cfg.learning_rate, scale));
+    t->updates += 1;
+    if (t->cfg.target_sync_interval > 0 && t->updates % (uint64_t)t->cfg.target_sync_interval == 0)
+        XQ_TRY(xq_dqn_update_target(t->dqn));
+    return XQ_OK;
+}
+
+int xq_trainer_step(xq_trainer* t, int n_iterations) {
+    if (!t || n_iterations < 0) return fail(XQ_ERR_INVALID_ARGUMENT, "bad argument");
+    for (int i = 0; i < n_iterations; ++i) {
+        XQ_TRY(xq_trainer_collect(t));
+        XQ_TRY(xq_trainer_learn_grads(t));
+        XQ_TRY(xq_trainer_learn_apply(t, 1));
+    }
+    return XQ_OK;
+}
+
+int xq_trainer_counters(xq_trainer* t, uint64_t* env_steps, uint64_t* updates, uint64_t* episodes) {
+    if (!t) return fail(XQ_ERR_INVALID_ARGUMENT, "null trainer");
+    if (env_steps) *env_steps = t->env_steps;
+    if (updates) *updates = t->updates;
+    if (episodes) {
+        unsigned long long head = 0;
+        XQ_HIP(hipStreamSynchronize(t->stream));
+        XQ_HIP(hipMemcpy(&head, t->env->ep_head, sizeof head, hipMemcpyDeviceToHost));
+        *episodes = head;
+    }
+    return XQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,336 @@
+"""GPU parity tests of the Q-network path (through the C ABI) — `pytest -m gpu`.
+
+HIP fp32/MFMA path vs the fp64 CPU oracle (oracle/xq_oracle.c restating reference dqn.cu / dqn.cpp / chessai.cpp) on
+identical inputs.  Tolerance, from BASELINE.json north_star: Q-values within 1e-4 (fp32 vs the fp64 reference).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import xqoracle as xo
+
+pytestmark = pytest.mark.gpu
+
+QTOL = 1e-4          # north_star tolerance on Q-values
+PTOL = 2e-5          # parameters after one update (|w| <= 0.05 + update; fp32 storage)
+
+REF_NET = [1260, 128, 8100]
+CFG2_NET = [1260, 256, 256, 8100]
+
+
+@pytest.fixture(scope="module")
+def xq():
+    import cn_chess_ai_amd as m
+    assert m._capi.device_count() > 0
+    return m
+
+
+@pytest.fixture(scope="module")
+def trace(golden_dir):
+    return np.load(os.path.join(golden_dir, "ref_trace.npz"))
+
+
+def one_hot(boards):
+    boards = np.asarray(boards).reshape(-1, 90)
+    x = np.zeros((len(boards), 1260))
+    for i, b in enumerate(boards):
+        for s in np.nonzero(b)[0]:
+            x[i, s * 14 + b[s] - 1] = 1.0
+    return x
+
+
+def make_net(xq, sizes, seed=1, lr=0.001, gamma=0.99):
+    w, b = xo.init_weights(sizes, seed)
+    b = np.random.default_rng(seed + 100).uniform(-0.05, 0.05, size=len(b))   # non-zero biases exercise the bias path
+    d = xq.DQN(sizes, lr, gamma, seed=seed)
+    d.set_params(w, b)
+    d.updateTargetNetwork()
+    return d, w.copy(), b.copy()
+
+
+def transitions(trace, idx):
+    """(s, action.to, reward, done, s') from consecutive records of the reference trace (valid moves only)."""
+    L = xo.lib()
+    S, A, R, D, S2 = [], [], [], [], []
+    for i in idx:
+        b = xo.board_from(trace["board"][i], trace["moveCount"][i], trace["player"][i], trace["redScore"][i],
+                          trace["blackScore"][i])
+        mover = b.currentPlayer
+        fr, fc, tr, tc = (int(x) for x in trace["move"][i])
+        S.append(b.squares())
+        L.xqo_move_piece(C.byref(b), fr, fc, tr, tc)
+        A.append(tr * 9 + tc)
+        R.append(float(L.xqo_evaluate_board(C.byref(b), mover, b.moveCount)))
+        D.append(int(L.xqo_check_game_over(C.byref(b)) or b.moveCount + 1 >= 200))
+        S2.append(b.squares())
+    return (np.array(S, np.uint8), np.array(A, np.int32), np.array(R, np.float32), np.array(D, np.uint8),
+            np.array(S2, np.uint8))
+
+
+def valid_indices(trace, n, seed=0):
+    ok = np.nonzero((trace["valid"] == 1) & (trace["over"] == 0))[0]
+    rng = np.random.default_rng(seed)
+    pick = rng.choice(ok, size=n, replace=False)
+    # make sure terminal / near-cap transitions are present
+    late = ok[trace["moveCount"][ok] >= 198][:4]
+    caps = ok[np.isin(trace["captured"][ok], (1, 8))][:2]
+    special = np.concatenate([late, caps])[:max(n // 4, 1)]
+    pick[:len(special)] = special
+    return pick
+
+
+# ------------------------------------------------------------------------------------------------ forward
+@pytest.mark.parametrize("sizes", [REF_NET, CFG2_NET, [1260, 64, 96, 200], [40, 24, 24, 56]])
+def test_forward_matches_oracle(xq, trace, sizes):
+    d, w, b = make_net(xq, sizes, seed=3)
+    rng = np.random.default_rng(0)
+    n = 37
+    if sizes[0] == 1260:
+        x = one_hot(trace["board"][rng.choice(len(trace["board"]), n, replace=False)])
+        x[-5:] = rng.uniform(-1, 1, size=(5, 1260))            # dense (non one-hot) inputs: getQValues takes any vector
+    else:
+        x = rng.uniform(-1, 1, size=(n, sizes[0]))
+    q = d.getQValues(x)
+    want = np.stack([xo.nn_forward(sizes, w, b, xi) for xi in x])
+    assert q.shape == want.shape
+    assert np.abs(q - want).max() < QTOL
+    assert np.abs(q - want).max() < 5e-6                          # in practice ~1e-7
+    q1 = d.getQValues(x[0])                                      # batch-1 call, like upstream
+    assert np.abs(q1 - want[0]).max() < 5e-6
+    d.close()
+
+
+def test_board_input_equals_dense_input(xq, trace):
+    d, w, b = make_net(xq, CFG2_NET, seed=4)
+    n = 200
+    boards = trace["board"][:n]
+    env = xq.VecEnv(n)
+    env.set_state(boards)
+    q96 = d.q_boards(env, 96).cpu().numpy()
+    qfull = d.q_boards(env, 8100).cpu().numpy()
+    dense = d.getQValues(one_hot(boards))
+    assert np.abs(qfull - dense).max() < 2e-6
+    assert np.abs(q96 - dense[:, :96]).max() < 2e-6
+    want = np.stack([xo.nn_forward(CFG2_NET, w, b, xo.state_repr(xo.board_from(bd))) for bd in boards[:20]])
+    assert np.abs(qfull[:20] - want).max() < 5e-6
+    env.close(); d.close()
+
+
+# ------------------------------------------------------------------------------------------------ backprop
+@pytest.mark.parametrize("sizes,mode", [(REF_NET, 0), (REF_NET, 1), (CFG2_NET, 0), (CFG2_NET, 1),
+                                        ([1260, 512, 512, 512, 8100], 0)])
+def test_backpropagate_single_sample_matches_oracle(xq, trace, sizes, mode):
+    """DQN::backpropagate(state, target, lr) with batch 1 — exactly the upstream call (dqn.cu:323-467)."""
+    d, w, b = make_net(xq, sizes, seed=5)
+    x = one_hot(trace["board"][100])[0]
+    target = xo.nn_forward(sizes, w, b, x)
+    target[33] = -0.35                                   # the TD-modified entry (chessai.cpp:124/127)
+    target[7000] += 0.01                                 # and an arbitrary far entry: the API takes any target
+    lr = 0.05
+    assert xo.nn_backprop(sizes, w, b, x, target, lr, mode) == 0
+    d.backpropagate(x, target, lr, 1.0, mode)
+    gw, gb = d.get_params()
+    assert np.abs(gw - w).max() < PTOL and np.abs(gb - b).max() < PTOL
+    q = d.getQValues(x)
+    assert np.abs(q - xo.nn_forward(sizes, w, b, x)).max() < QTOL
+    d.close()
+
+
+def test_backpropagate_modes_differ_and_batch_rule(xq, trace):
+    """reference vs textbook deltas really differ; the minibatch rule = sum of per-sample gradients at fixed weights."""
+    sizes = REF_NET
+    n = 6
+    xs = one_hot(trace["board"][200:200 + n])
+    d0, w, b = make_net(xq, sizes, seed=6)
+    d1, _, _ = make_net(xq, sizes, seed=6)
+    targets = np.stack([xo.nn_forward(sizes, w, b, x) for x in xs])
+    targets[np.arange(n), np.arange(n) * 7] = np.linspace(-0.9, 0.9, n)
+    lr, scale = 0.02, 1.0 / n
+    res = {}
+    for mode, d in ((0, d0), (1, d1)):
+        gw, gb = np.zeros_like(w), np.zeros_like(b)
+        for x, t in zip(xs, targets):
+            assert xo.nn_accum_grad(sizes, w, b, x, t, mode, gw, gb) == 0
+        want_w, want_b = w - lr * scale * gw, b - lr * scale * gb
+        d.backpropagate(xs, targets, lr, scale, mode)
+        got_w, got_b = d.get_params()
+        assert np.abs(got_w - want_w).max() < PTOL and np.abs(got_b - want_b).max() < PTOL
+        res[mode] = got_w
+    assert np.abs(res[0] - res[1]).max() > 1e-5          # the shifted-stride hidden delta is a different update
+    d0.close(); d1.close()
+
+
+def test_reference_mode_rejects_undefined_topology(xq):
+    d = xq.DQN([1260, 32, 64, 128], seed=1)
+    x, t = np.zeros(1260), np.zeros(128)
+    with pytest.raises(xq.XqError) as e:
+        d.backpropagate(x, t, 0.01, 1.0, 0)
+    assert e.value.code == 5
+    d.backpropagate(x, t, 0.01, 1.0, 1)                  # textbook mode is defined everywhere
+    d.close()
+
+
+# ------------------------------------------------------------------------------------------------ TD step
+def oracle_td_update(sizes, w, b, wt, bt, S, A, R, D, S2, gamma, lr, scale, mode):
+    gw, gb = np.zeros_like(w), np.zeros_like(b)
+    qsa, ys = [], []
+    for s, a, r, dn, s2 in zip(S, A, R, D, S2):
+        x = xo.state_repr(xo.board_from(s))
+        tq = xo.nn_forward(sizes, w, b, x)                                   # chessai.cpp:122
+        qsa.append(tq[a])
+        if dn:
+            y = float(r)
+        else:
+            y = float(r) + gamma * xo.nn_forward(sizes, wt, bt, xo.state_repr(xo.board_from(s2))).max()   # :126-127
+        tq[a] = y
+        ys.append(y)
+        assert xo.nn_accum_grad(sizes, w, b, x, tq, mode, gw, gb) == 0      # :131
+    return w - lr * scale * gw, b - lr * scale * gb, np.array(qsa), np.array(ys)
+
+
+@pytest.mark.parametrize("sizes,td_net,mode", [(REF_NET, 0, 0), (CFG2_NET, 0, 0), (CFG2_NET, 1, 0), (CFG2_NET, 1, 1)])
+def test_td_update_matches_oracle(xq, trace, sizes, td_net, mode):
+    n = 48
+    S, A, R, D, S2 = transitions(trace, valid_indices(trace, n, seed=1))
+    assert D.sum() >= 2 and (D == 0).sum() > 10
+    d, w, b = make_net(xq, sizes, seed=7)
+    wt, bt = w, b
+    if td_net == 1:                                       # make the target net different from the online net
+        wt, bt = xo.init_weights(sizes, 99)
+        d.set_params(wt, bt, net=1)
+    R = R / 1000.0                                        # keep |target| O(1) so tanh' is not ~0 everywhere
+    lr, scale = 0.05, 1.0 / n
+    want_w, want_b, want_q, want_y = oracle_td_update(sizes, w, b, wt, bt, S, A, R, D, S2, 0.99, lr, scale, mode)
+    qsa, y = d.td_update(S, S2, A, R, D, td_net=td_net, mode=mode, learning_rate=lr, grad_scale=scale)
+    assert np.abs(qsa - want_q).max() < QTOL and np.abs(y - want_y).max() < QTOL
+    got_w, got_b = d.get_params()
+    assert np.abs(got_w - want_w).max() < PTOL and np.abs(got_b - want_b).max() < PTOL
+    assert np.abs(got_w - w).max() > 1e-4                # something was learnt
+    # untouched output rows (>= 96) stay bit-identical: action.to < 90
+    hl = sizes[-2]
+    wo_out = sum(sizes[i] * sizes[i + 1] for i in range(len(sizes) - 2))
+    assert np.array_equal(got_w[wo_out + 96 * hl:], w.astype(np.float32).astype(np.float64)[wo_out + 96 * hl:])
+    x = xo.state_repr(xo.board_from(S[0]))
+    assert np.abs(d.getQValues(x) - xo.nn_forward(sizes, want_w, want_b, x)).max() < QTOL
+    d.close()
+
+
+def test_td_update_raw_rewards_and_sequence(xq, trace):
+    """Upstream-scale rewards (+-thousands against tanh outputs) through 3 consecutive updates, reference net."""
+    sizes = REF_NET
+    d, w, b = make_net(xq, sizes, seed=8)
+    lr = 0.001
+    for k in range(3):
+        S, A, R, D, S2 = transitions(trace, valid_indices(trace, 16, seed=10 + k))
+        w, b, _, _ = oracle_td_update(sizes, w, b, w, b, S, A, R, D, S2, 0.99, lr, 1.0 / 16, 0)
+        d.td_update(S, S2, A, R, D, td_net=0, mode=0, learning_rate=lr, grad_scale=1.0 / 16)
+    got_w, got_b = d.get_params()
+    assert np.abs(got_w - w).max() < 1e-4 and np.abs(got_b - b).max() < 1e-4
+    xs = one_hot(trace["board"][300:310])
+    want = np.stack([xo.nn_forward(sizes, w, b, x) for x in xs])
+    assert np.abs(d.getQValues(xs) - want).max() < QTOL
+    d.close()
+
+
+def test_td_update_equals_dense_backpropagate(xq, trace):
+    """The sparse TD path (delta in columns 0..95) must equal DQN::backpropagate on the dense target vector."""
+    sizes = CFG2_NET
+    n = 24
+    S, A, R, D, S2 = transitions(trace, valid_indices(trace, n, seed=2))
+    R = R / 500.0
+    da, w, b = make_net(xq, sizes, seed=9)
+    db, _, _ = make_net(xq, sizes, seed=9)
+    xs = one_hot(S)
+    q = db.getQValues(xs)
+    nq = db.getQValues(one_hot(S2))
+    tq = q.copy()
+    for i in range(n):
+        tq[i, A[i]] = R[i] if D[i] else R[i] + 0.99 * nq[i].max()
+    db.backpropagate(xs, tq, 0.03, 1.0 / n, 0)
+    da.td_update(S, S2, A, R, D, td_net=0, mode=0, learning_rate=0.03, grad_scale=1.0 / n)
+    wa, ba = da.get_params()
+    wb, bb = db.get_params()
+    assert np.abs(wa - wb).max() < 2e-6 and np.abs(ba - bb).max() < 2e-6
+    da.close(); db.close()
+
+
+# ------------------------------------------------------------------------------------------------ DQN facade
+def test_select_action_matches_oracle(xq, trace):
+    sizes = REF_NET
+    d, w, b = make_net(xq, sizes, seed=11)
+    L = xo.lib()
+    for i in (0, 50, 400, 1234):
+        bd = xo.board_from(trace["board"][i])
+        codes, n = xo.all_valid_actions(bd, int(trace["player"][i]))
+        if n == 0:
+            continue
+        x = xo.state_repr(bd)
+        q = xo.nn_forward(sizes, w, b, x)
+        acts = [(int(c) // 90, int(c) % 90) for c in codes]
+        rm = 2147483647                                      # RAND_MAX: randValue = rand() / RAND_MAX (dqn.cpp:30)
+        for k1, r2 in ((rm // 2, 0), (rm // 20, 12345), (214748364, 7), (214748365, 3), (rm, 1)):
+            want = L.xqo_select_action(q.ctypes.data_as(C.POINTER(C.c_double)), len(q),
+                                       codes.ctypes.data_as(C.POINTER(C.c_uint16)), n, k1, r2, rm, 0.1)
+            assert d.selectAction(x, 0.1, acts, rand1=k1 / rm, rand2=r2) == acts[want]
+    with pytest.raises(RuntimeError):
+        d.selectAction(np.zeros(1260), 0.1, [])
+    d.close()
+
+
+def test_target_network_and_dqn_train(xq, trace):
+    sizes = REF_NET
+    d, w, b = make_net(xq, sizes, seed=12)
+    S, A, R, D, S2 = transitions(trace, valid_indices(trace, 4, seed=3))
+    d.td_update(S, S2, A, R / 1000, D, learning_rate=0.05)
+    w1, b1 = d.get_params(0)
+    wt, bt = d.get_params(1)
+    assert np.abs(wt - w).max() < 1e-8 and np.abs(w1 - wt).max() > 1e-5      # target still the old weights
+    d.updateTargetNetwork()
+    wt, bt = d.get_params(1)
+    assert np.array_equal(wt, w1) and np.array_equal(bt, b1)                # now the TRAINED weights (not upstream's stale copy)
+    # DQN::train (dqn.cpp:157-172): single transition, target net
+    x, x2 = xo.state_repr(xo.board_from(S[0])), xo.state_repr(xo.board_from(S2[0]))
+    q = xo.nn_forward(sizes, w1, b1, x)
+    q[A[0]] = 0.25 + 0.99 * xo.nn_forward(sizes, wt, bt, x2).max()
+    xo.nn_backprop(sizes, w1, b1, x, q, 0.001, 0)
+    d.train(x, int(A[0]), 0.25, x2, False)
+    w2, b2 = d.get_params(0)
+    assert np.abs(w2 - w1).max() < PTOL
+    d.close()
+
+
+def test_model_file_format(xq, tmp_path):
+    d, w, b = make_net(xq, REF_NET, seed=13)
+    p = tmp_path / "model.bin"
+    d.saveModel(p)
+    raw = p.read_bytes()
+    assert len(raw) == 9650484                                              # verified upstream size
+    nw, nb = 1198080, 8228
+    fw = np.frombuffer(raw[:nw * 8], dtype="<f8")
+    fb = np.frombuffer(raw[nw * 8:(nw + nb) * 8], dtype="<f8")
+    assert np.array_equal(fw, w.astype(np.float32).astype(np.float64)) and np.array_equal(fb, b.astype(np.float32).astype(np.float64))
+    tail = raw[(nw + nb) * 8:]
+    assert tail == (3).to_bytes(8, "big") + b"".join(int(s).to_bytes(4, "big") for s in REF_NET)
+    d2 = xq.DQN(REF_NET, seed=77)
+    d2.loadModel(p)
+    w2, b2 = d2.get_params()
+    assert np.array_equal(w2, fw) and np.array_equal(b2, fb)
+    d3 = xq.DQN(CFG2_NET, seed=1)
+    with pytest.raises(xq.XqError) as e:
+        d3.loadModel(p)
+    assert e.value.code == 4
+    with pytest.raises(xq.XqError):
+        d3.loadModel(tmp_path / "missing.bin")
+    d.close(); d2.close(); d3.close()
+
+
+def test_invalid_arguments(xq):
+    with pytest.raises(xq.XqError) as e:
+        xq.DQN([1260])
+    assert e.value.code == 1
+    d = xq.DQN([1260, 16, 32], seed=1)                  # < 96 outputs: dense API only
+    with pytest.raises(xq.XqError):
+        d.td_update(np.zeros((1, 90)), np.zeros((1, 90)), [0], [0.0], [0])
+    d.close()

@@ -1,0 +1,120 @@
+"""GPU tests of the whole loop (collect -> learn) — `pytest -m gpu`.
+
+(1) the loop composed from C-ABI calls vs the CPU oracle's restatement of chessai.cpp:96-143, same Q inputs;
+(2) xq_trainer_step == that composition, bit for bit (the trainer adds no arithmetic of its own);
+(3) BASELINE config 2 shape (8192 games, (256,256) net) runs and stays finite.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import xqoracle as xo
+from test_dqn_gpu import oracle_td_update, REF_NET, CFG2_NET
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def xq():
+    import cn_chess_ai_amd as m
+    assert m._capi.device_count() > 0
+    return m
+
+
+def test_loop_matches_oracle(xq):
+    """16 games x 8 plies, reference net, on-policy batch update with upstream hyper-parameters (lr 1e-3, gamma .99)."""
+    n, iters, seed, first, eps, lr = 16, 8, 77, 5, 0.1, 0.001
+    sizes = REF_NET
+    env = xq.VecEnv(n, seed=seed, first_game_id=first)
+    w, b = xo.init_weights(sizes, 21)
+    d = xq.DQN(sizes, lr, 0.99, seed=1)
+    d.set_params(w, b)
+    boards = [xo.new_board() for _ in range(n)]
+    plies = np.zeros(n, dtype=np.int64)
+    for it in range(iters):
+        q = d.q_boards(env, 96).cpu().numpy()[:, :90]
+        # the oracle's own Q agrees with the device Q to far better than the tolerance
+        want_q = np.stack([xo.nn_forward(sizes, w, b, xo.state_repr(bd))[:90] for bd in boards])
+        assert np.abs(q - want_q).max() < 1e-4
+        S, _ = env.get_state()
+        res = env.selfplay_step(q, eps)
+        S2, _ = env.get_state()
+        for g in range(n):
+            o = xo.selfplay_step(boards[g], q[g], seed, first + g, int(plies[g]), xo.eps_to_u32(eps))
+            assert (res[g]["action"], res[g]["reward"], res[g]["done"], res[g]["terminated"]) == \
+                (o.action_code, o.reward, o.done, o.terminated)
+            plies[g] += 1
+        A = (res["action"] % 90).astype(np.int32)
+        R = res["reward"].astype(np.float32)
+        D = res["done"]
+        w, b, _, _ = oracle_td_update(sizes, w, b, w, b, S, A, R, D, S2, 0.99, lr, 1.0 / n, 0)
+        d.td_update(S, S2, A, R, D, td_net=0, mode=0, learning_rate=lr, grad_scale=1.0 / n)
+        gw, gb = d.get_params()
+        assert np.abs(gw - w).max() < 1e-4 and np.abs(gb - b).max() < 1e-4, it
+    env.close(); d.close()
+
+
+@pytest.mark.parametrize("replay_capacity,minibatch", [(0, 0), (256, 48)])
+def test_trainer_equals_composition(xq, replay_capacity, minibatch):
+    n, iters, seed, first = 64, 7, 4242, 100
+    sizes = CFG2_NET
+    cfg = xq.TrainerConfig(n_games=n, layer_sizes=sizes, learning_rate=0.01, gamma=0.99, epsilon=0.2,
+                           replay_capacity=replay_capacity, minibatch=max(minibatch, 1), td_net=1, backprop_mode=0,
+                           target_sync_interval=3, mean_gradient=1, seed=seed, first_game_id=first)
+    t = xq.Trainer(cfg)
+    w0, b0 = t.dqn.get_params()
+    t.step(iters)
+    tw, tb = t.dqn.get_params()
+    ttw, ttb = t.dqn.get_params(net=1)
+    tboards, tmeta = t.env.get_state()
+    assert t.counters()["env_steps"] == n * iters and t.counters()["updates"] == iters
+
+    env = xq.VecEnv(n, seed=seed, first_game_id=first)
+    d = xq.DQN(sizes, 0.01, 0.99, seed=1)
+    d.set_params(w0, b0); d.updateTargetNetwork()
+    cap = replay_capacity if replay_capacity else n
+    rp = xq.ReplayBuffer(cap, seed=seed + 0x1234567 + first)
+    import torch
+    for it in range(iters):
+        q = d.q_boards(env, 96)
+        if replay_capacity == 0:
+            rp.close(); rp = xq.ReplayBuffer(cap, seed=0)          # on-policy: ring refilled from slot 0 every ply
+        env.selfplay_step_dev(q.data_ptr(), 96, 0.2, replay=rp)
+        torch.cuda.synchronize()
+        if replay_capacity:
+            rp.sample(minibatch)
+            d.td_grads_replay(rp, minibatch, td_net=1, mode=0)
+            d.apply_grads(0.01, 1.0 / minibatch)
+        else:
+            d.td_grads_replay(rp, 0, td_net=1, mode=0)
+            d.apply_grads(0.01, 1.0 / n)
+        if (it + 1) % 3 == 0:
+            d.updateTargetNetwork()
+    w, b = d.get_params()
+    wt, bt = d.get_params(net=1)
+    boards, meta = env.get_state()
+    assert np.array_equal(boards, tboards) and np.array_equal(meta, tmeta)
+    assert np.array_equal(w, tw) and np.array_equal(b, tb)
+    assert np.array_equal(wt, ttw) and np.array_equal(bt, ttb)
+    assert np.abs(w - w0).max() > 0
+    t.close(); env.close(); d.close(); rp.close()
+
+
+def test_trainer_baseline_config_shape(xq):
+    cfg = xq.TrainerConfig(n_games=8192, layer_sizes=CFG2_NET, replay_capacity=1 << 16, minibatch=8192,
+                           target_sync_interval=2)
+    t = xq.Trainer(cfg)
+    t.dqn.kernel_stats(enable=2)
+    t.step(4)
+    c = t.counters()
+    assert c["env_steps"] == 4 * 8192 and c["updates"] == 4
+    w, b = t.dqn.get_params()
+    assert np.isfinite(w).all() and np.isfinite(b).all()
+    stats = {s["name"]: s for s in t.dqn.kernel_stats(enable=0)}
+    assert stats["gemm_qmax_rowmax"]["launches"] == 4 and stats["env_selfplay_step"]["launches"] == 4
+    assert stats["gemm_qmax_rowmax"]["ms"] > 0
+    assert np.isfinite(t.dqn.last_loss())
+    size, cap, tot = t.replay.stats()
+    assert size == 4 * 8192 and tot == 4 * 8192
+    t.close()
