@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on its config: env steps/s + DQN updates/s at 8192 parallel games per MI355X.
+
+One "step" = one pass of the hot path over one batch: one ply in every one of the 8192 games of this GPU
+(Q(s)[0..89] forward -> fused self-play kernel -> transition into the replay ring) followed by one DQN update on a
+minibatch of 8192 replayed transitions (TD target with the full 8100-wide max, backward, [gradient all-reduce], SGD).
+Workload = BASELINE configs[1]: 8192 games, (256,256) hidden layers, fp32, replay 1 M transitions; random-init
+weights, self-play from the start position ("synthetic": nothing is read from disk).  N > 1: weak scaling, every rank
+runs its own 8192 games (game ids rank*8192..) and the gradient buffer is all-reduced over RCCL every update.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the 8192x8100x256 row-max GEMM, MFMA-bound) with
+HIP events recorded around each of its launches inside the timed region; `roofline_env` does the same for the fused
+self-play step kernel (HBM-bound).  `cpu_baseline` times the CPU port of ChessAI::train (oracle) on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_GAMES = 8192
+LAYERS = (1260, 256, 256, 8100)
+REPLAY = 1 << 20
+MINIBATCH = 8192
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+ENV_BYTES_PER_GAME = 2 * (48 + 16) + 360 + 105   # board+meta r/w, Q row, transition record
+
+
+def cpu_baseline(seconds=15.0):
+    """CPU port of the reference loop (oracle/xq_oracle.c: xqo_train_episode = chessai.cpp:90-167 with the
+    {1260,128,8100} fp64 net, batch 1, bug-compatible backprop) on one host core, bounded to ~`seconds`."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import xqoracle as xo
+    L = xo.lib()
+    sizes = xo.sizes_arr([1260, 128, 8100])
+    w, b = xo.init_weights([1260, 128, 8100], 1)
+    rng = C.c_uint64(12345)
+    st = xo.EpisodeStats()
+    steps, episodes = 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        L.xqo_train_episode(sizes.ctypes.data_as(C.POINTER(C.c_int)), len(sizes), w.ctypes.data_as(C.POINTER(C.c_double)),
+                            b.ctypes.data_as(C.POINTER(C.c_double)), 0.001, 0.99, 0.1, C.byref(rng), 0, C.byref(st))
+        steps += st.steps
+        episodes += 1
+    el = time.perf_counter() - t0
+    out = {"value": steps / el, "unit": "env steps/s (= DQN updates/s, batch 1)", "cores": 1, "kind": "port",
+           "sample": f"{episodes} episodes / {steps} plies of the ChessAI::train restatement, net 1260-128-8100 fp64, "
+                     f"{el:.1f} s on one host core"}
+    ref = os.path.join(ROOT, "oracle", "_ref", "xqref")
+    if os.path.exists(ref):     # the real reference rules engine (env only: movegen + movePiece), when it travelled
+        try:
+            s, t = subprocess.check_output([ref, "bench", "1", "3"], timeout=60).split()
+            out["env_only_reference_steps_per_s"] = float(s) / float(t)
+        except Exception as e:   # Qt runtime missing on the box: report, do not fail the bench
+            out["env_only_reference_error"] = str(e)[:80]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with HIP events (diagnostic)")
+    args = ap.parse_args()
+
+    import torch
+    import cn_chess_ai_amd as xq
+    from cn_chess_ai_amd import _capi, dist as xd
+    import torch.distributed as dist
+
+    rank, local_rank, world = xd.env_rank()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available() or _capi.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    _capi.call("xq_set_device", local_rank)
+    xd.init_process_group("nccl" if world > 1 else None)
+    stream = torch.cuda.current_stream().cuda_stream       # library kernels and RCCL share torch's current stream
+
+    first, _ = xd.shard_games(rank, N_GAMES)
+    cfg = xq.TrainerConfig(n_games=N_GAMES, layer_sizes=LAYERS, learning_rate=0.001, gamma=0.99, epsilon=0.1,
+                           replay_capacity=REPLAY, minibatch=MINIBATCH, td_net=_capi.TD_TARGET_NET,
+                           backprop_mode=_capi.BACKPROP_REFERENCE, target_sync_interval=100, mean_gradient=1,
+                           seed=0x5EED, first_game_id=first)
+    t = xq.Trainer(cfg, stream=C.c_void_p(stream))
+    grads = None
+    if world > 1:
+        ptr, n = t.dqn.grad_buffer()
+        grads = xd.wrap_device_floats(ptr, n)
+
+    def one_step():
+        t.collect()
+        t.learn_grads()
+        if grads is not None:
+            xd.allreduce_gradients(grads, world)
+        t.learn_apply(world)
+
+    for _ in range(args.warmup):
+        one_step()
+    t.dqn.kernel_stats(enable=2 if args.profile_all else 3)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = xd.max_over_ranks(elapsed, device="cuda" if world > 1 else "cpu")
+    stats = {s["name"]: s for s in t.dqn.kernel_stats(enable=0)}
+
+    if rank == 0:
+        env_steps = world * N_GAMES * args.steps
+        line = {
+            "metric": "env steps/sec + DQN updates/sec at 8192 parallel games, 1/2/4/8 MI355X",
+            "value": env_steps / elapsed, "unit": "env steps/s",
+            "updates_per_s": args.steps / elapsed,
+            "transitions_trained_per_s": world * MINIBATCH * args.steps / elapsed,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 8192 self-play games per GPU, DQN 1260-256-256-8100 fp32, "
+                                   "replay 1M transitions, minibatch 8192, one update per ply",
+                       "games_per_gpu": N_GAMES, "layer_sizes": list(LAYERS), "replay_capacity": REPLAY,
+                       "minibatch": MINIBATCH, "epsilon": 0.1, "td_net": "target", "backprop": "reference-compatible",
+                       "parallelism": f"dp{world} (games sharded, gradient all-reduce per update)" if world > 1 else "1 GPU"},
+        }
+        g = stats.get("gemm_qmax_rowmax")
+        if g and g["launches"]:
+            ms = g["ms"] / g["launches"]
+            fl = g["flops"] / g["launches"]
+            ach = fl / (ms * 1e-3) / 1e12
+            line["roofline"] = {"kernel": "gemm_f32_kernel<KCONTIG,KCONTIG,ROWMAX> (max_a' Q(s'), 8192x8100x256)",
+                                "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms,
+                                "flops_per_launch": fl, "launches": g["launches"]}
+        e = stats.get("env_selfplay_step")
+        if e and e["launches"]:
+            ms = e["ms"] / e["launches"]
+            by = e["bytes"] / e["launches"]
+            ach = by / (ms * 1e-3) / 1e9
+            line["roofline_env"] = {"kernel": "env_kernel<SELFPLAY> (movegen+select+move+reward+reset, 8192 boards)",
+                                    "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": ms,
+                                    "bytes_per_launch": by, "launches": e["launches"]}
+        if args.profile_all:
+            line["kernels"] = {k: {"ms_per_launch": v["ms"] / max(v["launches"], 1), "launches": v["launches"]}
+                               for k, v in stats.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    t.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -797,9 +797,10 @@ int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_st
         }
     }
     if (n_stats) *n_stats = n;
-    if (enable >= 0) {
-        if ((enable != 0) != d->prof.enabled || enable == 2) d->prof.reset();   // 2 = enable and clear
+    if (enable >= 0) {   // 0 off, 1 on, 2 on + clear, 3 on + clear, only the kernels bench.py prices (roofline leg)
+        if ((enable != 0) != d->prof.enabled || enable >= 2) d->prof.reset();
         d->prof.enabled = enable != 0;
+        d->prof.roofline_only = enable == 3;
     }
     return XQ_OK;
 }

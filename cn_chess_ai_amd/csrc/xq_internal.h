@@ -57,6 +57,7 @@ struct Profiler {
     struct Cat { char name[48]; double flops = 0, bytes = 0; int launches = 0; float ms = 0; };
     struct Rec { int cat; hipEvent_t a, b; };
     bool enabled = false;
+    bool roofline_only = false;   // bracket only the two kernels bench.py prices (keeps the timed region undisturbed)
     std::vector<Cat> cats;
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -72,6 +73,7 @@ struct Profiler {
     }
     int begin(const char* name, hipStream_t s) {
         if (!enabled) return -1;
+        if (roofline_only && strcmp(name, "gemm_qmax_rowmax") != 0 && strcmp(name, "env_selfplay_step") != 0) return -1;
         Rec r; r.cat = cat_id(name); r.a = get_event(); r.b = get_event();
         (void)hipEventRecord(r.a, s);
         recs.push_back(r);

@@ -203,7 +203,8 @@ int xq_dqn_td_update_host(xq_dqn* d, int n, const uint8_t* boards90, const uint8
                           double learning_rate, double grad_scale, float* q_sa_out, float* y_out);
 /* Sum-of-squared TD error of the last xq_dqn_td_grads (synchronises). */
 int xq_dqn_last_loss(xq_dqn* d, double* loss);
-/* Per-kernel HIP-event timing of the last td_grads/forward call sequence, for bench.py (name -> ms, launches). */
+/* Per-kernel HIP-event timing on the handle stream, for bench.py (name -> summed ms, launches, algorithmic flops/bytes).
+ * enable: -1 leave, 0 off, 1 on, 2 on + clear, 3 on + clear but bracket only gemm_qmax_rowmax and env_selfplay_step. */
 typedef struct { char name[48]; float ms; int launches; double flops; double bytes; } xq_kernel_stat;
 int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_stats, int* n_stats);
 
