@@ -333,7 +333,7 @@ int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev
     return XQ_OK;
 }
 
-// conditions under which dqn.cu:406-423 as written stays inside its buffers (same as oracle/xq_oracle.c)
+// conditions under which dqn.cu:406-423 as written stays inside its buffers (last paragraph)
 static int check_reference_topology(const xq_dqn* d) {
     for (int l = d->nl - 2; l >= 0; --l) {
         const int inputSize = d->L[l + 1], outputSize = d->L[l];

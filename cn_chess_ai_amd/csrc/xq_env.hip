@@ -315,7 +315,7 @@ int xq_device_count(int* n) {
     if (!n) return fail(XQ_ERR_INVALID_ARGUMENT, "null pointer");
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
-    if (e != hipSuccess) { *n = 0; return fail(XQ_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { *n = 0; return fail(XQ_ERR_NO_DEVICE, "hipGetDeviceCount: %s — libxqhip has no CPU fallback", hipGetErrorString(e)); }
     *n = c;
     return XQ_OK;
 }

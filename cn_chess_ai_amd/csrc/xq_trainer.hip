@@ -31,6 +31,9 @@ int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer
     if (cfg->replay_capacity != 0 && cfg->replay_capacity < cfg->n_games)
         return fail(XQ_ERR_INVALID_ARGUMENT, "replay_capacity must be 0 (on-policy) or >= n_games");
     if (cfg->replay_capacity != 0 && cfg->minibatch <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "minibatch must be > 0");
+    int ndev = 0;
+    XQ_TRY(xq_device_count(&ndev));
+    if (ndev == 0) return fail(XQ_ERR_NO_DEVICE, "no HIP device: libxqhip has no CPU fallback");
     xq_trainer* t = new xq_trainer();
     t->cfg = *cfg;
     if (hip_stream) t->stream = (hipStream_t)hip_stream;
