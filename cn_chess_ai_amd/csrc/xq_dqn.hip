@@ -8,7 +8,7 @@
 //   max_a' Q(s') : the 8100-wide output GEMM never writes Q — its epilogue reduces max(z) per row (tanh is monotone);
 //   backward     : the TD target equals Q(s) except at action.to < 90 (chessai.cpp:122-128), so the output delta
 //                  lives in columns 0..95: delta GEMM with K = 96, weight-gradient GEMM with M = 96;
-//   layer-0 grad : one-hot^T x delta as an MFMA GEMM whose A operand is decoded from the packed boards on the fly;
+//   layer-0 grad : one-hot^T x delta as per-(square, piece) segmented sums of delta rows (ordered, in LDS accumulators);
 //   reductions over the batch are split-K into slabs + an ordered slab sum: bitwise reproducible, no float atomics.
 // Device parameter layout (one flat fp32 buffer per net): [W0^T (L0 x L1)] [W_1 .. W_out, reference layout
 // row-major [out][in], concatenated] [b_0 .. b_out].  Keeping layers >= 1 in the reference's flat order lets the
@@ -42,12 +42,14 @@ struct xq_dqn {
     float* qsa = nullptr;
     float* yv = nullptr;
     float* lossv = nullptr;
+    uint32_t* gboards = nullptr;                // [cap][12] boards of the current minibatch, gathered
     int last_n = 0;
     // gradients
     float* grads_td = nullptr;  size_t n_grads_td = 0;
     size_t g_w0 = 0, g_wh[XQ_MAX_LAYERS] = {0}, g_wout = 0, g_bh[XQ_MAX_LAYERS] = {0}, g_bout = 0;
     float* grads_full = nullptr;
     float* slabs = nullptr;  size_t slabs_cap = 0;
+    float* bias_work = nullptr;  size_t bias_work_cap = 0;
     // dense API scratch
     float* xdense = nullptr;  size_t xdense_cap = 0;
     float* qfull = nullptr;   size_t qfull_cap = 0;
@@ -83,13 +85,15 @@ struct ProfScope {
 // One wave per sample; ascending square order = the reference's i-ascending accumulation with the zeros skipped.
 __global__ __launch_bounds__(256) void l0_forward_kernel(const uint32_t* __restrict__ boards, const int32_t* __restrict__ slots,
                                                          int n, const float* __restrict__ W0T, const float* __restrict__ b0,
-                                                         int H, float* __restrict__ out) {
+                                                         int H, float* __restrict__ out, uint32_t* __restrict__ gathered) {
     __shared__ int rows[4][96];
     const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int b = (int)blockIdx.x * 4 + wid;
     if (b >= n) return;
     const int srow = slots ? slots[b] : b;
     const uint32_t* bw = boards + (long long)srow * kBoardWords;
+    if (gathered != nullptr && lane < kBoardWords)      // the minibatch's boards, contiguous, for the one-hot gradient GEMM
+        gathered[(long long)b * kBoardWords + lane] = bw[lane];
     const int s0 = lane, s1 = 64 + lane;
     const uint32_t n0 = (bw[s0 >> 3] >> (4 * (s0 & 7))) & 15u;
     const uint32_t n1 = s1 < kSquares ? (bw[s1 >> 3] >> (4 * (s1 & 7))) & 15u : 0u;
@@ -129,6 +133,90 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(const uint32_t* __restr
             for (int i = 0; i < cnt; ++i) acc += W0T[(long long)rows[wid][i] * H + col];
             o[col] = tanhf(acc);
         }
+    }
+}
+
+// Layer-0 weight gradient gW0^T[(sq,piece)][:] = sum over the samples that have `piece` on `sq` of delta_0[sample][:]
+// (the one-hot input of chessai.cpp:268-289 transposed).  A dense one-hot GEMM would spend 2*1260*H FLOP per sample on
+// zeros; here block (sq, chunk) compacts the samples of its chunk that occupy `sq` (ascending sample order, so the sums
+// are bitwise reproducible), then streams their delta rows (1 KB each, L2-resident) into 14 LDS accumulator rows.
+// partial[chunk][sq*14 + piece-1][H]; the ordered chunk reduction is the usual reduce_slabs_kernel.
+__global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict__ gboards, const float* __restrict__ delta0,
+                                                      int n, int H, int chunk, int nsets, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* acc = smem;                                  // [nsets][14][H]
+    uint16_t* list = reinterpret_cast<uint16_t*>(smem + (long long)nsets * 14 * H);   // [chunk] (b_local | piece << 11)
+    __shared__ int wcount[4];
+    __shared__ int total;
+    const int s = (int)blockIdx.x;
+    const int c0 = (int)blockIdx.y * chunk;
+    const int c1 = min(n, c0 + chunk);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < nsets * 14 * H; i += 256) acc[i] = 0.f;
+    if (tid == 0) total = 0;
+    __syncthreads();
+    // phase 1: ordered compaction of the occupied samples
+    for (int base = c0; base < c1; base += 256) {
+        const int b = base + tid;
+        uint32_t nib = 0;
+        if (b < c1) nib = (gboards[(long long)b * kBoardWords + (s >> 3)] >> (4 * (s & 7))) & 15u;
+        const unsigned long long m = __ballot(nib != 0);
+        if (lane == 0) wcount[wid] = __popcll(m);
+        __syncthreads();
+        int off = total;
+        for (int w = 0; w < wid; ++w) off += wcount[w];
+        if (nib) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((b - c0) | (nib << 11));
+        __syncthreads();
+        if (tid == 0) total += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    const int cnt = total;
+    // phase 2: wave w streams list entries w, w+nsets, ... (whole 1-KB rows as float4 per lane, 8 rows in flight per
+    // wave) into ITS OWN accumulator set; the sets are added in fixed order afterwards => bitwise reproducible
+    if (wid < nsets && (H & 3) == 0) {
+        float* my = acc + (long long)wid * 14 * H;
+        for (int col = lane * 4; col < H; col += 256) {
+            int i = wid;
+            for (; i + 7 * nsets < cnt; i += 8 * nsets) {
+                int e[8];
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    e[u] = list[i + u * nsets];
+                    const float4 x = *reinterpret_cast<const float4*>(delta0 + (long long)(c0 + (e[u] & 2047)) * H + col);
+                    v[u].x = x.x; v[u].y = x.y; v[u].z = x.z; v[u].w = x.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float4* a = reinterpret_cast<float4*>(my + ((e[u] >> 11) - 1) * H + col);
+                    float4 t = *a;
+                    t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w;
+                    *a = t;
+                }
+            }
+            for (; i < cnt; i += nsets) {
+                const int e1 = list[i];
+                const float4 x = *reinterpret_cast<const float4*>(delta0 + (long long)(c0 + (e1 & 2047)) * H + col);
+                float4* a = reinterpret_cast<float4*>(my + ((e1 >> 11) - 1) * H + col);
+                float4 t = *a;
+                t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+                *a = t;
+            }
+        }
+    } else if ((H & 3) != 0 && wid == 0) {
+        for (int col = lane; col < H; col += 64)
+            for (int i = 0; i < cnt; ++i) {
+                const int e1 = list[i];
+                acc[((e1 >> 11) - 1) * H + col] += delta0[(long long)(c0 + (e1 & 2047)) * H + col];
+            }
+    }
+    __syncthreads();
+    float* out = partial + ((long long)blockIdx.y * kStateSize + (long long)s * 14) * H;
+    const int used = (H & 3) == 0 ? nsets : 1;
+    for (int i = tid; i < 14 * H; i += 256) {
+        float t = acc[i];
+        for (int w = 1; w < used; ++w) t += acc[(long long)w * 14 * H + i];
+        out[i] = t;
     }
 }
 
@@ -180,27 +268,64 @@ __global__ void out_delta_dense_kernel(const float* __restrict__ q, const float*
     }
 }
 
-// column sums of X[n][C] (bias gradients): partial[z][c] over row chunk z
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long long ld, int n, int C, int rows_per,
-                                                             float* __restrict__ partial) {
+// Bias gradients = column sums of the delta matrices.  All layers of one TD step go through ONE launch (job table)
+// of partial sums over row chunks, then ONE ordered reduction launch (deterministic, no atomics).
+struct ColsumJobs {
+    const float* X[XQ_MAX_LAYERS + 1];
+    long long ld[XQ_MAX_LAYERS + 1];
+    int C[XQ_MAX_LAYERS + 1];
+    float* dst[XQ_MAX_LAYERS + 1];
+    long long poff[XQ_MAX_LAYERS + 1];   // offset of the job's [R][C] partial block in the workspace
+    int njobs, n, rows_per, R;
+    float* work;
+};
+__global__ __launch_bounds__(256) void colsum_partial_kernel(ColsumJobs J) {
     __shared__ float red[4][64];
+    const int job = (int)blockIdx.z;
+    const int C = J.C[job];
     const int tx = (int)(threadIdx.x & 63), ty = (int)(threadIdx.x >> 6);
     const int c = (int)blockIdx.x * 64 + tx;
-    const int r0 = (int)blockIdx.y * rows_per, r1 = min(n, r0 + rows_per);
-    float s = 0.f;
-    if (c < C)
-        for (int r = r0 + ty; r < r1; r += 4) s += X[(long long)r * ld + c];
-    red[ty][tx] = s;
+    if ((int)blockIdx.x * 64 >= C) return;
+    const float* X = J.X[job];
+    const long long ld = J.ld[job];
+    const int r0 = (int)blockIdx.y * J.rows_per, r1 = min(J.n, r0 + J.rows_per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int r = r0 + ty;
+        for (; r + 12 < r1; r += 16) {
+            s0 += X[(long long)r * ld + c];
+            s1 += X[(long long)(r + 4) * ld + c];
+            s2 += X[(long long)(r + 8) * ld + c];
+            s3 += X[(long long)(r + 12) * ld + c];
+        }
+        for (; r < r1; r += 4) s0 += X[(long long)r * ld + c];
+    }
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (ty == 0 && c < C) partial[(long long)blockIdx.y * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (ty == 0 && c < C)
+        J.work[J.poff[job] + (long long)blockIdx.y * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(ColsumJobs J) {
+    const int job = (int)blockIdx.y;
+    const int C = J.C[job];
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= C) return;
+    const float* p = J.work + J.poff[job] + c;
+    float s0 = 0.f, s1 = 0.f;
+    int z = 0;
+    for (; z + 1 < J.R; z += 2) { s0 += p[(long long)z * C]; s1 += p[(long long)(z + 1) * C]; }
+    if (z < J.R) s0 += p[(long long)z * C];
+    J.dst[job][c] = s0 + s1;
 }
 
 // out[i] = sum_z slabs[z*stride + i], z ascending (deterministic)
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs, long long stride, long long len, float* __restrict__ out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int z = 0; z < nslabs; ++z) s += slabs[(long long)z * stride + i];
-        out[i] = s;
+        float s0 = 0.f, s1 = 0.f;
+        int z = 0;
+        for (; z + 1 < nslabs; z += 2) { s0 += slabs[(long long)z * stride + i]; s1 += slabs[(long long)(z + 1) * stride + i]; }
+        if (z < nslabs) s0 += slabs[(long long)z * stride + i];
+        out[i] = s0 + s1;
     }
 }
 
@@ -225,19 +350,28 @@ __global__ void sgd_segments_kernel(SegTable t, float alpha) {
 // ---------------------------------------------------------------------------------------------------------------
 static inline int vec_ok(const void* p, long long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }
 
+// tile choice: 128x128 when that grid already fills the chip twice over, else 64x64 (4x the blocks)
 template <int AL, int BL, int EPI>
-static int launch_gemm(xq_dqn* d, GemmArgs g, int splits, const char* name, int* used_splits = nullptr) {
+static int launch_gemm(xq_dqn* d, GemmArgs g, int splits, const char* name, int* used_splits = nullptr, bool force_small = false,
+                       bool force_big = false) {
     if (used_splits) *used_splits = 0;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "empty GEMM %s (%d x %d x %d)", name, g.M, g.N, g.K);
-    g.a_vec = (AL == L_ONEHOT) ? 0 : vec_ok(g.A, g.lda);
+    g.a_vec = vec_ok(g.A, g.lda);
     g.b_vec = vec_ok(g.B, g.ldb);
     if (splits < 1) splits = 1;
     g.k_chunk = round_up((g.K + splits - 1) / splits, GBK);
     splits = (g.K + g.k_chunk - 1) / g.k_chunk;
     if (splits < 1) splits = 1;
-    dim3 grid((g.M + GBM - 1) / GBM, (g.N + GBN - 1) / GBN, splits);
+    const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * splits;
+    const bool big = force_big || (!force_small && t128 >= 512);
     ProfScope ps(d, name, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
-    hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI>), grid, dim3(256), 0, d->stream, g);
+    if (big) {
+        dim3 grid((g.M + 127) / 128, (g.N + 127) / 128, splits);
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI, 2, 2>), grid, dim3(256), 0, d->stream, g);
+    } else {
+        dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, splits);
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI, 1, 1>), grid, dim3(256), 0, d->stream, g);
+    }
     XQ_HIP(hipGetLastError());
     if (used_splits) *used_splits = splits;
     return XQ_OK;
@@ -276,25 +410,28 @@ static int ensure_capacity(xq_dqn* d, int n) {
         if (d->tacts[i]) XQ_HIP(hipFree(d->tacts[i]));
         XQ_HIP(hipMalloc(&d->tacts[i], cap * (size_t)maxh * sizeof(float)));
     }
-    const int ntn = (d->nout() + GBN - 1) / GBN;
+    const int ntn = (d->nout() + 63) / 64;             // column-max partials: 2 per 64- or 128-row tile
     float** bufs[] = {&d->d2, &d->q90, &d->partial, &d->qsa, &d->yv, &d->lossv};
     const size_t sizes[] = {cap * 96, cap * 96, cap * (size_t)ntn * 2, cap, cap, cap};
     for (int i = 0; i < 6; ++i) {
         if (*bufs[i]) XQ_HIP(hipFree(*bufs[i]));
         XQ_HIP(hipMalloc(bufs[i], sizes[i] * sizeof(float)));
     }
+    if (d->gboards) XQ_HIP(hipFree(d->gboards));
+    XQ_HIP(hipMalloc(&d->gboards, cap * kBoardWords * sizeof(uint32_t)));
     d->cap = n;
     return XQ_OK;
 }
 
 // a_1 .. a_{nl-1} for n packed boards; outs[l] receives a_{l+1}
-static int chain_boards(xq_dqn* d, int net, const uint32_t* boards, const int32_t* slots, int n, float* const* outs) {
+static int chain_boards(xq_dqn* d, int net, const uint32_t* boards, const int32_t* slots, int n, float* const* outs,
+                        uint32_t* gathered = nullptr) {
     if (d->L[0] != kStateSize) return fail(XQ_ERR_INVALID_ARGUMENT, "board input needs layer_sizes[0] == 1260 (got %d)", d->L[0]);
     {
         const int H = d->L[1];
         ProfScope ps(d, "l0_forward_gather", 2.0 * n * 32 * H, (double)n * (48 + 32.0 * H * 4 + H * 4));
         hipLaunchKernelGGL(l0_forward_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, boards, slots, n, d->w0t(net),
-                           d->bl(net, 0), H, outs[0]);
+                           d->bl(net, 0), H, outs[0], gathered);
         XQ_HIP(hipGetLastError());
     }
     for (int l = 1; l + 1 < d->nl; ++l) {
@@ -367,16 +504,18 @@ static int hidden_deltas(xq_dqn* d, int n, const float* dnext, int ld_next, int 
     return XQ_OK;
 }
 
+// gradient GEMMs always use 64x64 tiles: more tiles => fewer k-splits => less slab traffic in the ordered reduction
 static int pick_splits(int M, int N, int K) {
-    const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
+    const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
     int s = (512 + tiles - 1) / tiles;
-    s = std::min(s, std::max(1, K / 64));
-    return std::max(1, std::min(s, 256));
+    s = std::min(s, std::max(1, K / 128));
+    return std::max(1, std::min(s, 32));
 }
 
 // dst[M][N] = sum over the batch: A(m,k) B(k,n), split-K slabs + ordered reduction
 template <int AL>
 static int grad_gemm(xq_dqn* d, GemmArgs g, float* dst, const char* name) {
+    const bool big = false;    // 64-tiles: more tiles, fewer k-splits, cheaper ordered reduction
     int splits = pick_splits(g.M, g.N, g.K);
     const long long len = (long long)g.M * g.N;
     if (splits > 1) {
@@ -386,7 +525,7 @@ static int grad_gemm(xq_dqn* d, GemmArgs g, float* dst, const char* name) {
         g.C = dst; g.ldc = g.N; g.slab_stride = 0;
     }
     int used = 0;
-    XQ_TRY((launch_gemm<AL, L_MCONTIG, EPI_STORE>(d, g, splits, name, &used)));
+    XQ_TRY((launch_gemm<AL, L_MCONTIG, EPI_STORE>(d, g, splits, name, &used, !big, big)));
     if (splits > 1) {
         ProfScope ps(d, "reduce_slabs", (double)used * len, 4.0 * (used + 1) * len);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)std::min<long long>((len + 255) / 256, 2048)), dim3(256), 0,
@@ -396,15 +535,35 @@ static int grad_gemm(xq_dqn* d, GemmArgs g, float* dst, const char* name) {
     return XQ_OK;
 }
 
-static int bias_grad(xq_dqn* d, const float* X, long long ld, int n, int C, float* dst) {
-    const int R = std::max(1, std::min(64, n / 64));
-    const int rows_per = (n + R - 1) / R;
-    XQ_TRY(ensure_slabs(d, (size_t)R * C));
-    ProfScope ps(d, "bias_grad_colsum", (double)n * C, 4.0 * n * C);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, R), dim3(256), 0, d->stream, X, ld, n, C, rows_per, d->slabs);
+struct BiasJobs {
+    ColsumJobs J;
+    BiasJobs() { memset(&J, 0, sizeof J); }
+    void add(const float* X, long long ld, int C, float* dst) {
+        const int k = J.njobs++;
+        J.X[k] = X; J.ld[k] = ld; J.C[k] = C; J.dst[k] = dst;
+    }
+};
+static int bias_grads(xq_dqn* d, BiasJobs& bj, int n) {
+    ColsumJobs& J = bj.J;
+    if (J.njobs == 0) return XQ_OK;
+    J.n = n;
+    J.R = std::max(1, std::min(64, n / 64));
+    J.rows_per = (n + J.R - 1) / J.R;
+    long long off = 0;
+    int maxc = 0;
+    for (int k = 0; k < J.njobs; ++k) { J.poff[k] = off; off += (long long)J.R * J.C[k]; maxc = std::max(maxc, J.C[k]); }
+    if ((size_t)off > d->bias_work_cap) {
+        if (d->bias_work) { XQ_HIP(hipStreamSynchronize(d->stream)); XQ_HIP(hipFree(d->bias_work)); }
+        XQ_HIP(hipMalloc(&d->bias_work, (size_t)off * sizeof(float)));
+        d->bias_work_cap = (size_t)off;
+    }
+    J.work = d->bias_work;
+    double tot = 0;
+    for (int k = 0; k < J.njobs; ++k) tot += (double)n * J.C[k];
+    ProfScope ps(d, "bias_grad_colsum", tot, 4.0 * tot);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((maxc + 63) / 64, J.R, J.njobs), dim3(256), 0, d->stream, J);
     XQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((C + 255) / 256), dim3(256), 0, d->stream, d->slabs, R, (long long)C,
-                       (long long)C, dst);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((maxc + 255) / 256, J.njobs), dim3(256), 0, d->stream, J);
     XQ_HIP(hipGetLastError());
     return XQ_OK;
 }
@@ -479,8 +638,8 @@ int xq_dqn_destroy(xq_dqn* d) {
     hipStreamSynchronize(d->stream);
     for (int i = 0; i < 2; ++i) { hipFree(d->params[i]); hipFree(d->tacts[i]); }
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts[l]); hipFree(d->deltas[l]); }
-    hipFree(d->d2); hipFree(d->q90); hipFree(d->partial); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
-    hipFree(d->grads_td); hipFree(d->grads_full); hipFree(d->slabs); hipFree(d->xdense); hipFree(d->qfull); hipFree(d->tfull);
+    hipFree(d->gboards); hipFree(d->d2); hipFree(d->q90); hipFree(d->partial); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
+    hipFree(d->grads_td); hipFree(d->grads_full); hipFree(d->slabs); hipFree(d->bias_work); hipFree(d->xdense); hipFree(d->qfull); hipFree(d->tfull);
     hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
     d->prof.collect();
     if (d->own_stream) hipStreamDestroy(d->stream);
@@ -610,13 +769,14 @@ int xq_dqn_backpropagate(xq_dqn* d, const double* states, const double* targets,
     // gradients, full layout = parameter layout
     float* gw = d->grads_full;
     float* gb = d->grads_full + d->nw;
+    BiasJobs bj;
     {   // layer 0: gW0^T[in][out] = X^T delta_0
         GemmArgs g; memset(&g, 0, sizeof g);
         g.M = d->L[0]; g.N = d->L[1]; g.K = n;
         g.A = d->xdense; g.lda = d->L[0];
         g.B = d->deltas[0]; g.ldb = d->L[1];
         XQ_TRY((grad_gemm<L_MCONTIG>(d, g, gw, "gemm_grad_l0_dense")));
-        XQ_TRY(bias_grad(d, d->deltas[0], d->L[1], n, d->L[1], gb + d->bo[0]));
+        bj.add(d->deltas[0], d->L[1], d->L[1], gb + d->bo[0]);
     }
     for (int l = 1; l < d->nl; ++l) {   // gW_l[out][in] = delta_l^T a_l
         const float* dl = (l == d->nl - 1) ? dout : d->deltas[l];
@@ -626,8 +786,9 @@ int xq_dqn_backpropagate(xq_dqn* d, const double* states, const double* targets,
         g.A = dl; g.lda = ldd;
         g.B = d->acts[l - 1]; g.ldb = d->L[l];
         XQ_TRY((grad_gemm<L_MCONTIG>(d, g, gw + d->wo[l], "gemm_grad_dense")));
-        XQ_TRY(bias_grad(d, dl, ldd, n, d->L[l + 1], gb + d->bo[l]));
+        bj.add(dl, ldd, d->L[l + 1], gb + d->bo[l]);
     }
+    XQ_TRY(bias_grads(d, bj, n));
     SegTable t; memset(&t, 0, sizeof t);
     t.nseg = 1; t.dst[0] = d->params[0]; t.src[0] = d->grads_full; t.len[0] = (long long)(d->nw + d->nb);
     XQ_TRY(sgd_apply(d, t, lr * grad_scale));
@@ -649,25 +810,28 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
     float* touts[XQ_MAX_LAYERS];
     for (int l = 0; l + 1 < nl; ++l) touts[l] = d->tacts[l & 1];
     XQ_TRY(chain_boards(d, td_net, next_boards, slots, n, touts));
-    const int ntn = (NO + GBN - 1) / GBN;
+    // launched transposed (rows = output neurons, columns = samples): the max over the 8100 outputs then runs over
+    // accumulator registers inside one lane instead of across the 32 lanes of a row
+    const bool big_tiles = (long long)((NO + 127) / 128) * ((n + 127) / 128) >= 512;
+    const int n_partial = 2 * (big_tiles ? (NO + 127) / 128 : (NO + 63) / 64);
     {
         GemmArgs g; memset(&g, 0, sizeof g);
-        g.M = n; g.N = NO; g.K = Hl;
-        g.A = touts[nl - 2]; g.lda = Hl;
-        g.B = d->wl(td_net, nl - 1); g.ldb = Hl;
+        g.M = NO; g.N = n; g.K = Hl;
+        g.A = d->wl(td_net, nl - 1); g.lda = Hl;
+        g.B = touts[nl - 2]; g.ldb = Hl;
         g.bias = d->bl(td_net, nl - 1);
         g.partial = d->partial;
-        XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_ROWMAX>(d, g, 1, "gemm_qmax_rowmax")));
+        XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_COLMAX>(d, g, 1, "gemm_qmax_rowmax")));
     }
     // 2. s chain on the online net (activations kept)
     float* outs[XQ_MAX_LAYERS];
     for (int l = 0; l + 1 < nl; ++l) outs[l] = d->acts[l];
-    XQ_TRY(chain_boards(d, XQ_NET_ONLINE, boards, slots, n, outs));
+    XQ_TRY(chain_boards(d, XQ_NET_ONLINE, boards, slots, n, outs, d->gboards));
     // 3. Q(s, a), target, output delta
     {
-        ProfScope ps(d, "td_target_delta", 2.0 * n * Hl, (double)n * (Hl * 8 + ntn * 8 + 96 * 4));
+        ProfScope ps(d, "td_target_delta", 2.0 * n * Hl, (double)n * (Hl * 8 + n_partial * 4 + 96 * 4));
         hipLaunchKernelGGL(td_delta_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, n, slots, action_to, reward, done,
-                           outs[nl - 2], Hl, d->wl(XQ_NET_ONLINE, nl - 1), d->bl(XQ_NET_ONLINE, nl - 1), d->partial, ntn * 2,
+                           outs[nl - 2], Hl, d->wl(XQ_NET_ONLINE, nl - 1), d->bl(XQ_NET_ONLINE, nl - 1), d->partial, n_partial,
                            (float)d->gamma, d->d2, d->qsa, d->yv, d->lossv);
         XQ_HIP(hipGetLastError());
     }
@@ -676,13 +840,14 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
     XQ_TRY(hidden_deltas(d, n, d->d2, 96, 96, mode));
     // 5. gradients (compact layout)
     float* G = d->grads_td;
+    BiasJobs bj;
     {   // output layer rows 0..95
         GemmArgs g; memset(&g, 0, sizeof g);
         g.M = 96; g.N = Hl; g.K = n;
         g.A = d->d2; g.lda = 96;
         g.B = outs[nl - 2]; g.ldb = Hl;
         XQ_TRY((grad_gemm<L_MCONTIG>(d, g, G + d->g_wout, "gemm_grad_out96")));
-        XQ_TRY(bias_grad(d, d->d2, 96, n, 96, G + d->g_bout));
+        bj.add(d->d2, 96, 96, G + d->g_bout);
     }
     for (int l = nl - 2; l >= 1; --l) {
         GemmArgs g; memset(&g, 0, sizeof g);
@@ -690,17 +855,35 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
         g.A = d->deltas[l]; g.lda = d->L[l + 1];
         g.B = outs[l - 1]; g.ldb = d->L[l];
         XQ_TRY((grad_gemm<L_MCONTIG>(d, g, G + d->g_wh[l], "gemm_grad_hidden")));
-        XQ_TRY(bias_grad(d, d->deltas[l], d->L[l + 1], n, d->L[l + 1], G + d->g_bh[l]));
+        bj.add(d->deltas[l], d->L[l + 1], d->L[l + 1], G + d->g_bh[l]);
     }
-    {   // layer 0: one-hot^T x delta_0, A decoded from the packed boards
-        GemmArgs g; memset(&g, 0, sizeof g);
-        g.M = d->L[0]; g.N = d->L[1]; g.K = n;
-        g.boards = boards; g.slots = slots;
-        g.A = nullptr; g.lda = 0;
-        g.B = d->deltas[0]; g.ldb = d->L[1];
-        XQ_TRY((grad_gemm<L_ONEHOT>(d, g, G + d->g_w0, "gemm_grad_l0_onehot")));
-        XQ_TRY(bias_grad(d, d->deltas[0], d->L[1], n, d->L[1], G + d->g_bh[0]));
+    {   // layer 0: per-(square, piece) segmented sums of delta_0 rows (no dense one-hot product)
+        const int H = d->L[1];
+        const int chunk = 1024;                          // samples per block; list entries hold 11 bits of sample index
+        const int nchunks = (n + chunk - 1) / chunk;
+        const long long len = (long long)kStateSize * H;
+        float* dst = G + d->g_w0;
+        float* out = dst;
+        if (nchunks > 1) { XQ_TRY(ensure_slabs(d, (size_t)nchunks * (size_t)len)); out = d->slabs; }
+        {
+            ProfScope ps(d, "l0_grad_segsum", 2.0 * n * 32 * H, (double)n * (32.0 * H * 4 + 48) + 4.0 * nchunks * len);
+            int nsets = 4;                               // one accumulator set per wave while they fit in 60 KB of LDS
+            while (nsets > 1 && (size_t)nsets * 14 * H * sizeof(float) > 60 * 1024) nsets >>= 1;
+            const size_t shmem = (size_t)nsets * 14 * H * sizeof(float) + (size_t)chunk * sizeof(uint16_t);
+            if (shmem > 64 * 1024) return fail(XQ_ERR_INVALID_ARGUMENT, "first hidden layer too wide for the layer-0 gradient kernel (%d)", H);
+            hipLaunchKernelGGL(l0_grad_kernel, dim3(kSquares, nchunks), dim3(256), shmem, d->stream, d->gboards, d->deltas[0], n,
+                               H, chunk, nsets, out);
+            XQ_HIP(hipGetLastError());
+        }
+        if (nchunks > 1) {
+            ProfScope ps(d, "reduce_slabs", (double)nchunks * len, 4.0 * (nchunks + 1) * len);
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)std::min<long long>((len + 255) / 256, 2048)), dim3(256), 0,
+                               d->stream, d->slabs, nchunks, len, len, dst);
+            XQ_HIP(hipGetLastError());
+        }
+        bj.add(d->deltas[0], d->L[1], d->L[1], G + d->g_bh[0]);
     }
+    XQ_TRY(bias_grads(d, bj, n));
     return XQ_OK;
 }
 

@@ -2,19 +2,18 @@
 //
 // One template serves every dense contraction of the Q-network (reference dqn.cu kernels forwardKernel :184/:275,
 // hiddenLayerDeltaKernel :297, updateWeightsBiasesKernel :310 — there one thread per output neuron with a serial
-// loop over inputs and batch 1; here batched, 128x128x32 block tiles, 4 waves of 64 lanes, each wave a 64x64
-// sub-tile = 2x2 MFMA tiles with 16 accumulator registers each).
+// loop over inputs and batch 1; here batched, (64*TM)x(64*TN)x32 block tiles — 128x128 for the large products,
+// 64x64 where a 128-tile grid would leave CUs idle — 4 waves of 64 lanes, each wave TM x TN MFMA tiles of 32x32 with
+// 16 accumulator registers each).
 //
 //   C[m][n] (+epilogue) = sum_k A(m,k) * B(k,n)
 //
 // Operand layouts (how the logical operand sits in HBM):
 //   KCONTIG : X[row][k], ld = row stride      (activations [batch][features]; weights W[out][in] used as B(k,n)=W[n][k])
 //   MCONTIG : X[k][row], ld = k stride        (weights used as B(k,n)=W[k][n]; deltas [batch][out] used as A(m=out,k=batch))
-//   ONEHOT  : A only: row = feature f in [0,1260), k = sample; value = 1 if the packed board of sample k has piece
-//             code f%14+1 on square f/14 — the one-hot of reference chessai.cpp:268-289, never materialised.
-// LDS images: KCONTIG tiles are [128][36] floats read with ds_read_b128 (k = 8c+4h+t for MFMA t of chunk c, lane half
+// LDS images: KCONTIG tiles are [rows][36] floats read with ds_read_b128 (k = 8c+4h+t for MFMA t of chunk c, lane half
 // h — both operands use the same k permutation, so any order is a valid contraction order); MCONTIG tiles are
-// [32][132] floats read with ds_read_b32.  Both strides are conflict-free for their read instruction.
+// [32][rows+4] floats read with ds_read_b32.  Both strides are conflict-free for their read instruction.
 // fp32 MFMA runs at the fp32 vector rate (64 FLOP/clk/SIMD), 1/16 of bf16: the kernel is MFMA-bound long before LDS
 // or L2 bandwidth matter, so staging goes through registers (global_load_dwordx4 -> ds_write_b128) with the next
 // tile's loads in flight under the current tile's 64 MFMAs per wave.
@@ -26,13 +25,15 @@ namespace xq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { L_KCONTIG = 0, L_MCONTIG = 1, L_ONEHOT = 2 };
-enum { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_ROWMAX = 2, EPI_DELTA = 3 };
+enum { L_KCONTIG = 0, L_MCONTIG = 1 };
+// EPI_COLMAX: per column n, max over the rows m of (acc + bias[m]) — the GEMM is launched "transposed" (rows = output
+// neurons, columns = samples) so that the reduction runs over accumulator REGISTERS of one lane, not across lanes.
+enum { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_COLMAX = 2, EPI_DELTA = 3 };
 
-constexpr int GBM = 128, GBN = 128, GBK = 32;
-constexpr int G_LDK = GBK + 4;    // 36
-constexpr int G_LDM = GBM + 4;    // 132
-constexpr int G_TILE_FLOATS = GBM * G_LDK;   // 4608 >= 32*132 = 4224
+constexpr int GBK = 32;
+constexpr int G_LDK = GBK + 4;    // 36: row stride of a k-contiguous LDS tile
+// block tile = (64*TM) x (64*TN), 4 waves as 2x2, each wave TM x TN MFMA tiles of 32x32
+__host__ __device__ constexpr int g_tile_floats(int rows) { return rows * G_LDK > 32 * (rows + 4) ? rows * G_LDK : 32 * (rows + 4); }
 
 struct GemmArgs {
     int M, N, K;
@@ -41,24 +42,46 @@ struct GemmArgs {
     float* C; long long ldc;
     const float* bias;            // EPI_BIAS_TANH / EPI_ROWMAX: [N]
     const float* H; long long ldh;  // EPI_DELTA: activation a = tanh(z) of the layer the delta belongs to
-    float* partial;               // EPI_ROWMAX: [gridDim.y*2][M] partial row maxima of (acc + bias)
+    float* partial;               // EPI_COLMAX: [gridDim.x*2][N] partial column maxima of (acc + bias[m])
     int k_chunk;                  // split-K: k range of blockIdx.z is [z*k_chunk, min(K,(z+1)*k_chunk))
     long long slab_stride;        // split-K: C of split z = C + z*slab_stride
-    const uint32_t* boards;       // L_ONEHOT
-    const int32_t* slots;         // L_ONEHOT: optional row gather (replay slots)
     int a_vec, b_vec;             // 16-byte vector loads allowed (base and ld aligned)
+    int dbg;                      // tools/gemm_bench.hip only: 1 = no global loads in the k loop, 2 = no LDS restage/barriers
 };
 
 // ---- global -> register staging (4 x float4 per thread per operand) --------------------------------------------
-template <int LAYOUT>
+// FAST = the whole tile is interior and 16-byte aligned (decided once per block): unconditional global_load_dwordx4,
+// no per-element bounds logic — the checked path compiles to scalar loads with waits and must stay off the hot tiles.
+template <int LAYOUT, int ROWS, bool FAST>
 __device__ __forceinline__ void stage_load(const GemmArgs& g, const float* __restrict__ X, long long ld, int vec_ok,
-                                           int rows0, int R, int k0, int kend, float4 (&v)[4]) {
+                                           int rows0, int R, int k0, int kend, float4 (&v)[ROWS / 32]) {
+    constexpr int NV = ROWS / 32;          // float4 per thread
+    constexpr int TPR = ROWS / 4;          // threads per k-row of an m-contiguous tile
+    constexpr int KPP = 256 / TPR;         // k-rows per pass
     const int tid = (int)threadIdx.x;
+    if (FAST && LAYOUT == L_KCONTIG) {
+        const float* p = X + (long long)(rows0 + (tid >> 3)) * ld + k0 + (tid & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {     // element-wise copy: a whole-float4 assignment keeps v[] as a stack object
+            const float4 x = *reinterpret_cast<const float4*>(p + (long long)(32 * j) * ld);
+            v[j].x = x.x; v[j].y = x.y; v[j].z = x.z; v[j].w = x.w;
+        }
+        return;
+    }
+    if (FAST && LAYOUT == L_MCONTIG) {
+        const float* p = X + (long long)(k0 + (tid / TPR)) * ld + rows0 + (tid % TPR) * 4;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float4 x = *reinterpret_cast<const float4*>(p + (long long)(KPP * j) * ld);
+            v[j].x = x.x; v[j].y = x.y; v[j].z = x.z; v[j].w = x.w;
+        }
+        return;
+    }
     if (LAYOUT == L_KCONTIG) {
         const int kq = (tid & 7) * 4;
         const int k = k0 + kq;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int row = rows0 + (tid >> 3) + 32 * j;
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < R) {
@@ -75,11 +98,11 @@ __device__ __forceinline__ void stage_load(const GemmArgs& g, const float* __res
             v[j] = x;
         }
     } else if (LAYOUT == L_MCONTIG) {
-        const int mq = (tid & 31) * 4;
+        const int mq = (tid % TPR) * 4;
         const int row = rows0 + mq;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + (tid >> 5) + 8 * j;
+        for (int j = 0; j < NV; ++j) {
+            const int k = k0 + (tid / TPR) + KPP * j;
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < kend) {
                 const float* p = X + (long long)k * ld + row;
@@ -94,156 +117,172 @@ __device__ __forceinline__ void stage_load(const GemmArgs& g, const float* __res
             }
             v[j] = x;
         }
-    } else {  // L_ONEHOT: rows = features, k = samples
-        const int mq = (tid & 31) * 4;
-        const int f0 = rows0 + mq;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + (tid >> 5) + 8 * j;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < kend && f0 < R) {
-                const int srow = g.slots ? g.slots[k] : k;
-                const uint32_t* bw = g.boards + (long long)srow * kBoardWords;
-                float e[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int f = f0 + q;
-                    float val = 0.f;
-                    if (f < R) {
-                        const int s = f / 14, pc = f - s * 14;
-                        const uint32_t nib = (bw[s >> 3] >> (4 * (s & 7))) & 15u;
-                        val = (nib == (uint32_t)(pc + 1)) ? 1.f : 0.f;
-                    }
-                    e[q] = val;
-                }
-                x = make_float4(e[0], e[1], e[2], e[3]);
-            }
-            v[j] = x;
-        }
     }
 }
 
-template <int LAYOUT>
-__device__ __forceinline__ void stage_store(float* __restrict__ Xs, const float4 (&v)[4]) {
+template <int LAYOUT, int ROWS>
+__device__ __forceinline__ void stage_store(float* __restrict__ Xs, const float4 (&v)[ROWS / 32]) {
+    constexpr int NV = ROWS / 32, TPR = ROWS / 4, KPP = 256 / TPR, LDM = ROWS + 4;
     const int tid = (int)threadIdx.x;
     if (LAYOUT == L_KCONTIG) {
         const int kq = (tid & 7) * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int row = (tid >> 3) + 32 * j;
             *reinterpret_cast<float4*>(&Xs[row * G_LDK + kq]) = v[j];
         }
     } else {
-        const int mq = (tid & 31) * 4;
+        const int mq = (tid % TPR) * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kr = (tid >> 5) + 8 * j;
-            *reinterpret_cast<float4*>(&Xs[kr * G_LDM + mq]) = v[j];
+        for (int j = 0; j < NV; ++j) {
+            const int kr = (tid / TPR) + KPP * j;
+            *reinterpret_cast<float4*>(&Xs[kr * LDM + mq]) = v[j];
         }
     }
 }
 
 // fragments of chunk c (8 k values) for the wave's two 32-row sub-tiles
-template <int LAYOUT>
-__device__ __forceinline__ void frag_read(const float* __restrict__ Xs, int wbase, int c, int r, int h, float (&f)[2][4]) {
+template <int LAYOUT, int ROWS, int T>
+__device__ __forceinline__ void frag_read(const float* __restrict__ Xs, int wbase, int c, int r, int h, float (&f)[T][4]) {
+    constexpr int LDM = ROWS + 4;
     if (LAYOUT == L_KCONTIG) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < T; ++i) {
             const float4 x = *reinterpret_cast<const float4*>(&Xs[(wbase + i * 32 + r) * G_LDK + c * 8 + 4 * h]);
             f[i][0] = x.x; f[i][1] = x.y; f[i][2] = x.z; f[i][3] = x.w;
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < T; ++i)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) f[i][t] = Xs[(c * 8 + 4 * h + t) * G_LDM + wbase + i * 32 + r];
+            for (int t = 0; t < 4; ++t) f[i][t] = Xs[(c * 8 + 4 * h + t) * LDM + wbase + i * 32 + r];
     }
 }
 
-template <int AL, int BL, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[G_TILE_FLOATS];
-    __shared__ __attribute__((aligned(16))) float Bs[G_TILE_FLOATS];
-    constexpr int ASL = (AL == L_ONEHOT) ? L_MCONTIG : AL;
+template <int AL, int BL, int TM, int TN, bool FAST>
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* __restrict__ As, float* __restrict__ Bs, int m0, int n0,
+                                              int kbeg, int kend, f32x16 (&acc)[TM][TN]) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int ASL = AL;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    float4 va[BM / 32], vb[BN / 32];
+    if (kbeg < kend) {
+        stage_load<AL, BM, FAST>(g, g.A, g.lda, g.a_vec, m0, g.M, kbeg, kend, va);
+        stage_load<BL, BN, FAST>(g, g.B, g.ldb, g.b_vec, n0, g.N, kbeg, kend, vb);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+        if (!(g.dbg & 2) || k0 == kbeg) {
+        __syncthreads();                         // previous tile fully consumed
+        stage_store<ASL, BM>(As, va);
+        stage_store<BL, BN>(Bs, vb);
+        __syncthreads();
+        }
+        if (k0 + GBK < kend && !(g.dbg & 1)) {   // next tile's loads fly under this tile's MFMAs
+            stage_load<AL, BM, FAST>(g, g.A, g.lda, g.a_vec, m0, g.M, k0 + GBK, kend, va);
+            stage_load<BL, BN, FAST>(g, g.B, g.ldb, g.b_vec, n0, g.N, k0 + GBK, kend, vb);
+        }
+        // fragments of chunk c+1 are read from LDS while the MFMAs of chunk c issue (two named register sets, static
+        // indexing), so no MFMA waits on an LDS round trip except the first of the tile
+        float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
+        frag_read<ASL, BM, TM>(As, wm * 32 * TM, 0, r, h, fa0);
+        frag_read<BL, BN, TN>(Bs, wn * 32 * TN, 0, r, h, fb0);
+#pragma unroll
+        for (int c = 0; c < GBK / 8; c += 2) {
+            frag_read<ASL, BM, TM>(As, wm * 32 * TM, c + 1, r, h, fa1);
+            frag_read<BL, BN, TN>(Bs, wn * 32 * TN, c + 1, r, h, fb1);
+            __builtin_amdgcn_sched_barrier(0);                        // keep the DS reads ahead of the whole MFMA block
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][t], fb0[j][t], acc[i][j], 0, 0, 0);
+            if (c + 2 < GBK / 8) {
+                frag_read<ASL, BM, TM>(As, wm * 32 * TM, c + 2, r, h, fa0);
+                frag_read<BL, BN, TN>(Bs, wn * 32 * TN, c + 2, r, h, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i][t], fb1[j][t], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+template <int AL, int BL, int EPI, int TM, int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_f32_kernel(const GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    __shared__ __attribute__((aligned(16))) float As[g_tile_floats(BM)];
+    __shared__ __attribute__((aligned(16))) float Bs[g_tile_floats(BN)];
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
-    const int m0 = (int)blockIdx.x * GBM, n0 = (int)blockIdx.y * GBN;
+    const int m0 = (int)blockIdx.x * BM, n0 = (int)blockIdx.y * BN;
     const int kbeg = (int)blockIdx.z * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    float4 va[4], vb[4];
-    if (kbeg < kend) {
-        stage_load<AL>(g, g.A, g.lda, g.a_vec, m0, g.M, kbeg, kend, va);
-        stage_load<BL>(g, g.B, g.ldb, g.b_vec, n0, g.N, kbeg, kend, vb);
-    }
-    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-        __syncthreads();                         // previous tile fully consumed
-        stage_store<ASL>(As, va);
-        stage_store<BL>(Bs, vb);
-        __syncthreads();
-        if (k0 + GBK < kend) {                   // next tile's loads fly under this tile's MFMAs
-            stage_load<AL>(g, g.A, g.lda, g.a_vec, m0, g.M, k0 + GBK, kend, va);
-            stage_load<BL>(g, g.B, g.ldb, g.b_vec, n0, g.N, k0 + GBK, kend, vb);
-        }
-#pragma unroll
-        for (int c = 0; c < GBK / 8; ++c) {
-            float fa[2][4], fb[2][4];
-            frag_read<ASL>(As, wm * 64, c, r, h, fa);
-            frag_read<BL>(Bs, wn * 64, c, r, h, fb);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
-        }
-    }
+    // interior tiles (all rows/columns in range, k range a multiple of 32, 16-byte aligned operands) take the
+    // branch-free loaders; the decision is block-uniform
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (((kend - kbeg) & (GBK - 1)) == 0) &&
+                          g.a_vec && g.b_vec;
+    if (interior) gemm_mainloop<AL, BL, TM, TN, true>(g, As, Bs, m0, n0, kbeg, kend, acc);
+    else gemm_mainloop<AL, BL, TM, TN, false>(g, As, Bs, m0, n0, kbeg, kend, acc);
 
     // ---- epilogue.  32x32 accumulator map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ---------------
-    if (EPI == EPI_ROWMAX) {
+    if (EPI == EPI_COLMAX) {
         const float NEG = -__builtin_inff();
+        float cm[TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < TN; ++j) cm[j] = NEG;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                float v = NEG;
+                const int m = m0 + wm * 32 * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (m < g.M) {
+                    const float bm = g.bias[m];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int n = n0 + wn * 64 + j * 32 + r;
-                    if (n < g.N) v = fmaxf(v, acc[i][j][q] + g.bias[n]);
+                    for (int j = 0; j < TN; ++j) cm[j] = fmaxf(cm[j], acc[i][j][q] + bm);
                 }
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));   // stays inside a 32-lane half
-                const int m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (r == 0 && m < g.M) g.partial[((long long)blockIdx.y * 2 + wn) * g.M + m] = v;
             }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float v = fmaxf(cm[j], __shfl_xor(cm[j], 32, 64));      // the other 4-row groups live in the other half-wave
+            const int n = n0 + wn * 32 * TN + j * 32 + r;
+            if (h == 0 && n < g.N) g.partial[((long long)blockIdx.x * 2 + wm) * g.N + n] = v;
         }
         return;
     }
     float* Cz = g.C + (long long)blockIdx.z * g.slab_stride;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + r;
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 32 * TN + j * 32 + r;
             if (n >= g.N) continue;
             float bias = 0.f;
             if (EPI == EPI_BIAS_TANH) bias = g.bias[n];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const int m = m0 + wm * 32 * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                 if (m >= g.M) continue;
                 float v = acc[i][j][q];
                 if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
