@@ -406,9 +406,11 @@ static int ensure_capacity(xq_dqn* d, int n) {
         XQ_HIP(hipMalloc(&d->acts[l], cap * d->L[l + 1] * sizeof(float)));
         XQ_HIP(hipMalloc(&d->deltas[l], cap * d->L[l + 1] * sizeof(float)));
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) {    // rows padded to a multiple of 128 (whole-tile reads of the persistent GEMM)
         if (d->tacts[i]) XQ_HIP(hipFree(d->tacts[i]));
-        XQ_HIP(hipMalloc(&d->tacts[i], cap * (size_t)maxh * sizeof(float)));
+        const size_t rows = (size_t)round_up(n, 128);
+        XQ_HIP(hipMalloc(&d->tacts[i], rows * (size_t)maxh * sizeof(float)));
+        XQ_HIP(hipMemsetAsync(d->tacts[i], 0, rows * (size_t)maxh * sizeof(float), d->stream));
     }
     const int ntn = (d->nout() + 63) / 64;             // column-max partials: 2 per 64- or 128-row tile
     float** bufs[] = {&d->d2, &d->q90, &d->partial, &d->qsa, &d->yv, &d->lossv};
@@ -619,7 +621,15 @@ int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, dou
     d->lr = learning_rate; d->gamma = gamma; d->seed = seed;
     if (hip_stream) d->stream = (hipStream_t)hip_stream;
     else { XQ_HIP(hipStreamCreate(&d->stream)); d->own_stream = true; }
-    for (int i = 0; i < 2; ++i) XQ_HIP(hipMalloc(&d->params[i], (d->nw + d->nb) * sizeof(float)));
+    // + 128 rows of the widest layer: the persistent column-max GEMM reads whole 128-row tiles of W_out (rows beyond the
+    // last output are masked in its epilogue, but must be readable)
+    int widest = 0;
+    for (int i = 0; i < n_sizes; ++i) widest = std::max(widest, layer_sizes[i]);
+    const size_t pad = (size_t)128 * widest;
+    for (int i = 0; i < 2; ++i) {
+        XQ_HIP(hipMalloc(&d->params[i], (d->nw + d->nb + pad) * sizeof(float)));
+        XQ_HIP(hipMemsetAsync(d->params[i], 0, (d->nw + d->nb + pad) * sizeof(float), d->stream));
+    }
     layout_td_grads(d);
     XQ_HIP(hipMalloc(&d->grads_td, d->n_grads_td * sizeof(float)));
     XQ_HIP(hipMemsetAsync(d->grads_td, 0, d->n_grads_td * sizeof(float), d->stream));
@@ -821,7 +831,20 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
         g.B = touts[nl - 2]; g.ldb = Hl;
         g.bias = d->bl(td_net, nl - 1);
         g.partial = d->partial;
-        XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_COLMAX>(d, g, 1, "gemm_qmax_rowmax")));
+        if (big_tiles && (Hl % GBK) == 0 && vec_ok(g.A, g.lda) && vec_ok(g.B, g.ldb)) {
+            // persistent form: 2 blocks per CU walk the tile list with the prefetch running across tile boundaries
+            const int tiles_m = (NO + 127) / 128, total = tiles_m * ((n + 127) / 128);
+            int ncu = 256;
+            hipDeviceProp_t prop; int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+            g.a_vec = g.b_vec = 1; g.k_chunk = Hl;
+            ProfScope ps(d, "gemm_qmax_rowmax", 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + 2.0 * tiles_m * g.N));
+            hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(std::min(total, 2 * ncu)), dim3(256), 0, d->stream, g,
+                               tiles_m, total);
+            XQ_HIP(hipGetLastError());
+        } else {
+            XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_COLMAX>(d, g, 1, "gemm_qmax_rowmax")));
+        }
     }
     // 2. s chain on the online net (activations kept)
     float* outs[XQ_MAX_LAYERS];

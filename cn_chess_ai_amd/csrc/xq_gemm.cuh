@@ -46,13 +46,12 @@ struct GemmArgs {
     int k_chunk;                  // split-K: k range of blockIdx.z is [z*k_chunk, min(K,(z+1)*k_chunk))
     long long slab_stride;        // split-K: C of split z = C + z*slab_stride
     int a_vec, b_vec;             // 16-byte vector loads allowed (base and ld aligned)
-    int dbg;                      // tools/gemm_bench.hip only: 1 = no global loads in the k loop, 2 = no LDS restage/barriers
 };
 
 // ---- global -> register staging (4 x float4 per thread per operand) --------------------------------------------
 // FAST = the whole tile is interior and 16-byte aligned (decided once per block): unconditional global_load_dwordx4,
 // no per-element bounds logic — the checked path compiles to scalar loads with waits and must stay off the hot tiles.
-template <int LAYOUT, int ROWS, bool FAST>
+template <int LAYOUT, int ROWS, bool FAST, int J0 = 0, int J1 = ROWS / 32>
 __device__ __forceinline__ void stage_load(const GemmArgs& g, const float* __restrict__ X, long long ld, int vec_ok,
                                            int rows0, int R, int k0, int kend, float4 (&v)[ROWS / 32]) {
     constexpr int NV = ROWS / 32;          // float4 per thread
@@ -62,7 +61,7 @@ __device__ __forceinline__ void stage_load(const GemmArgs& g, const float* __res
     if (FAST && LAYOUT == L_KCONTIG) {
         const float* p = X + (long long)(rows0 + (tid >> 3)) * ld + k0 + (tid & 7) * 4;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {     // element-wise copy: a whole-float4 assignment keeps v[] as a stack object
+        for (int j = J0; j < J1; ++j) {    // element-wise copy: a whole-float4 assignment keeps v[] as a stack object
             const float4 x = *reinterpret_cast<const float4*>(p + (long long)(32 * j) * ld);
             v[j].x = x.x; v[j].y = x.y; v[j].z = x.z; v[j].w = x.w;
         }
@@ -71,7 +70,7 @@ __device__ __forceinline__ void stage_load(const GemmArgs& g, const float* __res
     if (FAST && LAYOUT == L_MCONTIG) {
         const float* p = X + (long long)(k0 + (tid / TPR)) * ld + rows0 + (tid % TPR) * 4;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
+        for (int j = J0; j < J1; ++j) {
             const float4 x = *reinterpret_cast<const float4*>(p + (long long)(KPP * j) * ld);
             v[j].x = x.x; v[j].y = x.y; v[j].z = x.z; v[j].w = x.w;
         }
@@ -159,11 +158,45 @@ __device__ __forceinline__ void frag_read(const float* __restrict__ Xs, int wbas
     }
 }
 
+// MFMAs of one staged k-tile (32 deep = 4 chunks of 8).  Fragments of chunk c+1 are read from LDS while the MFMAs of
+// chunk c issue (two named register sets, static indexing).
+template <int ASL, int BL, int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void tile_mma(const float* __restrict__ As, const float* __restrict__ Bs, int wm, int wn, int r, int h,
+                                         f32x16 (&acc)[TM][TN]) {
+    float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
+    frag_read<ASL, BM, TM>(As, wm * 32 * TM, 0, r, h, fa0);
+    frag_read<BL, BN, TN>(Bs, wn * 32 * TN, 0, r, h, fb0);
+#pragma unroll
+    for (int c = 0; c < GBK / 8; c += 2) {
+        frag_read<ASL, BM, TM>(As, wm * 32 * TM, c + 1, r, h, fa1);
+        frag_read<BL, BN, TN>(Bs, wn * 32 * TN, c + 1, r, h, fb1);
+        __builtin_amdgcn_sched_barrier(0);                        // keep the DS reads ahead of the whole MFMA block
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][t], fb0[j][t], acc[i][j], 0, 0, 0);
+        if (c + 2 < GBK / 8) {
+            frag_read<ASL, BM, TM>(As, wm * 32 * TM, c + 2, r, h, fa0);
+            frag_read<BL, BN, TN>(Bs, wn * 32 * TN, c + 2, r, h, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i][t], fb1[j][t], acc[i][j], 0, 0, 0);
+    }
+}
+
 template <int AL, int BL, int TM, int TN, bool FAST>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* __restrict__ As, float* __restrict__ Bs, int m0, int n0,
                                               int kbeg, int kend, f32x16 (&acc)[TM][TN]) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int ASL = AL;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -174,46 +207,45 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* __restri
         stage_load<BL, BN, FAST>(g, g.B, g.ldb, g.b_vec, n0, g.N, kbeg, kend, vb);
     }
     for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-        if (!(g.dbg & 2) || k0 == kbeg) {
         __syncthreads();                         // previous tile fully consumed
-        stage_store<ASL, BM>(As, va);
+        stage_store<AL, BM>(As, va);
         stage_store<BL, BN>(Bs, vb);
         __syncthreads();
-        }
-        if (k0 + GBK < kend && !(g.dbg & 1)) {   // next tile's loads fly under this tile's MFMAs
+        if (k0 + GBK < kend) {                   // next tile's loads fly under this tile's MFMAs
             stage_load<AL, BM, FAST>(g, g.A, g.lda, g.a_vec, m0, g.M, k0 + GBK, kend, va);
             stage_load<BL, BN, FAST>(g, g.B, g.ldb, g.b_vec, n0, g.N, k0 + GBK, kend, vb);
         }
-        // fragments of chunk c+1 are read from LDS while the MFMAs of chunk c issue (two named register sets, static
-        // indexing), so no MFMA waits on an LDS round trip except the first of the tile
-        float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
-        frag_read<ASL, BM, TM>(As, wm * 32 * TM, 0, r, h, fa0);
-        frag_read<BL, BN, TN>(Bs, wn * 32 * TN, 0, r, h, fb0);
+        tile_mma<AL, BL, BM, BN, TM, TN>(As, Bs, wm, wn, r, h, acc);
+    }
+}
+
+// column-max epilogue: partial[(tile_m*2 + wm)][n] = max over the wave's rows of (acc + bias[m]); runs over the
+// accumulator registers of one lane, then one exchange between the two half-waves
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_colmax(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int tile_m) {
+    const int lane = (int)threadIdx.x & 63, wid = (int)threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    const float NEG = -__builtin_inff();
+    float cm[TN];
 #pragma unroll
-        for (int c = 0; c < GBK / 8; c += 2) {
-            frag_read<ASL, BM, TM>(As, wm * 32 * TM, c + 1, r, h, fa1);
-            frag_read<BL, BN, TN>(Bs, wn * 32 * TN, c + 1, r, h, fb1);
-            __builtin_amdgcn_sched_barrier(0);                        // keep the DS reads ahead of the whole MFMA block
+    for (int j = 0; j < TN; ++j) cm[j] = NEG;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + wm * 32 * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (m < g.M) {
+                const float bm = g.bias[m];
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][t], fb0[j][t], acc[i][j], 0, 0, 0);
-            if (c + 2 < GBK / 8) {
-                frag_read<ASL, BM, TM>(As, wm * 32 * TM, c + 2, r, h, fa0);
-                frag_read<BL, BN, TN>(Bs, wn * 32 * TN, c + 2, r, h, fb0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < TN; ++j) cm[j] = fmaxf(cm[j], acc[i][j][q] + bm);
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i][t], fb1[j][t], acc[i][j], 0, 0, 0);
         }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const float v = fmaxf(cm[j], __shfl_xor(cm[j], 32, 64));      // the other 4-row groups live in the other half-wave
+        const int n = n0 + wn * 32 * TN + j * 32 + r;
+        if (h == 0 && n < g.N) g.partial[((long long)tile_m * 2 + wm) * g.N + n] = v;
     }
 }
 
@@ -241,34 +273,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
     // interior tiles (all rows/columns in range, k range a multiple of 32, 16-byte aligned operands) take the
     // branch-free loaders; the decision is block-uniform
-    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (((kend - kbeg) & (GBK - 1)) == 0) &&
-                          g.a_vec && g.b_vec;
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (((kend - kbeg) & (GBK - 1)) == 0) && g.a_vec && g.b_vec;
     if (interior) gemm_mainloop<AL, BL, TM, TN, true>(g, As, Bs, m0, n0, kbeg, kend, acc);
     else gemm_mainloop<AL, BL, TM, TN, false>(g, As, Bs, m0, n0, kbeg, kend, acc);
 
     // ---- epilogue.  32x32 accumulator map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ---------------
     if (EPI == EPI_COLMAX) {
-        const float NEG = -__builtin_inff();
-        float cm[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) cm[j] = NEG;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int m = m0 + wm * 32 * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (m < g.M) {
-                    const float bm = g.bias[m];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) cm[j] = fmaxf(cm[j], acc[i][j][q] + bm);
-                }
-            }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float v = fmaxf(cm[j], __shfl_xor(cm[j], 32, 64));      // the other 4-row groups live in the other half-wave
-            const int n = n0 + wn * 32 * TN + j * 32 + r;
-            if (h == 0 && n < g.N) g.partial[((long long)blockIdx.x * 2 + wm) * g.N + n] = v;
-        }
+        epilogue_colmax<TM, TN>(g, acc, m0, n0, (int)blockIdx.x);
         return;
     }
     float* Cz = g.C + (long long)blockIdx.z * g.slab_stride;
@@ -293,6 +304,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 Cz[(long long)m * g.ldc + n] = v;
             }
         }
+}
+
+// Persistent column-max GEMM for the dominant product (rows = output neurons, columns = samples, both operands
+// k-contiguous).  The plain kernel runs its 4096 tiles in lock-step rounds (every resident block loads its first tile,
+// computes and drains at the same time), so prologue and epilogue are exposed once per round.  Here 2 blocks per CU walk
+// the tile list (t, t+grid, ...: same row tile = same weight panel, resident in L2) and the register prefetch runs
+// ACROSS tile boundaries: the first k-tile of the next output tile is in flight under the last MFMAs and the epilogue of
+// the current one.  Requires K % 32 == 0, 16-byte aligned operands, and both operands readable up to the next multiple of
+// 128 rows (the callers pad their allocations); rows/columns beyond M/N are masked in the epilogue.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_colmax_persistent_kernel(const GemmArgs g,
+                                                                                                        int tiles_m, int total) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    __shared__ __attribute__((aligned(16))) float As[g_tile_floats(BM)];
+    __shared__ __attribute__((aligned(16))) float Bs[g_tile_floats(BN)];
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    int t = (int)blockIdx.x;
+    if (t >= total) return;
+    int tm = t % tiles_m, tn = t / tiles_m;
+    float4 va[BM / 32], vb[BN / 32];
+    stage_load<L_KCONTIG, BM, true>(g, g.A, g.lda, 1, tm * BM, g.M, 0, g.K, va);
+    stage_load<L_KCONTIG, BN, true>(g, g.B, g.ldb, 1, tn * BN, g.N, 0, g.K, vb);
+    for (;;) {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        const int tnext = t + (int)gridDim.x;
+        for (int k0 = 0; k0 < g.K; k0 += GBK) {
+            __syncthreads();
+            stage_store<L_KCONTIG, BM>(As, va);
+            stage_store<L_KCONTIG, BN>(Bs, vb);
+            __syncthreads();
+            if (k0 + GBK < g.K) {
+                stage_load<L_KCONTIG, BM, true>(g, g.A, g.lda, 1, tm * BM, g.M, k0 + GBK, g.K, va);
+                stage_load<L_KCONTIG, BN, true>(g, g.B, g.ldb, 1, tn * BN, g.N, k0 + GBK, g.K, vb);
+            } else if (tnext < total) {          // first k-tile of the NEXT output tile
+                stage_load<L_KCONTIG, BM, true>(g, g.A, g.lda, 1, (tnext % tiles_m) * BM, g.M, 0, g.K, va);
+                stage_load<L_KCONTIG, BN, true>(g, g.B, g.ldb, 1, (tnext / tiles_m) * BN, g.N, 0, g.K, vb);
+            }
+            tile_mma<L_KCONTIG, L_KCONTIG, BM, BN, TM, TN>(As, Bs, wm, wn, r, h, acc);
+        }
+        epilogue_colmax<TM, TN>(g, acc, tm * BM, tn * BN, tm);
+        if (tnext >= total) break;
+        t = tnext; tm = t % tiles_m; tn = t / tiles_m;
+    }
 }
 
 }  // namespace xq

@@ -22,7 +22,7 @@ float run(GemmArgs g, int iters) {
 int main(int argc, char** argv) {
     const int M = 8100, N = argc > 1 ? atoi(argv[1]) : 8192, K = argc > 2 ? atoi(argv[2]) : 256;
     float *A, *B, *C, *bias, *partial;
-    CK(hipMalloc(&A, (size_t)M * K * 4)); CK(hipMalloc(&B, (size_t)N * K * 4)); CK(hipMalloc(&C, (size_t)M * N * 4));
+    CK(hipMalloc(&A, (size_t)(M + 128) * K * 4)); CK(hipMalloc(&B, (size_t)(N + 128) * K * 4)); CK(hipMalloc(&C, (size_t)M * N * 4));
     CK(hipMalloc(&bias, (size_t)M * 4)); CK(hipMalloc(&partial, (size_t)N * 2 * ((M + 63) / 64) * 4));
     std::vector<float> h((size_t)std::max(M, N) * K);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
@@ -33,15 +33,30 @@ int main(int argc, char** argv) {
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = K; g.B = B; g.ldb = K; g.C = C; g.ldc = N; g.bias = bias; g.partial = partial;
     g.k_chunk = K; g.a_vec = 1; g.b_vec = 1;
     const double fl = 2.0 * M * N * K;
-    for (int dbg = 0; dbg < 4; ++dbg) {
-        g.dbg = dbg;
+    {
         float t = run<EPI_COLMAX, 2, 2>(g, 20);
-        printf("colmax 128x128 dbg=%d: %8.1f us  %6.1f TF/s\n", dbg, t * 1e3, fl / t / 1e9);
+        printf("colmax 128x128          : %8.1f us  %6.1f TF/s\n", t * 1e3, fl / t / 1e9);
     }
-    g.dbg = 0;
-    float t = run<EPI_COLMAX, 1, 1>(g, 20);
-    printf("colmax  64x64        : %8.1f us  %6.1f TF/s\n", t * 1e3, fl / t / 1e9);
-    t = run<EPI_BIAS_TANH, 2, 2>(g, 10);
-    printf("tanh-store 128x128   : %8.1f us  %6.1f TF/s\n", t * 1e3, fl / t / 1e9);
+    for (int grid : {256, 512, 768, 1024}) {
+        const int tiles_m = (M + 127) / 128, total = tiles_m * ((N + 127) / 128);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(grid), dim3(256), 0, 0, g, tiles_m, total);
+        hipEventRecord(a, 0);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(grid), dim3(256), 0, 0, g, tiles_m, total);
+        hipEventRecord(b, 0); hipEventSynchronize(b);
+        float ms = 0; hipEventElapsedTime(&ms, a, b); ms /= 20;
+        printf("colmax persistent g=%4d : %8.1f us  %6.1f TF/s\n", grid, ms * 1e3, fl / ms / 1e9);
+    }
+    // check: persistent == plain
+    {
+        std::vector<float> p0((size_t)N * 2 * ((M + 127) / 128)), p1(p0.size());
+        hipLaunchKernelGGL((gemm_f32_kernel<L_KCONTIG, L_KCONTIG, EPI_COLMAX, 2, 2>), dim3((M + 127) / 128, (N + 127) / 128, 1), dim3(256), 0, 0, g);
+        CK(hipMemcpy(p0.data(), partial, p0.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(partial, 0, p0.size() * 4));
+        hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(512), dim3(256), 0, 0, g, (M + 127) / 128, ((M + 127) / 128) * ((N + 127) / 128));
+        CK(hipMemcpy(p1.data(), partial, p1.size() * 4, hipMemcpyDeviceToHost));
+        size_t bad = 0; for (size_t i = 0; i < p0.size(); ++i) bad += p0[i] != p1[i];
+        printf("persistent vs plain: %zu mismatches of %zu\n", bad, p0.size());
+    }
     return 0;
 }
