@@ -68,6 +68,25 @@ def cpu_baseline(seconds=15.0):
     return out
 
 
+def pmc_traffic(kernel_substring):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 --pmc summary (profiles/*_pmc_hbm_traffic.json,
+    made by tools/collect_profiles.sh + tools/summarize_profiles.py on this same bench command: separate FETCH_SIZE /
+    WRITE_SIZE passes, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction).  None if absent: PMC counters
+    cannot be read from inside the timed run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        data = json.load(open(files[-1]))
+    except Exception:
+        return None, None
+    for k, v in data.items():
+        if kernel_substring in k:
+            return v.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +110,12 @@ def main():
     torch.cuda.set_device(local_rank)
     _capi.call("xq_set_device", local_rank)
     xd.init_process_group("nccl" if world > 1 else None)
-    stream = torch.cuda.current_stream().cuda_stream       # library kernels and RCCL share torch's current stream
+    # library kernels and RCCL share ONE torch stream (a real stream object: the legacy default stream has handle 0,
+    # which the C ABI reads as "create your own")
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     first, _ = xd.shard_games(rank, N_GAMES)
     cfg = xq.TrainerConfig(n_games=N_GAMES, layer_sizes=LAYERS, learning_rate=0.001, gamma=0.99, epsilon=0.1,
@@ -147,10 +171,11 @@ def main():
             ms = g["ms"] / g["launches"]
             fl = g["flops"] / g["launches"]
             ach = fl / (ms * 1e-3) / 1e12
-            line["roofline"] = {"kernel": "gemm_f32_kernel<KCONTIG,KCONTIG,ROWMAX> (max_a' Q(s'), 8192x8100x256)",
+            tr, src = pmc_traffic("gemm_colmax_persistent_kernel")
+            line["roofline"] = {"kernel": "gemm_colmax_persistent_kernel<2,2> (max_a' Q(s'): 8100 x 8192 x 256, fp32 MFMA)",
                                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms,
-                                "flops_per_launch": fl, "launches": g["launches"]}
+                                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, offline)",
+                                "traffic_source": src, "avg_launch_ms": ms, "flops_per_launch": fl, "launches": g["launches"]}
         e = stats.get("env_selfplay_step")
         if e and e["launches"]:
             ms = e["ms"] / e["launches"]
@@ -158,7 +183,7 @@ def main():
             ach = by / (ms * 1e-3) / 1e9
             line["roofline_env"] = {"kernel": "env_kernel<SELFPLAY> (movegen+select+move+reward+reset, 8192 boards)",
                                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                    "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": ms,
+                                    "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("env_kernel<2>")[0], "avg_launch_ms": ms,
                                     "bytes_per_launch": by, "launches": e["launches"]}
         if args.profile_all:
             line["kernels"] = {k: {"ms_per_launch": v["ms"] / max(v["launches"], 1), "launches": v["launches"]}

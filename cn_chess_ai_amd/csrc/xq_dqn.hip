@@ -30,6 +30,11 @@ struct xq_dqn {
     uint64_t seed = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // side stream for work that is independent of the main chain inside one TD step (the s-chain forward runs beside the
+    // s'-chain + column-max GEMM; the layer-0 gradient beside the other gradient GEMMs); `cur` = stream launches go to
+    hipStream_t side = nullptr;
+    hipStream_t cur = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float* params[2] = {nullptr, nullptr};
     // workspaces sized for `cap` samples
     int cap = 0;
@@ -49,6 +54,7 @@ struct xq_dqn {
     size_t g_w0 = 0, g_wh[XQ_MAX_LAYERS] = {0}, g_wout = 0, g_bh[XQ_MAX_LAYERS] = {0}, g_bout = 0;
     float* grads_full = nullptr;
     float* slabs = nullptr;  size_t slabs_cap = 0;
+    float* slabs_l0 = nullptr;  size_t slabs_l0_cap = 0;     // layer-0 gradient partials (runs on the side stream)
     float* bias_work = nullptr;  size_t bias_work_cap = 0;
     // dense API scratch
     float* xdense = nullptr;  size_t xdense_cap = 0;
@@ -73,7 +79,7 @@ hipStream_t dqn_stream(xq_dqn* d) { return d->stream; }
 
 struct ProfScope {
     Profiler& p; hipStream_t s; int h; double flops, bytes;
-    ProfScope(xq_dqn* d, const char* name, double fl, double by) : p(d->prof), s(d->stream), flops(fl), bytes(by) { h = p.begin(name, s); }
+    ProfScope(xq_dqn* d, const char* name, double fl, double by) : p(d->prof), s(d->cur), flops(fl), bytes(by) { h = p.begin(name, s); }
     ~ProfScope() { p.end(h, s, flops, bytes); }
 };
 
@@ -367,10 +373,10 @@ static int launch_gemm(xq_dqn* d, GemmArgs g, int splits, const char* name, int*
     ProfScope ps(d, name, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
     if (big) {
         dim3 grid((g.M + 127) / 128, (g.N + 127) / 128, splits);
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI, 2, 2>), grid, dim3(256), 0, d->stream, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI, 2, 2>), grid, dim3(256), 0, d->cur, g);
     } else {
         dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, splits);
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI, 1, 1>), grid, dim3(256), 0, d->stream, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI, 1, 1>), grid, dim3(256), 0, d->cur, g);
     }
     XQ_HIP(hipGetLastError());
     if (used_splits) *used_splits = splits;
@@ -432,7 +438,7 @@ static int chain_boards(xq_dqn* d, int net, const uint32_t* boards, const int32_
     {
         const int H = d->L[1];
         ProfScope ps(d, "l0_forward_gather", 2.0 * n * 32 * H, (double)n * (48 + 32.0 * H * 4 + H * 4));
-        hipLaunchKernelGGL(l0_forward_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, boards, slots, n, d->w0t(net),
+        hipLaunchKernelGGL(l0_forward_kernel, dim3((n + 3) / 4), dim3(256), 0, d->cur, boards, slots, n, d->w0t(net),
                            d->bl(net, 0), H, outs[0], gathered);
         XQ_HIP(hipGetLastError());
     }
@@ -531,7 +537,7 @@ static int grad_gemm(xq_dqn* d, GemmArgs g, float* dst, const char* name) {
     if (splits > 1) {
         ProfScope ps(d, "reduce_slabs", (double)used * len, 4.0 * (used + 1) * len);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)std::min<long long>((len + 255) / 256, 2048)), dim3(256), 0,
-                           d->stream, d->slabs, used, len, len, dst);
+                           d->cur, d->slabs, used, len, len, dst);
         XQ_HIP(hipGetLastError());
     }
     return XQ_OK;
@@ -563,10 +569,45 @@ static int bias_grads(xq_dqn* d, BiasJobs& bj, int n) {
     double tot = 0;
     for (int k = 0; k < J.njobs; ++k) tot += (double)n * J.C[k];
     ProfScope ps(d, "bias_grad_colsum", tot, 4.0 * tot);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((maxc + 63) / 64, J.R, J.njobs), dim3(256), 0, d->stream, J);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((maxc + 63) / 64, J.R, J.njobs), dim3(256), 0, d->cur, J);
     XQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((maxc + 255) / 256, J.njobs), dim3(256), 0, d->stream, J);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((maxc + 255) / 256, J.njobs), dim3(256), 0, d->cur, J);
     XQ_HIP(hipGetLastError());
+    return XQ_OK;
+}
+
+// layer 0: per-(square, piece) segmented sums of delta_0 rows (no dense one-hot product); launches on d->cur
+static int l0_gradient(xq_dqn* d, int n, float* dst) {
+    const int H = d->L[1];
+    const int chunk = 1024;                          // samples per block; list entries hold 11 bits of sample index
+    const int nchunks = (n + chunk - 1) / chunk;
+    const long long len = (long long)kStateSize * H;
+    float* out = dst;
+    if (nchunks > 1) {
+        const size_t need = (size_t)nchunks * (size_t)len;
+        if (need > d->slabs_l0_cap) {
+            if (d->slabs_l0) { XQ_HIP(hipDeviceSynchronize()); XQ_HIP(hipFree(d->slabs_l0)); }
+            XQ_HIP(hipMalloc(&d->slabs_l0, need * sizeof(float)));
+            d->slabs_l0_cap = need;
+        }
+        out = d->slabs_l0;
+    }
+    {
+        ProfScope ps(d, "l0_grad_segsum", 2.0 * n * 32 * H, (double)n * (32.0 * H * 4 + 48) + 4.0 * nchunks * len);
+        int nsets = 4;                               // one accumulator set per wave while they fit in 60 KB of LDS
+        while (nsets > 1 && (size_t)nsets * 14 * H * sizeof(float) > 60 * 1024) nsets >>= 1;
+        const size_t shmem = (size_t)nsets * 14 * H * sizeof(float) + (size_t)chunk * sizeof(uint16_t);
+        if (shmem > 64 * 1024) return fail(XQ_ERR_INVALID_ARGUMENT, "first hidden layer too wide for the layer-0 gradient kernel (%d)", H);
+        hipLaunchKernelGGL(l0_grad_kernel, dim3(kSquares, nchunks), dim3(256), shmem, d->cur, d->gboards, d->deltas[0], n, H,
+                           chunk, nsets, out);
+        XQ_HIP(hipGetLastError());
+    }
+    if (nchunks > 1) {
+        ProfScope ps(d, "reduce_slabs", (double)nchunks * len, 4.0 * (nchunks + 1) * len);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)std::min<long long>((len + 255) / 256, 2048)), dim3(256), 0, d->cur,
+                           d->slabs_l0, nchunks, len, len, dst);
+        XQ_HIP(hipGetLastError());
+    }
     return XQ_OK;
 }
 
@@ -575,7 +616,7 @@ static int sgd_apply(xq_dqn* d, const SegTable& t, double alpha) {
     for (int i = 0; i < t.nseg; ++i) mx = std::max(mx, t.len[i]);
     const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>((mx + 255) / 256, 1024));
     ProfScope ps(d, "sgd_apply", 0, 0);
-    hipLaunchKernelGGL(sgd_segments_kernel, dim3(bx, t.nseg), dim3(256), 0, d->stream, t, (float)alpha);
+    hipLaunchKernelGGL(sgd_segments_kernel, dim3(bx, t.nseg), dim3(256), 0, d->cur, t, (float)alpha);
     XQ_HIP(hipGetLastError());
     return XQ_OK;
 }
@@ -621,6 +662,10 @@ int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, dou
     d->lr = learning_rate; d->gamma = gamma; d->seed = seed;
     if (hip_stream) d->stream = (hipStream_t)hip_stream;
     else { XQ_HIP(hipStreamCreate(&d->stream)); d->own_stream = true; }
+    d->cur = d->stream;
+    XQ_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+    XQ_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+    XQ_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
     // + 128 rows of the widest layer: the persistent column-max GEMM reads whole 128-row tiles of W_out (rows beyond the
     // last output are masked in its epilogue, but must be readable)
     int widest = 0;
@@ -652,6 +697,10 @@ int xq_dqn_destroy(xq_dqn* d) {
     hipFree(d->grads_td); hipFree(d->grads_full); hipFree(d->slabs); hipFree(d->bias_work); hipFree(d->xdense); hipFree(d->qfull); hipFree(d->tfull);
     hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
     d->prof.collect();
+    hipFree(d->slabs_l0);
+    if (d->side) { hipStreamSynchronize(d->side); hipStreamDestroy(d->side); }
+    if (d->ev_fork) hipEventDestroy(d->ev_fork);
+    if (d->ev_join) hipEventDestroy(d->ev_join);
     if (d->own_stream) hipStreamDestroy(d->stream);
     delete d;
     return XQ_OK;
@@ -772,7 +821,7 @@ int xq_dqn_backpropagate(xq_dqn* d, const double* states, const double* targets,
     XQ_TRY(q_head(d, XQ_NET_ONLINE, outs[d->nl - 2], n, NO, d->qfull, NO, "gemm_q_full"));
     const long long total = (long long)n * NO;
     hipLaunchKernelGGL(out_delta_dense_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
-                       d->stream, d->qfull, d->tfull, total, d->tfull);      // delta overwrites the target buffer
+                       d->cur, d->qfull, d->tfull, total, d->tfull);      // delta overwrites the target buffer
     XQ_HIP(hipGetLastError());
     const float* dout = d->tfull;
     XQ_TRY(hidden_deltas(d, n, dout, NO, NO, mode));
@@ -816,6 +865,19 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
     if (mode == XQ_BACKPROP_REFERENCE) XQ_TRY(check_reference_topology(d));
     XQ_TRY(ensure_capacity(d, n));
     const int nl = d->nl, Hl = d->hlast(), NO = d->nout();
+    // fork: the s chain (online net, activations kept) is independent of the s' chain + column-max GEMM — it runs on
+    // the side stream and fills the issue slots the MFMA-bound GEMM leaves idle
+    float* outs[XQ_MAX_LAYERS];
+    for (int l = 0; l + 1 < nl; ++l) outs[l] = d->acts[l];
+    XQ_HIP(hipEventRecord(d->ev_fork, d->stream));
+    XQ_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+    d->cur = d->side;
+    {
+        const int rc = chain_boards(d, XQ_NET_ONLINE, boards, slots, n, outs, d->gboards);
+        d->cur = d->stream;
+        if (rc != XQ_OK) return rc;
+    }
+    XQ_HIP(hipEventRecord(d->ev_join, d->side));
     // 1. s' chain on the TD net, row max of the full output layer (never written to HBM)
     float* touts[XQ_MAX_LAYERS];
     for (int l = 0; l + 1 < nl; ++l) touts[l] = d->tacts[l & 1];
@@ -839,21 +901,19 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
             g.a_vec = g.b_vec = 1; g.k_chunk = Hl;
             ProfScope ps(d, "gemm_qmax_rowmax", 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + 2.0 * tiles_m * g.N));
-            hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(std::min(total, 2 * ncu)), dim3(256), 0, d->stream, g,
+            hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(std::min(total, 2 * ncu)), dim3(256), 0, d->cur, g,
                                tiles_m, total);
             XQ_HIP(hipGetLastError());
         } else {
             XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_COLMAX>(d, g, 1, "gemm_qmax_rowmax")));
         }
     }
-    // 2. s chain on the online net (activations kept)
-    float* outs[XQ_MAX_LAYERS];
-    for (int l = 0; l + 1 < nl; ++l) outs[l] = d->acts[l];
-    XQ_TRY(chain_boards(d, XQ_NET_ONLINE, boards, slots, n, outs, d->gboards));
+    // 2. join the s chain
+    XQ_HIP(hipStreamWaitEvent(d->stream, d->ev_join, 0));
     // 3. Q(s, a), target, output delta
     {
         ProfScope ps(d, "td_target_delta", 2.0 * n * Hl, (double)n * (Hl * 8 + n_partial * 4 + 96 * 4));
-        hipLaunchKernelGGL(td_delta_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, n, slots, action_to, reward, done,
+        hipLaunchKernelGGL(td_delta_kernel, dim3((n + 3) / 4), dim3(256), 0, d->cur, n, slots, action_to, reward, done,
                            outs[nl - 2], Hl, d->wl(XQ_NET_ONLINE, nl - 1), d->bl(XQ_NET_ONLINE, nl - 1), d->partial, n_partial,
                            (float)d->gamma, d->d2, d->qsa, d->yv, d->lossv);
         XQ_HIP(hipGetLastError());
@@ -861,9 +921,18 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
     d->last_n = n;
     // 4. hidden deltas
     XQ_TRY(hidden_deltas(d, n, d->d2, 96, 96, mode));
-    // 5. gradients (compact layout)
+    // 5. gradients (compact layout).  The layer-0 segmented sum (side stream) overlaps the gradient GEMMs.
     float* G = d->grads_td;
     BiasJobs bj;
+    XQ_HIP(hipEventRecord(d->ev_fork, d->stream));
+    XQ_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+    d->cur = d->side;
+    {
+        const int rc = l0_gradient(d, n, G + d->g_w0);
+        d->cur = d->stream;
+        if (rc != XQ_OK) return rc;
+    }
+    XQ_HIP(hipEventRecord(d->ev_join, d->side));
     {   // output layer rows 0..95
         GemmArgs g; memset(&g, 0, sizeof g);
         g.M = 96; g.N = Hl; g.K = n;
@@ -880,33 +949,9 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
         XQ_TRY((grad_gemm<L_MCONTIG>(d, g, G + d->g_wh[l], "gemm_grad_hidden")));
         bj.add(d->deltas[l], d->L[l + 1], d->L[l + 1], G + d->g_bh[l]);
     }
-    {   // layer 0: per-(square, piece) segmented sums of delta_0 rows (no dense one-hot product)
-        const int H = d->L[1];
-        const int chunk = 1024;                          // samples per block; list entries hold 11 bits of sample index
-        const int nchunks = (n + chunk - 1) / chunk;
-        const long long len = (long long)kStateSize * H;
-        float* dst = G + d->g_w0;
-        float* out = dst;
-        if (nchunks > 1) { XQ_TRY(ensure_slabs(d, (size_t)nchunks * (size_t)len)); out = d->slabs; }
-        {
-            ProfScope ps(d, "l0_grad_segsum", 2.0 * n * 32 * H, (double)n * (32.0 * H * 4 + 48) + 4.0 * nchunks * len);
-            int nsets = 4;                               // one accumulator set per wave while they fit in 60 KB of LDS
-            while (nsets > 1 && (size_t)nsets * 14 * H * sizeof(float) > 60 * 1024) nsets >>= 1;
-            const size_t shmem = (size_t)nsets * 14 * H * sizeof(float) + (size_t)chunk * sizeof(uint16_t);
-            if (shmem > 64 * 1024) return fail(XQ_ERR_INVALID_ARGUMENT, "first hidden layer too wide for the layer-0 gradient kernel (%d)", H);
-            hipLaunchKernelGGL(l0_grad_kernel, dim3(kSquares, nchunks), dim3(256), shmem, d->stream, d->gboards, d->deltas[0], n,
-                               H, chunk, nsets, out);
-            XQ_HIP(hipGetLastError());
-        }
-        if (nchunks > 1) {
-            ProfScope ps(d, "reduce_slabs", (double)nchunks * len, 4.0 * (nchunks + 1) * len);
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)std::min<long long>((len + 255) / 256, 2048)), dim3(256), 0,
-                               d->stream, d->slabs, nchunks, len, len, dst);
-            XQ_HIP(hipGetLastError());
-        }
-        bj.add(d->deltas[0], d->L[1], d->L[1], G + d->g_bh[0]);
-    }
+    bj.add(d->deltas[0], d->L[1], d->L[1], G + d->g_bh[0]);
     XQ_TRY(bias_grads(d, bj, n));
+    XQ_HIP(hipStreamWaitEvent(d->stream, d->ev_join, 0));
     return XQ_OK;
 }
 

@@ -1,0 +1,39 @@
+"""GPU-side plumbing of the multi-GPU path that can be checked on one device — `pytest -m gpu`.
+
+The N > 1 collective itself is covered by the gloo test (tests/test_dist_cpu.py) and by the driver's scaling run."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gradient_buffer_is_visible_to_torch_zero_copy():
+    import torch
+    import cn_chess_ai_amd as xq
+    from cn_chess_ai_amd import dist as xd
+    s = torch.cuda.Stream()
+    torch.cuda.set_stream(s)
+    cfg = xq.TrainerConfig(n_games=256, layer_sizes=(1260, 128, 8100), replay_capacity=0, minibatch=256, td_net=0)
+    t = xq.Trainer(cfg, stream=C.c_void_p(s.cuda_stream))
+    ptr, n = t.dqn.grad_buffer()
+    g = xd.wrap_device_floats(ptr, n)
+    assert g.is_cuda and g.numel() == n and g.data_ptr() == ptr and g.dtype == torch.float32
+    t.collect()
+    t.learn_grads()
+    torch.cuda.synchronize()
+    before = g.clone()
+    assert torch.isfinite(before).all() and before.abs().sum().item() > 0
+    # an in-place torch op on the view is what RCCL's all_reduce does: the library must see it
+    w0, b0 = t.dqn.get_params()
+    g.mul_(2.0)                                   # "sum over 2 identical ranks"
+    xd.allreduce_gradients(g, 1)
+    t.learn_apply(world_size=2)                   # mean over batch * 2 ranks -> same update as one rank, unscaled
+    w1, b1 = t.dqn.get_params()
+    t2 = xq.Trainer(cfg, stream=C.c_void_p(s.cuda_stream))
+    t2.collect(); t2.learn_grads(); t2.learn_apply(world_size=1)
+    w2, b2 = t2.dqn.get_params()
+    assert np.array_equal(w1, w2) and np.array_equal(b1, b2) and not np.array_equal(w1, w0)
+    t.close(); t2.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())
