@@ -1,9 +1,10 @@
 // xq_rules.cuh — Xiangqi rules engine for one wavefront = one board (gfx950, wave64).
 //
 // Semantics follow the reference rules engine exactly (Qervas/cn_chess_ai, src/chessboard.cpp — cited per function);
-// the formulation is new: the 90-square board lives as bytes in a per-wave LDS slab, every lane owns the squares
-// `lane` and `lane+64`, each lane generates the ordered move list of its own pieces into two packed registers, and a
-// wave prefix-sum places them in the canonical order of ChessAI::getAllValidActions (chessai.cpp:347-368).
+// the formulation is new: the 90-square board lives as bytes in a per-wave LDS slab plus 90-bit occupancy bitboards in
+// scalar registers (wave ballots); move generation gives every lane one (piece, direction) slot, resolves chariot and
+// cannon rays with bit scans, and a wave prefix-sum places the moves in the canonical order of
+// ChessAI::getAllValidActions (chessai.cpp:347-368).
 #pragma once
 
 #include "xq_common.h"
@@ -15,7 +16,7 @@ struct __attribute__((aligned(16))) WaveSlab {
     float q[96];             // Q-values of outputs 0..89 for this game (selectAction reads q[action.to] only)
     uint16_t moves[kMaxMoves];
     uint8_t sq[96];          // piece code per square (90 used)
-    int32_t misc[8];
+    int32_t misc[8];         // scratch: rank -> square table of move generation (16 bytes) + spare
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
@@ -76,115 +77,6 @@ __device__ inline bool is_valid_move(const uint8_t* sq, int fr, int fc, int tr, 
     }
 }
 
-// up to 17 targets of one piece, 7 bits each, in generation order
-struct PieceMoves {
-    unsigned long long lo = 0, hi = 0;
-    int n = 0;
-    __device__ __forceinline__ void emit(int to) {
-        if (n < 9) lo |= (unsigned long long)to << (7 * n);
-        else hi |= (unsigned long long)to << (7 * (n - 9));
-        ++n;
-    }
-    __device__ __forceinline__ int get(int k) const {
-        return (int)((k < 9 ? lo >> (7 * k) : hi >> (7 * (k - 9))) & 127ull);
-    }
-};
-
-// ChessBoard::getValidMoves(row,col) (chessboard.cpp:112-147) — generator order of :149-283.
-__device__ inline void gen_piece_moves(const uint8_t* sq, int s, PieceMoves& out) {
-    const int p = sq[s];
-    const int row = s / 9, col = s - row * 9;
-    const int color = p > 7 ? C_BLACK : C_RED;
-    switch (code_type(p)) {
-        case T_GENERAL: {                                                   // :149-160  (1,0) (-1,0) (0,1) (0,-1)
-            const int d[4][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int nr = row + d[k][0], nc = col + d[k][1];
-                if (inside(nr, nc) && is_valid_move(sq, row, col, nr, nc)) out.emit(nr * 9 + nc);
-            }
-            break;
-        }
-        case T_ADVISOR: {                                                   // :162-177  own palace only
-            const int d[4][2] = {{1, 1}, {1, -1}, {-1, 1}, {-1, -1}};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int nr = row + d[k][0], nc = col + d[k][1];
-                if (in_own_palace(color, nr, nc) && is_valid_move(sq, row, col, nr, nc)) out.emit(nr * 9 + nc);
-            }
-            break;
-        }
-        case T_ELEPHANT: {                                                  // :179-196  own side, eye empty
-            const int d[4][2] = {{2, 2}, {2, -2}, {-2, 2}, {-2, -2}};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int nr = row + d[k][0], nc = col + d[k][1];
-                const bool own_side = color == C_RED ? (nr >= 0 && nr <= 4) : (nr >= 5 && nr <= 9);
-                if (inside(nr, nc) && own_side && at(sq, row + d[k][0] / 2, col + d[k][1] / 2) == 0 &&
-                    is_valid_move(sq, row, col, nr, nc))
-                    out.emit(nr * 9 + nc);
-            }
-            break;
-        }
-        case T_HORSE: {                                                     // :248-263
-            const int d[8][2] = {{1, 2}, {1, -2}, {-1, 2}, {-1, -2}, {2, 1}, {2, -1}, {-2, 1}, {-2, -1}};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int nr = row + d[k][0], nc = col + d[k][1];
-                if (inside(nr, nc) && at(sq, row + d[k][0] / 2, col + d[k][1] / 2) == 0 &&
-                    is_valid_move(sq, row, col, nr, nc))
-                    out.emit(nr * 9 + nc);
-            }
-            break;
-        }
-        case T_CHARIOT: {                                                   // :198-218  right, left, +row, -row
-            const int d[4][2] = {{0, 1}, {0, -1}, {1, 0}, {-1, 0}};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int nr = row + d[k][0], nc = col + d[k][1];
-                while (inside(nr, nc)) {
-                    const int t = sq[nr * 9 + nc];
-                    if (t != 0 && same_side(p, t)) break;      // isValidMove fails -> break
-                    out.emit(nr * 9 + nc);
-                    if (t != 0) break;                         // stop at the first piece
-                    nr += d[k][0]; nc += d[k][1];
-                }
-            }
-            break;
-        }
-        case T_CANNON: {                                                    // :220-246
-            const int d[4][2] = {{0, 1}, {0, -1}, {1, 0}, {-1, 0}};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int nr = row + d[k][0], nc = col + d[k][1];
-                bool screen = false;
-                while (inside(nr, nc)) {
-                    const int t = sq[nr * 9 + nc];
-                    if (!screen) {
-                        if (t == 0) out.emit(nr * 9 + nc); else screen = true;
-                    } else if (t != 0) {
-                        // first piece behind the screen: capturable iff enemy; anything further has >= 2 screens
-                        if (!same_side(p, t)) out.emit(nr * 9 + nc);
-                        break;
-                    }
-                    nr += d[k][0]; nc += d[k][1];
-                }
-            }
-            break;
-        }
-        case T_SOLDIER: {                                                   // :265-283  forward, col-1, col+1
-            const int nr = row + (color == C_RED ? 1 : -1);
-            if (inside(nr, col) && is_valid_move(sq, row, col, nr, col)) out.emit(nr * 9 + col);
-            if ((color == C_RED && row > 4) || (color == C_BLACK && row < 5)) {
-                if (inside(row, col - 1) && is_valid_move(sq, row, col, row, col - 1)) out.emit(row * 9 + col - 1);
-                if (inside(row, col + 1) && is_valid_move(sq, row, col, row, col + 1)) out.emit(row * 9 + col + 1);
-            }
-            break;
-        }
-        default: break;
-    }
-}
-
 // inclusive wave prefix sum over 64 lanes
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
     const int lane = lane_id();
@@ -240,31 +132,167 @@ __device__ __forceinline__ uint32_t pack_from_slab(const uint8_t* sq) {   // val
     return v;
 }
 
-// ChessAI::getAllValidActions(player) (chessai.cpp:347-368): fills slab.moves in canonical order, returns the count.
-// Every lane of the wave must call this; slab.sq must be visible (synchronised) before the call.  The caller
-// synchronises again before reading slab.moves.
+// 90-bit board masks as two 64-bit words (bits 0..63 / 64..89)
+struct Mask90 { unsigned long long lo, hi; };
+__device__ __forceinline__ unsigned bits_at(const Mask90& m, int pos, unsigned mask) {   // bits [pos, pos+len) of the mask
+    unsigned long long v;
+    if (pos >= 64) v = m.hi >> (pos - 64);
+    else v = (m.lo >> pos) | (pos ? (m.hi << (64 - pos)) : 0ull);
+    return (unsigned)v & mask;
+}
+
+// One ray of a chariot / cannon resolved with bit operations on the line's occupancy (`line`: bit i = square i of the
+// row or column, `pos`: the piece's index on the line, `len`: squares on the line, forward = towards higher indices).
+//   empties : empty squares before the first piece (chariot and cannon both emit them, chessboard.cpp:205-216/228-232)
+//   first   : index of the first piece or -1      (chariot: capturable iff enemy, then stop)
+//   second  : index of the next piece behind it or -1 (cannon: capturable iff enemy, chessboard.cpp:235-240)
+struct RayHit { int empties, first, second; };
+__device__ __forceinline__ RayHit ray_scan(unsigned line, int pos, int len, bool forward) {
+    RayHit h;
+    if (forward) {
+        const unsigned x = line >> (pos + 1);
+        if (x == 0) { h.empties = len - 1 - pos; h.first = -1; h.second = -1; return h; }
+        const int e = __ffs((int)x) - 1;
+        h.empties = e; h.first = pos + 1 + e;
+        const unsigned y = x >> (e + 1);
+        h.second = y ? h.first + 1 + (__ffs((int)y) - 1) : -1;
+    } else {
+        const unsigned x = line & ((1u << pos) - 1u);
+        if (x == 0) { h.empties = pos; h.first = -1; h.second = -1; return h; }
+        const int f = 31 - __clz((int)x);
+        h.empties = pos - 1 - f; h.first = f;
+        const unsigned y = x & ((1u << f) - 1u);
+        h.second = y ? 31 - __clz((int)y) : -1;
+    }
+    return h;
+}
+
+// ChessAI::getAllValidActions(player) (chessai.cpp:347-368): fills slab.moves in canonical order (from ascending, then
+// the generator's direction order, chessboard.cpp:149-283), returns the count.
+//
+// Lane mapping: the side's pieces are ranked by square (ballot + popcount); in pass P lane l owns direction slot l&7 of
+// piece rank 8P + (l>>3).  A slot yields at most one target — except chariot/cannon slots, which yield one ray: a run of
+// consecutive squares plus (cannon) one jump capture.  Rays are resolved with bit scans on the row occupancy and on a
+// column-major copy of it (second ballot), never by walking squares.  A wave prefix sum over the slots (pass 0 then
+// pass 1 = piece order, slot order = generator order) places every move at its canonical index.
+// Every lane of the wave must call this; slab.sq must be visible (wave_sync) before the call, and the caller
+// synchronises again before reading slab.moves.  slab.misc[0..15] is used as scratch.
 __device__ inline int gen_all_actions(WaveSlab& slab, int player) {
     const int lane = lane_id();
     const uint8_t* sq = slab.sq;
     const int p0 = sq[lane];
     const int p1 = lane < 26 ? sq[64 + lane] : 0;
-    PieceMoves ma, mb;
-    if (p0 != 0 && (p0 > 7) == (player == C_BLACK)) gen_piece_moves(sq, lane, ma);
-    if (p1 != 0 && (p1 > 7) == (player == C_BLACK)) gen_piece_moves(sq, 64 + lane, mb);
-    const int inc_a = wave_inclusive_scan(ma.n);
-    const int tot_a = __shfl(inc_a, 63, 64);
-    const int inc_b = wave_inclusive_scan(mb.n);
-    const int tot_b = __shfl(inc_b, 63, 64);
-    int off = inc_a - ma.n;
-    for (int k = 0; k < ma.n; ++k) {
-        if (off + k < kMaxMoves) slab.moves[off + k] = (uint16_t)(lane * 90 + ma.get(k));
+    const bool black = player == C_BLACK;
+    Mask90 occ, own, occT;
+    occ.lo = __ballot(p0 != 0); occ.hi = __ballot(p1 != 0);
+    const bool o0 = p0 != 0 && (p0 > 7) == black, o1 = p1 != 0 && (p1 > 7) == black;
+    own.lo = __ballot(o0); own.hi = __ballot(o1);
+    {   // column-major occupancy: bit c*10 + r
+        const int t0 = lane, t1 = 64 + lane;
+        const int s0 = (t0 % 10) * 9 + t0 / 10;
+        const int s1 = t1 < 90 ? (t1 % 10) * 9 + t1 / 10 : 0;
+        occT.lo = __ballot(sq[s0] != 0);
+        occT.hi = __ballot(t1 < 90 && sq[s1] != 0);
     }
-    off = tot_a + inc_b - mb.n;
-    for (int k = 0; k < mb.n; ++k) {
-        if (off + k < kMaxMoves) slab.moves[off + k] = (uint16_t)((64 + lane) * 90 + mb.get(k));
+    // rank -> square table of the side's pieces
+    uint8_t* rank_sq = reinterpret_cast<uint8_t*>(slab.misc);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int n_lo = __popcll(own.lo);
+    const int n_own = n_lo + __popcll(own.hi);
+    if (o0) { const int k = __popcll(own.lo & below); if (k < 16) rank_sq[k] = (uint8_t)lane; }
+    if (o1) { const int k = n_lo + __popcll(own.hi & below); if (k < 16) rank_sq[k] = (uint8_t)(64 + lane); }
+    wave_sync();
+
+    int total = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass * 8 >= n_own) break;                      // wave-uniform
+        const int k = pass * 8 + (lane >> 3), slot = lane & 7;
+        int n_run = 0, t0 = 0, delta = 0, extra = -1, from = 0;
+        if (k < n_own && k < 16) {
+            from = rank_sq[k];
+            const int p = sq[from];
+            const int row = from / 9, col = from - row * 9;
+            const int type = p > 7 ? p - 7 : p;
+            if (type == T_CHARIOT || type == T_CANNON) {
+                if (slot < 4) {                            // right, left, +row, -row (chessboard.cpp:199 / :221)
+                    const bool horiz = slot < 2, fwd = (slot & 1) == 0;
+                    const unsigned line = horiz ? bits_at(occ, row * 9, 0x1FFu) : bits_at(occT, col * 10, 0x3FFu);
+                    const int pos = horiz ? col : row, len = horiz ? 9 : 10;
+                    const RayHit h = ray_scan(line, pos, len, fwd);
+                    delta = horiz ? (fwd ? 1 : -1) : (fwd ? 9 : -9);
+                    t0 = from + delta;
+                    n_run = h.empties;
+                    if (type == T_CHARIOT) {
+                        if (h.first >= 0) {
+                            const int bs = horiz ? row * 9 + h.first : h.first * 9 + col;
+                            if ((sq[bs] > 7) != black) n_run += 1;         // enemy blocker: captured, it is the next square
+                        }
+                    } else if (h.second >= 0) {
+                        const int bs = horiz ? row * 9 + h.second : h.second * 9 + col;
+                        if ((sq[bs] > 7) != black) extra = bs;             // first piece behind the screen, iff enemy
+                    }
+                }
+            } else {
+                int dr = 0, dc = 0;
+                bool ok = false;
+                int guard = -1;                             // square that must be empty (horse leg / elephant eye)
+                switch (type) {
+                    case T_GENERAL:                         // (1,0) (-1,0) (0,1) (0,-1), chessboard.cpp:150
+                        if (slot < 4) { dr = slot == 0 ? 1 : slot == 1 ? -1 : 0; dc = slot == 2 ? 1 : slot == 3 ? -1 : 0; ok = true; }
+                        break;
+                    case T_ADVISOR:                         // (1,1) (1,-1) (-1,1) (-1,-1), :163
+                        if (slot < 4) { dr = slot < 2 ? 1 : -1; dc = (slot & 1) ? -1 : 1; ok = true; }
+                        break;
+                    case T_ELEPHANT:                        // (2,2) (2,-2) (-2,2) (-2,-2), :180
+                        if (slot < 4) { dr = slot < 2 ? 2 : -2; dc = (slot & 1) ? -2 : 2; ok = true; }
+                        break;
+                    case T_HORSE:                           // (1,2)(1,-2)(-1,2)(-1,-2)(2,1)(2,-1)(-2,1)(-2,-1), :249
+                        dr = slot < 4 ? ((slot & 2) ? -1 : 1) : ((slot & 2) ? -2 : 2);
+                        dc = slot < 4 ? ((slot & 1) ? -2 : 2) : ((slot & 1) ? -1 : 1);
+                        ok = true;
+                        break;
+                    case T_SOLDIER: {                       // forward, col-1, col+1, :265-283
+                        const int fw = black ? -1 : 1;
+                        const bool crossed = black ? row < 5 : row > 4;
+                        if (slot == 0) { dr = fw; ok = true; }
+                        else if (slot < 3 && crossed) { dc = slot == 1 ? -1 : 1; ok = true; }
+                        break;
+                    }
+                    default: break;
+                }
+                const int nr = row + dr, nc = col + dc;
+                ok = ok && inside(nr, nc);
+                if (ok) {
+                    switch (type) {
+                        case T_GENERAL: ok = in_any_palace(row, col) && in_any_palace(nr, nc); break;          // :328-343
+                        case T_ADVISOR: ok = in_own_palace(black ? C_BLACK : C_RED, nr, nc); break;            // :170-172
+                        case T_ELEPHANT:                                                                      // :189-192, :359
+                            ok = (black ? nr >= 5 : nr <= 4) && ((row < 5) == (nr < 5));
+                            guard = (row + dr / 2) * 9 + col + dc / 2;
+                            break;
+                        case T_HORSE: guard = (row + dr / 2) * 9 + col + dc / 2; break;                        // :254-258
+                        default: break;
+                    }
+                }
+                if (ok && guard >= 0) ok = sq[guard] == 0;
+                if (ok) {
+                    const int t = sq[nr * 9 + nc];
+                    ok = t == 0 || (t > 7) != black;                                                           // :78-80
+                }
+                if (ok) { n_run = 1; t0 = nr * 9 + nc; }
+            }
+        }
+        const int cnt = n_run + (extra >= 0 ? 1 : 0);
+        const int inc = wave_inclusive_scan(cnt);
+        int off = total + inc - cnt;
+        const int base = from * 90;
+        for (int i = 0; i < n_run; ++i, ++off)
+            if (off < kMaxMoves) slab.moves[off] = (uint16_t)(base + t0 + i * delta);
+        if (extra >= 0 && off < kMaxMoves) slab.moves[off] = (uint16_t)(base + extra);
+        total += __shfl(inc, 63, 64);
     }
-    const int n = tot_a + tot_b;
-    return n < kMaxMoves ? n : kMaxMoves;
+    return total < kMaxMoves ? total : kMaxMoves;
 }
 
 __device__ __forceinline__ int piece_value(int code) {                   // PieceScore, chessboard.h:23-31
