@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with HIP events (diagnostic)")
+    ap.add_argument("--games", type=int, default=N_GAMES, help="games per GPU (default = BASELINE's 8192; other values are diagnostic)")
+    ap.add_argument("--minibatch", type=int, default=0, help="transitions per update (default = games per GPU)")
     args = ap.parse_args()
 
     import torch
@@ -117,9 +119,11 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
 
-    first, _ = xd.shard_games(rank, N_GAMES)
-    cfg = xq.TrainerConfig(n_games=N_GAMES, layer_sizes=LAYERS, learning_rate=0.001, gamma=0.99, epsilon=0.1,
-                           replay_capacity=REPLAY, minibatch=MINIBATCH, td_net=_capi.TD_TARGET_NET,
+    n_games = args.games
+    minibatch = args.minibatch or (MINIBATCH if n_games == N_GAMES else n_games)
+    first, _ = xd.shard_games(rank, n_games)
+    cfg = xq.TrainerConfig(n_games=n_games, layer_sizes=LAYERS, learning_rate=0.001, gamma=0.99, epsilon=0.1,
+                           replay_capacity=max(REPLAY, n_games), minibatch=minibatch, td_net=_capi.TD_TARGET_NET,
                            backprop_mode=_capi.BACKPROP_REFERENCE, target_sync_interval=100, mean_gradient=1,
                            seed=0x5EED, first_game_id=first)
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
@@ -152,18 +156,18 @@ def main():
     stats = {s["name"]: s for s in t.dqn.kernel_stats(enable=0)}
 
     if rank == 0:
-        env_steps = world * N_GAMES * args.steps
+        env_steps = world * n_games * args.steps
         line = {
             "metric": "env steps/sec + DQN updates/sec at 8192 parallel games, 1/2/4/8 MI355X",
             "value": env_steps / elapsed, "unit": "env steps/s",
             "updates_per_s": args.steps / elapsed,
-            "transitions_trained_per_s": world * MINIBATCH * args.steps / elapsed,
+            "transitions_trained_per_s": world * minibatch * args.steps / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 8192 self-play games per GPU, DQN 1260-256-256-8100 fp32, "
                                    "replay 1M transitions, minibatch 8192, one update per ply",
-                       "games_per_gpu": N_GAMES, "layer_sizes": list(LAYERS), "replay_capacity": REPLAY,
-                       "minibatch": MINIBATCH, "epsilon": 0.1, "td_net": "target", "backprop": "reference-compatible",
+                       "games_per_gpu": n_games, "layer_sizes": list(LAYERS), "replay_capacity": max(REPLAY, n_games),
+                       "minibatch": minibatch, "epsilon": 0.1, "td_net": "target", "backprop": "reference-compatible",
                        "parallelism": f"dp{world} (games sharded, gradient all-reduce per update)" if world > 1 else "1 GPU"},
         }
         g = stats.get("gemm_qmax_rowmax")

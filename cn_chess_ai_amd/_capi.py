@@ -49,7 +49,7 @@ class TrainerConfig(C.Structure):
                 ("learning_rate", C.c_double), ("gamma", C.c_double), ("epsilon", C.c_double),
                 ("replay_capacity", C.c_int), ("minibatch", C.c_int), ("td_net", C.c_int), ("backprop_mode", C.c_int),
                 ("target_sync_interval", C.c_int), ("mean_gradient", C.c_int), ("seed", C.c_uint64),
-                ("first_game_id", C.c_uint32)]
+                ("first_game_id", C.c_uint32), ("collects_per_update", C.c_int)]
 
 
 assert C.sizeof(StepResult) == 24 and C.sizeof(EpisodeRecord) == 16
@@ -79,6 +79,7 @@ PROTOTYPES = {
     "xq_env_legal_moves": [_vp, _i, _pu16, _pi],
     "xq_env_legal_moves_dev": [_vp, _i, _vp, _vp],
     "xq_env_valid_matrix": [_vp, _i, _pu8],
+    "xq_env_get_winner": [_vp, _i, _i, _pu8],
     "xq_env_step": [_vp, _pi, _i, C.POINTER(StepResult)],
     "xq_env_selfplay_step": [_vp, _vp, _i, _u32, _vp, _vp],
     "xq_env_selfplay_step_host": [_vp, _pf, _u32, C.POINTER(StepResult)],

@@ -241,6 +241,19 @@ __global__ __launch_bounds__(256) void valid_matrix_kernel(const uint32_t* board
     }
 }
 
+// getWinner() for a range of games, one wave per game
+__global__ __launch_bounds__(256) void winner_kernel(const uint32_t* boards, int first, int n, uint8_t* out) {
+    __shared__ WaveSlab slabs[4];
+    const int wid = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int i = (int)blockIdx.x * 4 + wid;
+    uint32_t word = 0;
+    if (i < n && lane < kBoardWords) word = boards[(size_t)(first + i) * kBoardWords + lane];
+    unpack_to_slab(word, slabs[wid].sq);
+    wave_sync();
+    const BoardStatus st = board_status_wave(slabs[wid].sq);
+    if (i < n && lane == 0) out[i] = (uint8_t)st.first_general_color;
+}
+
 __global__ void fill_start_kernel(uint32_t* boards, uint4* meta, uint4* stats, int n) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i < n * kBoardWords) boards[i] = c_start_words[i % kBoardWords];
@@ -469,6 +482,16 @@ int xq_env_valid_matrix(xq_env* e, int game, uint8_t* valid8100_host) {
     hipLaunchKernelGGL(valid_matrix_kernel, dim3(8), dim3(256), 0, e->stream, e->boards, game, e->validmat);
     XQ_HIP(hipGetLastError());
     XQ_HIP(hipMemcpyAsync(valid8100_host, e->validmat, 8100, hipMemcpyDeviceToHost, e->stream));
+    XQ_HIP(hipStreamSynchronize(e->stream));
+    return XQ_OK;
+}
+
+int xq_env_get_winner(xq_env* e, int first, int n, uint8_t* winners_host) {
+    if (!e || !winners_host || first < 0 || n <= 0 || first + n > e->n) return fail(XQ_ERR_INVALID_ARGUMENT, "bad game range");
+    uint8_t* out = reinterpret_cast<uint8_t*>(e->counts);          // n bytes of the [n] int32 scratch
+    hipLaunchKernelGGL(winner_kernel, dim3((n + 3) / 4), dim3(256), 0, e->stream, e->boards, first, n, out);
+    XQ_HIP(hipGetLastError());
+    XQ_HIP(hipMemcpyAsync(winners_host, out, (size_t)n, hipMemcpyDeviceToHost, e->stream));
     XQ_HIP(hipStreamSynchronize(e->stream));
     return XQ_OK;
 }

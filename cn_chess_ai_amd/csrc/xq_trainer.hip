@@ -106,8 +106,11 @@ int xq_trainer_learn_apply(xq_trainer* t, int world_size) {
 
 int xq_trainer_step(xq_trainer* t, int n_iterations) {
     if (!t || n_iterations < 0) return fail(XQ_ERR_INVALID_ARGUMENT, "bad argument");
+    const int plies = t->cfg.collects_per_update > 1 ? t->cfg.collects_per_update : 1;
+    if (plies > 1 && t->cfg.replay_capacity == 0)
+        return fail(XQ_ERR_INVALID_ARGUMENT, "collects_per_update > 1 needs a replay ring (on-policy keeps one ply)");
     for (int i = 0; i < n_iterations; ++i) {
-        XQ_TRY(xq_trainer_collect(t));
+        for (int c = 0; c < plies; ++c) XQ_TRY(xq_trainer_collect(t));
         XQ_TRY(xq_trainer_learn_grads(t));
         XQ_TRY(xq_trainer_learn_apply(t, 1));
     }

@@ -154,6 +154,13 @@ class VecEnv:
         call("xq_env_valid_matrix", self._h, int(game), _ptr(m, C.c_uint8))
         return m
 
+    def get_winner(self, first=0, n=None):
+        """ChessBoard::getWinner() per game (colour of the first general in index order)."""
+        n = self.n_games - first if n is None else n
+        w = np.zeros(n, dtype=np.uint8)
+        call("xq_env_get_winner", self._h, int(first), int(n), _ptr(w, C.c_uint8))
+        return w
+
     def step(self, actions, auto_reset=True):
         actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.n_games)
         res = np.zeros(self.n_games, dtype=STEP_DTYPE)

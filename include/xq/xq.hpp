@@ -91,10 +91,10 @@ public:
     int getRedScore() const { return meta_[2]; }
     int getBlackScore() const { return meta_[3]; }
     bool checkGameOver() const { return probe().terminated != 0; }             // chessboard.cpp:286-309, on device
-    PieceColor getWinner() const {                                             // chessboard.cpp:312-320
-        for (int i = 0; i < 90; ++i)
-            if (sq_[i] == 1 || sq_[i] == 8) return sq_[i] == 1 ? PieceColor::Red : PieceColor::Black;
-        return PieceColor::None;
+    PieceColor getWinner() const {                                             // chessboard.cpp:312-320, on device
+        uint8_t w = 2;
+        check(xq_env_get_winner(env_, 0, 1, &w));
+        return w == 0 ? PieceColor::Red : w == 1 ? PieceColor::Black : PieceColor::None;
     }
     PieceColor getCurrentPlayer() const { return meta_[1] == 0 ? PieceColor::Red : PieceColor::Black; }
     int getMoveCount() const { return meta_[0]; }

@@ -76,6 +76,9 @@ int xq_env_get_state(xq_env* env, int first, int n, uint8_t* boards90_host, int3
  * codes: [n_games][128] u16 action codes, counts: [n_games]. */
 int xq_env_legal_moves(xq_env* env, int player, uint16_t* codes_host, int32_t* counts_host);
 int xq_env_legal_moves_dev(xq_env* env, int player, uint16_t* codes_dev, int32_t* counts_dev);
+/* ChessBoard::getWinner() (chessboard.cpp:312-320) for games first..first+n-1: colour of the first general in index order
+ * (so Red while both are alive), 2 if none. */
+int xq_env_get_winner(xq_env* env, int first, int n, uint8_t* winners_host);
 /* ChessBoard::isValidMove for all 90x90 (from,to) pairs of game g (chessboard.cpp:66-93,328-440): valid8100[f*90+t]. */
 int xq_env_valid_matrix(xq_env* env, int game, uint8_t* valid8100_host);
 
@@ -228,6 +231,7 @@ typedef struct {
     int mean_gradient;                      /* 1: grad_scale = 1/(minibatch*world), 0: sum (grad_scale = 1) */
     uint64_t seed;
     uint32_t first_game_id;
+    int collects_per_update;                /* plies played in every game per learn step (0 or 1 = one; BASELINE configs[3] uses 4) */
 } xq_trainer_config;
 
 int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer** out);
@@ -238,7 +242,7 @@ int xq_trainer_replay(xq_trainer* t, xq_replay** replay);
 int xq_trainer_collect(xq_trainer* t);                       /* one ply in every game */
 int xq_trainer_learn_grads(xq_trainer* t);                   /* sample + gradients into the grad buffer */
 int xq_trainer_learn_apply(xq_trainer* t, int world_size);   /* SGD apply (+ target sync bookkeeping) */
-int xq_trainer_step(xq_trainer* t, int n_iterations);        /* collect + learn_grads + learn_apply, n times (single GPU) */
+int xq_trainer_step(xq_trainer* t, int n_iterations);        /* (collect x collects_per_update) + learn_grads + learn_apply, n times (single GPU) */
 int xq_trainer_counters(xq_trainer* t, uint64_t* env_steps, uint64_t* updates, uint64_t* episodes);
 
 #ifdef __cplusplus

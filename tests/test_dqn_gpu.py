@@ -334,3 +334,59 @@ def test_invalid_arguments(xq):
     with pytest.raises(xq.XqError):
         d.td_update(np.zeros((1, 90)), np.zeros((1, 90)), [0], [0.0], [0])
     d.close()
+
+
+def test_td_update_config4_topology(xq, trace):
+    """BASELINE configs[3] network (512,512,512): reference-compatible TD step vs oracle (layer-0 gradient kernel with two
+    accumulator sets, 4 hidden-delta GEMMs with the as-written cross-layer view)."""
+    sizes = [1260, 512, 512, 512, 8100]
+    n = 12
+    S, A, R, D, S2 = transitions(trace, valid_indices(trace, n, seed=5))
+    d, w, b = make_net(xq, sizes, seed=15)
+    R = R / 1000.0
+    lr, scale = 0.05, 1.0 / n
+    want_w, want_b, want_q, want_y = oracle_td_update(sizes, w, b, w, b, S, A, R, D, S2, 0.99, lr, scale, 0)
+    qsa, y = d.td_update(S, S2, A, R, D, td_net=0, mode=0, learning_rate=lr, grad_scale=scale)
+    assert np.abs(qsa - want_q).max() < QTOL and np.abs(y - want_y).max() < QTOL
+    got_w, got_b = d.get_params()
+    assert np.abs(got_w - want_w).max() < PTOL and np.abs(got_b - want_b).max() < PTOL
+    d.close()
+
+
+def test_td_update_full_batch_properties(xq):
+    """BASELINE-size minibatch (8192): size-independent properties — linearity of the update in grad_scale, determinism
+    (bitwise equal reruns), rows >= 96 of the output layer untouched, empty slots (action -1) contribute nothing."""
+    sizes = CFG2_NET
+    n = 8192
+    env = xq.VecEnv(n, seed=77)
+    for _ in range(30):
+        env.selfplay_step(None)
+    S, _ = env.get_state()
+    res = env.selfplay_step(None)
+    S2, _ = env.get_state()
+    A = (res["action"] % 90).astype(np.int32)
+    R = (res["reward"] / 100.0).astype(np.float32)
+    D = res["done"]
+    runs = []
+    for scale in (64.0 / n, 64.0 / n, 128.0 / n):
+        d, w, b = make_net(xq, sizes, seed=21)
+        d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=1.0, grad_scale=scale)
+        runs.append(d.get_params())
+        d.close()
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])      # deterministic
+    w32 = w.astype(np.float32).astype(np.float64)
+    dw1, dw2 = runs[0][0] - w32, runs[2][0] - w32
+    m = np.abs(dw1) > 2e-3
+    assert m.sum() > 1000 and np.abs(dw2[m] / dw1[m] - 2.0).max() < 1e-2                          # linear in grad_scale
+    wo_out = 1260 * 256 + 256 * 256
+    assert np.array_equal(runs[0][0][wo_out + 96 * 256:], w32[wo_out + 96 * 256:])
+    # a batch whose second half is "empty slots" equals the first half alone (same scale)
+    d1, _, _ = make_net(xq, sizes, seed=21)
+    d2, _, _ = make_net(xq, sizes, seed=21)
+    A2 = A.copy(); A2[n // 2:] = -1
+    d1.td_update(S, S2, A2, R, D, td_net=1, mode=0, learning_rate=1.0, grad_scale=64.0 / n)
+    d2.td_update(S[:n // 2], S2[:n // 2], A[:n // 2], R[:n // 2], D[:n // 2], td_net=1, mode=0, learning_rate=1.0,
+                 grad_scale=64.0 / n)
+    w1, b1 = d1.get_params(); w2, b2 = d2.get_params()
+    assert np.abs(w1 - w2).max() < 1e-5 and np.abs(b1 - b2).max() < 1e-5
+    env.close(); d1.close(); d2.close()

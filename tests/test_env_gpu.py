@@ -61,6 +61,7 @@ def test_legal_moves_match_reference_trace(xq, trace):
     for i in range(n):
         key = "red" if trace["player"][i] == 0 else "black"
         assert np.array_equal(codes[i, :counts[i]], _ragged(trace, key, i)), i
+    assert np.array_equal(env.get_winner(), trace["winner"])          # getWinner() of the real reference, every record
     env.close()
 
 

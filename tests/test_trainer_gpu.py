@@ -118,3 +118,16 @@ def test_trainer_baseline_config_shape(xq):
     size, cap, tot = t.replay.stats()
     assert size == 4 * 8192 and tot == 4 * 8192
     t.close()
+
+
+def test_collects_per_update(xq):
+    """BASELINE configs[3] cadence: 4 plies per update."""
+    cfg = xq.TrainerConfig(n_games=128, layer_sizes=REF_NET, replay_capacity=2048, minibatch=256, collects_per_update=4)
+    t = xq.Trainer(cfg)
+    t.step(3)
+    c = t.counters()
+    assert c["env_steps"] == 128 * 12 and c["updates"] == 3 and t.replay.stats()[0] == 128 * 12
+    bad = xq.Trainer(xq.TrainerConfig(n_games=16, layer_sizes=REF_NET, replay_capacity=0, minibatch=16, collects_per_update=2))
+    with pytest.raises(xq.XqError):
+        bad.step(1)
+    t.close(); bad.close()
