@@ -41,7 +41,9 @@ struct xq_dqn {
     float* acts[XQ_MAX_LAYERS] = {nullptr};     // online hidden activations a_{l+1} = tanh(z_l), l = 0..nl-2
     float* tacts[2] = {nullptr, nullptr};       // ping-pong chain for s' / inference
     float* deltas[XQ_MAX_LAYERS] = {nullptr};   // delta_l of hidden layer l
-    float* d2 = nullptr;                        // [cap][96] output delta, columns 0..95
+    float* d2 = nullptr;                        // [cap][96] dense output delta (kept for diagnostics; TD path is sparse)
+    float* dsc = nullptr;                       // [cap] the one non-zero output delta of each TD sample
+    int32_t* act_mb = nullptr;                  // [cap] action.to of each TD sample (gathered), -1 = empty slot
     float* q90 = nullptr;                       // [cap][96]
     float* partial = nullptr;                   // row-max partials
     float* qsa = nullptr;
@@ -177,23 +179,23 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
         __syncthreads();
     }
     const int cnt = total;
-    // phase 2: wave w streams list entries w, w+nsets, ... (whole 1-KB rows as float4 per lane, 8 rows in flight per
+    // phase 2: wave w streams list entries w, w+nsets, ... (whole 1-KB rows as float4 per lane, 16 rows in flight per
     // wave) into ITS OWN accumulator set; the sets are added in fixed order afterwards => bitwise reproducible
     if (wid < nsets && (H & 3) == 0) {
         float* my = acc + (long long)wid * 14 * H;
         for (int col = lane * 4; col < H; col += 256) {
             int i = wid;
-            for (; i + 7 * nsets < cnt; i += 8 * nsets) {
-                int e[8];
-                float4 v[8];
+            for (; i + 15 * nsets < cnt; i += 16 * nsets) {
+                int e[16];
+                float4 v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     e[u] = list[i + u * nsets];
                     const float4 x = *reinterpret_cast<const float4*>(delta0 + (long long)(c0 + (e[u] & 2047)) * H + col);
                     v[u].x = x.x; v[u].y = x.y; v[u].z = x.z; v[u].w = x.w;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     float4* a = reinterpret_cast<float4*>(my + ((e[u] >> 11) - 1) * H + col);
                     float4 t = *a;
                     t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w;
@@ -226,24 +228,32 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
     }
 }
 
-// TD target + output delta for one sample per wave (chessai.cpp:122-128 + outputLayerDeltaKernel dqn.cu:288-295).
+// TD target, output delta and the TOP hidden delta for one sample per wave (chessai.cpp:122-128 +
+// outputLayerDeltaKernel dqn.cu:288-295 + hiddenLayerDeltaKernel dqn.cu:297-308 for the last hidden layer).
+// The output delta of a TD step has ONE non-zero entry per sample (column action.to), so the last hidden layer's delta
+// is a scaled row of the weight view — no GEMM:  dtop[b][i] = delta_b * View[a_b][i] * (1 - a_last[b][i]^2), where
+// View[a][i] = view[a*view_ld + i] is the as-written (reference mode: a < view_kmax = width of the last hidden layer,
+// stride = width of the layer below) or the textbook (row a of W_out) operand.  Also emits, per sample, the scalar
+// delta and the action (gathered through `slots`) for the segmented output-layer gradient.
 __global__ __launch_bounds__(256) void td_delta_kernel(int n, const int32_t* __restrict__ slots,
                                                        const int32_t* __restrict__ action_to, const float* __restrict__ reward,
                                                        const uint8_t* __restrict__ done, const float* __restrict__ a_last, int H,
                                                        const float* __restrict__ w_out, const float* __restrict__ b_out,
                                                        const float* __restrict__ partial, int n_partial, float gamma,
-                                                       float* __restrict__ d2, float* __restrict__ qsa, float* __restrict__ yv,
-                                                       float* __restrict__ lossv) {
+                                                       const float* __restrict__ view, long long view_ld, int view_kmax,
+                                                       float* __restrict__ dtop, float* __restrict__ dsc, int32_t* __restrict__ act,
+                                                       float* __restrict__ qsa, float* __restrict__ yv, float* __restrict__ lossv) {
     const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int b = (int)blockIdx.x * 4 + wid;
     if (b >= n) return;
     const int s = slots ? slots[b] : b;
     const int a = action_to[s];
+    const bool live = a >= 0 && a < 96;
     float delta = 0.f, q = 0.f, y = 0.f;
-    if (a >= 0 && a < 96) {
+    const float* ar = a_last + (long long)b * H;
+    if (live) {
         float z = 0.f;
         const float* wr = w_out + (long long)a * H;
-        const float* ar = a_last + (long long)b * H;
         for (int i = lane; i < H; i += 64) z += wr[i] * ar[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
@@ -257,13 +267,111 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, const int32_t* __r
         y = done[s] ? r : r + gamma * tanhf(zm);       // max_k tanh(z_k) = tanh(max_k z_k)
         delta = (q - y) * (1.f - q * q);               // (a - target) * (1 - tanh(z)^2)
     }
-    float* row = d2 + (long long)b * 96;
-    row[lane] = lane == a ? delta : 0.f;
-    if (lane < 32) row[64 + lane] = (64 + lane) == a ? delta : 0.f;
-    if (lane == 0) {
-        qsa[b] = q; yv[b] = y;
-        lossv[b] = (a >= 0 && a < 96) ? 0.5f * (q - y) * (q - y) : 0.f;
+    float* drow = dtop + (long long)b * H;
+    if (live && a < view_kmax) {
+        const float* vr = view + (long long)a * view_ld;
+        for (int i = lane; i < H; i += 64) {
+            const float h = ar[i];
+            drow[i] = delta * vr[i] * (1.f - h * h);
+        }
+    } else {
+        for (int i = lane; i < H; i += 64) drow[i] = 0.f;
     }
+    if (lane == 0) {
+        dsc[b] = delta;
+        act[b] = live ? a : -1;
+        qsa[b] = q; yv[b] = y;
+        lossv[b] = live ? 0.5f * (q - y) * (q - y) : 0.f;
+    }
+}
+
+// Output-layer gradient of a TD minibatch: gW_out[j][:] = sum over the samples with action.to == j of delta_b * a_last[b][:]
+// and gb_out[j] = sum of delta_b (j < 96).  Segmented sums instead of a [96 x B] x [B x H] product: every sample's
+// activation row is read exactly once.  Block (group of 4 actions, chunk of samples): ordered compaction of the chunk's
+// samples whose action falls in the group, then the rows are streamed into per-wave LDS accumulators (combined in fixed
+// order => bitwise reproducible).  partial[chunk][96*H + 96] (weights, then biases).
+__global__ __launch_bounds__(256) void out_grad_kernel(const int32_t* __restrict__ act, const float* __restrict__ dsc,
+                                                       const float* __restrict__ a_last, int n, int H, int chunk,
+                                                       float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* acc = smem;                                  // [4 waves][4 actions][H]
+    uint16_t* list = reinterpret_cast<uint16_t*>(smem + 16 * H);   // [chunk] (b_local | class << 11)
+    __shared__ int wcount[4];
+    __shared__ int total;
+    __shared__ float bsum[4][4];
+    const int g = (int)blockIdx.x;                      // actions 4g .. 4g+3
+    const int c0 = (int)blockIdx.y * chunk, c1 = min(n, c0 + chunk);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < 16 * H; i += 256) acc[i] = 0.f;
+    if (tid == 0) total = 0;
+    __syncthreads();
+    for (int base = c0; base < c1; base += 256) {
+        const int b = base + tid;
+        int cls = -1;
+        if (b < c1) { const int a = act[b]; if (a >= 4 * g && a < 4 * g + 4) cls = a - 4 * g; }
+        const unsigned long long m = __ballot(cls >= 0);
+        if (lane == 0) wcount[wid] = __popcll(m);
+        __syncthreads();
+        int off = total;
+        for (int w = 0; w < wid; ++w) off += wcount[w];
+        if (cls >= 0) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((b - c0) | (cls << 11));
+        __syncthreads();
+        if (tid == 0) total += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    const int cnt = total;
+    float* my = acc + (long long)wid * 4 * H;
+    float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
+    // wave w takes entries w, w+4, ... (fixed assignment), 8 rows in flight
+    int i = wid;
+    for (; i + 28 < cnt; i += 32) {
+        int bb[8], cl[8];
+        float dl[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = list[i + 4 * u];
+            bb[u] = c0 + (e & 2047); cl[u] = e >> 11;
+            dl[u] = dsc[bb[u]];
+        }
+        for (int col = lane * 4; col < H; col += 256) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 x = *reinterpret_cast<const float4*>(a_last + (long long)bb[u] * H + col);
+                v[u].x = x.x; v[u].y = x.y; v[u].z = x.z; v[u].w = x.w;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float4* a = reinterpret_cast<float4*>(my + cl[u] * H + col);
+                float4 t = *a;
+                t.x += dl[u] * v[u].x; t.y += dl[u] * v[u].y; t.z += dl[u] * v[u].z; t.w += dl[u] * v[u].w;
+                *a = t;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (cl[u] == 0) bs0 += dl[u]; else if (cl[u] == 1) bs1 += dl[u]; else if (cl[u] == 2) bs2 += dl[u]; else bs3 += dl[u];
+        }
+    }
+    for (; i < cnt; i += 4) {
+        const int e = list[i];
+        const int b = c0 + (e & 2047), cls = e >> 11;
+        const float d1 = dsc[b];
+        if (cls == 0) bs0 += d1; else if (cls == 1) bs1 += d1; else if (cls == 2) bs2 += d1; else bs3 += d1;
+        for (int col = lane * 4; col < H; col += 256) {
+            const float4 x = *reinterpret_cast<const float4*>(a_last + (long long)b * H + col);
+            float4* a = reinterpret_cast<float4*>(my + cls * H + col);
+            float4 t = *a;
+            t.x += d1 * x.x; t.y += d1 * x.y; t.z += d1 * x.z; t.w += d1 * x.w;
+            *a = t;
+        }
+    }
+    if (lane == 0) { bsum[wid][0] = bs0; bsum[wid][1] = bs1; bsum[wid][2] = bs2; bsum[wid][3] = bs3; }
+    __syncthreads();
+    float* out = partial + (long long)blockIdx.y * (96LL * H + 96);
+    for (int i = tid; i < 4 * H; i += 256)
+        out[(long long)4 * g * H + i] = ((acc[i] + acc[4 * H + i]) + acc[8 * H + i]) + acc[12 * H + i];
+    if (tid < 4) out[96LL * H + 4 * g + tid] = ((bsum[0][tid] + bsum[1][tid]) + bsum[2][tid]) + bsum[3][tid];
 }
 
 // dense output delta (general DQN::backpropagate target): d = (q - t) * (1 - q^2)
@@ -311,27 +419,38 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(ColsumJobs J) {
     if (ty == 0 && c < C)
         J.work[J.poff[job] + (long long)blockIdx.y * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(ColsumJobs J) {
+__global__ __launch_bounds__(256) void colsum_final_kernel(ColsumJobs J) {   // 64 columns x 4 partial lanes per block
+    __shared__ float red[4][64];
     const int job = (int)blockIdx.y;
     const int C = J.C[job];
-    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (c >= C) return;
-    const float* p = J.work + J.poff[job] + c;
+    const int tx = (int)(threadIdx.x & 63), ty = (int)(threadIdx.x >> 6);
+    const int c = (int)blockIdx.x * 64 + tx;
+    if ((int)blockIdx.x * 64 >= C) return;
     float s0 = 0.f, s1 = 0.f;
-    int z = 0;
-    for (; z + 1 < J.R; z += 2) { s0 += p[(long long)z * C]; s1 += p[(long long)(z + 1) * C]; }
-    if (z < J.R) s0 += p[(long long)z * C];
-    J.dst[job][c] = s0 + s1;
+    if (c < C) {
+        const float* p = J.work + J.poff[job] + c;
+        int z = ty;
+        for (; z + 4 < J.R; z += 8) { s0 += p[(long long)z * C]; s1 += p[(long long)(z + 4) * C]; }
+        if (z < J.R) s0 += p[(long long)z * C];
+    }
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && c < C) J.dst[job][c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
 // out[i] = sum_z slabs[z*stride + i], z ascending (deterministic)
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs, long long stride, long long len, float* __restrict__ out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
-        float s0 = 0.f, s1 = 0.f;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int z = 0;
-        for (; z + 1 < nslabs; z += 2) { s0 += slabs[(long long)z * stride + i]; s1 += slabs[(long long)(z + 1) * stride + i]; }
-        if (z < nslabs) s0 += slabs[(long long)z * stride + i];
-        out[i] = s0 + s1;
+        for (; z + 3 < nslabs; z += 4) {
+            s0 += slabs[(long long)z * stride + i];
+            s1 += slabs[(long long)(z + 1) * stride + i];
+            s2 += slabs[(long long)(z + 2) * stride + i];
+            s3 += slabs[(long long)(z + 3) * stride + i];
+        }
+        for (; z < nslabs; ++z) s0 += slabs[(long long)z * stride + i];
+        out[i] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -419,9 +538,9 @@ static int ensure_capacity(xq_dqn* d, int n) {
         XQ_HIP(hipMemsetAsync(d->tacts[i], 0, rows * (size_t)maxh * sizeof(float), d->stream));
     }
     const int ntn = (d->nout() + 63) / 64;             // column-max partials: 2 per 64- or 128-row tile
-    float** bufs[] = {&d->d2, &d->q90, &d->partial, &d->qsa, &d->yv, &d->lossv};
-    const size_t sizes[] = {cap * 96, cap * 96, cap * (size_t)ntn * 2, cap, cap, cap};
-    for (int i = 0; i < 6; ++i) {
+    float** bufs[] = {&d->d2, &d->q90, &d->partial, &d->qsa, &d->yv, &d->lossv, &d->dsc, reinterpret_cast<float**>(&d->act_mb)};
+    const size_t sizes[] = {cap * 96, cap * 96, cap * (size_t)ntn * 2, cap, cap, cap, cap, cap};
+    for (int i = 0; i < 8; ++i) {
         if (*bufs[i]) XQ_HIP(hipFree(*bufs[i]));
         XQ_HIP(hipMalloc(bufs[i], sizes[i] * sizeof(float)));
     }
@@ -493,10 +612,11 @@ static int check_reference_topology(const xq_dqn* d) {
 // hidden deltas l = nl-2 .. 0 from the output-side delta `dnext` ([n][ld_next], only the first k_nz columns can be
 // non-zero).  reference mode: delta_l = (dnext[:, :L[l+1]] x View) * (1-a^2), View[i][idx] = Wflat[wo[l+1] + i*L[l] + idx];
 // textbook: View[k][idx] = W_{l+1}[k][idx], k < L[l+2].
-static int hidden_deltas(xq_dqn* d, int n, const float* dnext, int ld_next, int k_nz, int mode) {
+static int hidden_deltas(xq_dqn* d, int n, const float* dnext, int ld_next, int k_nz, int mode, int l_start = -1) {
     const float* up = dnext;
     int ld_up = ld_next, nz = k_nz;
-    for (int l = d->nl - 2; l >= 0; --l) {
+    if (l_start < 0) l_start = d->nl - 2;
+    for (int l = l_start; l >= 0; --l) {
         GemmArgs g; memset(&g, 0, sizeof g);
         g.M = n; g.N = d->L[l + 1];
         const int kfull = (mode == XQ_BACKPROP_REFERENCE) ? d->L[l + 1] : d->L[l + 2];
@@ -571,7 +691,7 @@ static int bias_grads(xq_dqn* d, BiasJobs& bj, int n) {
     ProfScope ps(d, "bias_grad_colsum", tot, 4.0 * tot);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((maxc + 63) / 64, J.R, J.njobs), dim3(256), 0, d->cur, J);
     XQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((maxc + 255) / 256, J.njobs), dim3(256), 0, d->cur, J);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((maxc + 63) / 64, J.njobs), dim3(256), 0, d->cur, J);
     XQ_HIP(hipGetLastError());
     return XQ_OK;
 }
@@ -579,7 +699,7 @@ static int bias_grads(xq_dqn* d, BiasJobs& bj, int n) {
 // layer 0: per-(square, piece) segmented sums of delta_0 rows (no dense one-hot product); launches on d->cur
 static int l0_gradient(xq_dqn* d, int n, float* dst) {
     const int H = d->L[1];
-    const int chunk = 1024;                          // samples per block; list entries hold 11 bits of sample index
+    const int chunk = 1024;                          // samples per block (list entries hold 11 bits of sample index)
     const int nchunks = (n + chunk - 1) / chunk;
     const long long len = (long long)kStateSize * H;
     float* out = dst;
@@ -626,8 +746,8 @@ static void layout_td_grads(xq_dqn* d) {
     d->g_w0 = off; off += (size_t)d->L[0] * d->L[1];
     for (int l = 1; l + 1 < d->nl; ++l) { d->g_wh[l] = off; off += (size_t)d->L[l] * d->L[l + 1]; }
     d->g_wout = off; off += (size_t)96 * d->hlast();
+    d->g_bout = off; off += 96;                      // directly behind the output rows: one ordered reduction fills both
     for (int l = 0; l + 1 < d->nl; ++l) { d->g_bh[l] = off; off += (size_t)d->L[l + 1]; }
-    d->g_bout = off; off += 96;
     d->n_grads_td = off;
 }
 
@@ -693,7 +813,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     hipStreamSynchronize(d->stream);
     for (int i = 0; i < 2; ++i) { hipFree(d->params[i]); hipFree(d->tacts[i]); }
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts[l]); hipFree(d->deltas[l]); }
-    hipFree(d->gboards); hipFree(d->d2); hipFree(d->q90); hipFree(d->partial); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
+    hipFree(d->gboards); hipFree(d->dsc); hipFree(d->act_mb); hipFree(d->d2); hipFree(d->q90); hipFree(d->partial); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
     hipFree(d->grads_td); hipFree(d->grads_full); hipFree(d->slabs); hipFree(d->bias_work); hipFree(d->xdense); hipFree(d->qfull); hipFree(d->tfull);
     hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
     d->prof.collect();
@@ -910,18 +1030,22 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
     }
     // 2. join the s chain
     XQ_HIP(hipStreamWaitEvent(d->stream, d->ev_join, 0));
-    // 3. Q(s, a), target, output delta
+    // 3. Q(s, a), target, the scalar output delta and the delta of the last hidden layer (one launch, no GEMM)
     {
-        ProfScope ps(d, "td_target_delta", 2.0 * n * Hl, (double)n * (Hl * 8 + n_partial * 4 + 96 * 4));
+        const int lt = nl - 2;                               // last hidden layer
+        const float* view = d->wrest(XQ_NET_ONLINE) + (d->wo[lt + 1] - d->wo[1]);
+        const long long view_ld = (mode == XQ_BACKPROP_REFERENCE) ? d->L[lt] : d->L[lt + 1];
+        const int view_kmax = (mode == XQ_BACKPROP_REFERENCE) ? d->L[lt + 1] : NO;
+        ProfScope ps(d, "td_target_delta", 4.0 * n * Hl, (double)n * (Hl * 16 + n_partial * 4));
         hipLaunchKernelGGL(td_delta_kernel, dim3((n + 3) / 4), dim3(256), 0, d->cur, n, slots, action_to, reward, done,
                            outs[nl - 2], Hl, d->wl(XQ_NET_ONLINE, nl - 1), d->bl(XQ_NET_ONLINE, nl - 1), d->partial, n_partial,
-                           (float)d->gamma, d->d2, d->qsa, d->yv, d->lossv);
+                           (float)d->gamma, view, view_ld, view_kmax, d->deltas[lt], d->dsc, d->act_mb, d->qsa, d->yv, d->lossv);
         XQ_HIP(hipGetLastError());
     }
     d->last_n = n;
-    // 4. hidden deltas
-    XQ_TRY(hidden_deltas(d, n, d->d2, 96, 96, mode));
-    // 5. gradients (compact layout).  The layer-0 segmented sum (side stream) overlaps the gradient GEMMs.
+    // 4. the remaining hidden deltas (GEMMs)
+    if (nl >= 3) XQ_TRY(hidden_deltas(d, n, d->deltas[nl - 2], d->L[nl - 1], d->L[nl - 1], mode, nl - 3));
+    // 5. gradients (compact layout).  The layer-0 segmented sum (side stream) overlaps the other gradient kernels.
     float* G = d->grads_td;
     BiasJobs bj;
     XQ_HIP(hipEventRecord(d->ev_fork, d->stream));
@@ -933,13 +1057,27 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
         if (rc != XQ_OK) return rc;
     }
     XQ_HIP(hipEventRecord(d->ev_join, d->side));
-    {   // output layer rows 0..95
-        GemmArgs g; memset(&g, 0, sizeof g);
-        g.M = 96; g.N = Hl; g.K = n;
-        g.A = d->d2; g.lda = 96;
-        g.B = outs[nl - 2]; g.ldb = Hl;
-        XQ_TRY((grad_gemm<L_MCONTIG>(d, g, G + d->g_wout, "gemm_grad_out96")));
-        bj.add(d->d2, 96, 96, G + d->g_bout);
+    {   // output layer rows 0..95 + their biases: segmented sums by action
+        const int chunk = 1024;
+        const int nchunks = (n + chunk - 1) / chunk;
+        const long long len = 96LL * Hl + 96;
+        float* dst = G + d->g_wout;                      // g_bout follows directly
+        float* out = dst;
+        if (nchunks > 1) { XQ_TRY(ensure_slabs(d, (size_t)nchunks * (size_t)len)); out = d->slabs; }
+        {
+            ProfScope ps(d, "out_grad_segsum", 2.0 * n * Hl, (double)n * (Hl * 4 + 8) + 4.0 * nchunks * len);
+            const size_t shmem = (size_t)16 * Hl * sizeof(float) + (size_t)chunk * sizeof(uint16_t);
+            if (shmem > 64 * 1024 || (Hl & 3)) return fail(XQ_ERR_INVALID_ARGUMENT, "last hidden layer width %d unsupported by the output-gradient kernel (multiple of 4, <= 960)", Hl);
+            hipLaunchKernelGGL(out_grad_kernel, dim3(24, nchunks), dim3(256), shmem, d->cur, d->act_mb, d->dsc, outs[nl - 2], n, Hl,
+                               chunk, out);
+            XQ_HIP(hipGetLastError());
+        }
+        if (nchunks > 1) {
+            ProfScope ps(d, "reduce_slabs", (double)nchunks * len, 4.0 * (nchunks + 1) * len);
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, d->cur, d->slabs, nchunks, len,
+                               len, dst);
+            XQ_HIP(hipGetLastError());
+        }
     }
     for (int l = nl - 2; l >= 1; --l) {
         GemmArgs g; memset(&g, 0, sizeof g);
