@@ -227,6 +227,16 @@ __device__ __forceinline__ void epilogue_colmax(const GemmArgs& g, const f32x16 
     const int r = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
     const float NEG = -__builtin_inff();
+    // all bias values of this lane's rows in ONE batch of loads (clamped index, masked by select): a branch per row
+    // compiles to 32 serialised load + wait pairs
+    float bm[TM][16];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + wm * 32 * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            bm[i][q] = g.bias[m < g.M ? m : g.M - 1];
+        }
     float cm[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) cm[j] = NEG;
@@ -235,11 +245,9 @@ __device__ __forceinline__ void epilogue_colmax(const GemmArgs& g, const f32x16 
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int m = m0 + wm * 32 * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (m < g.M) {
-                const float bm = g.bias[m];
+            const bool ok = m < g.M;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) cm[j] = fmaxf(cm[j], acc[i][j][q] + bm);
-            }
+            for (int j = 0; j < TN; ++j) cm[j] = fmaxf(cm[j], ok ? acc[i][j][q] + bm[i][q] : NEG);
         }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -283,6 +291,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         return;
     }
     float* Cz = g.C + (long long)blockIdx.z * g.slab_stride;
+    if ((m0 + BM <= g.M) && (n0 + BN <= g.N)) {
+        // tile fully inside the output: no per-element bounds logic, so the epilogue's loads (bias / activation for the
+        // delta) are issued as one batch instead of a load + wait per row
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * 32 * TN + j * 32 + r;
+                const int mb = m0 + wm * 32 * TM + i * 32 + 4 * h;
+                float bias = 0.f;
+                if (EPI == EPI_BIAS_TANH) bias = g.bias[n];
+                float hv[16];
+                if (EPI == EPI_DELTA) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) hv[q] = g.H[(long long)(mb + (q & 3) + 8 * (q >> 2)) * g.ldh + n];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float v = acc[i][j][q];
+                    if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
+                    if (EPI == EPI_DELTA) v = v * (1.f - hv[q] * hv[q]);
+                    Cz[(long long)(mb + (q & 3) + 8 * (q >> 2)) * g.ldc + n] = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
