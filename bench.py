@@ -87,6 +87,29 @@ def pmc_traffic(kernel_substring):
     return None, None
 
 
+def env_only(args, xq, tstream):
+    """Env-only random-policy stepping (BASELINE.md §3 C2 on the GPU): legal moves + uniform choice + movePiece + reward +
+    terminal + auto-reset for every game, nothing else.  Prints one JSON line (diagnostic, not the headline metric)."""
+    import torch
+    env = xq.VecEnv(args.games, seed=0x5EED, stream=C.c_void_p(tstream.cuda_stream))
+    for _ in range(args.warmup):
+        env.selfplay_step_dev()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(tstream)
+    for _ in range(args.steps):
+        env.selfplay_step_dev()
+    b.record(tstream)
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / args.steps
+    bytes_per = args.games * (2 * (48 + 16))                     # board + meta read and written; no Q row, no replay record
+    c = env.counters()
+    print(json.dumps({"metric": "env-only steps/s, uniform-random policy", "value": args.games / (ms * 1e-3), "unit": "env steps/s",
+                      "games": args.games, "steps": args.steps, "us_per_launch": ms * 1e3,
+                      "algorithmic_GBps": bytes_per / (ms * 1e-3) / 1e9, "episodes_finished": c["episodes"]}), flush=True)
+    env.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +119,8 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with HIP events (diagnostic)")
     ap.add_argument("--games", type=int, default=N_GAMES, help="games per GPU (default = BASELINE's 8192; other values are diagnostic)")
     ap.add_argument("--minibatch", type=int, default=0, help="transitions per update (default = games per GPU)")
+    ap.add_argument("--env-only", action="store_true",
+                    help="diagnostic: time only the fused self-play kernel with the uniform-random policy (no Q-network)")
     args = ap.parse_args()
 
     import torch
@@ -121,6 +146,8 @@ def main():
 
     n_games = args.games
     minibatch = args.minibatch or (MINIBATCH if n_games == N_GAMES else n_games)
+    if args.env_only:
+        return env_only(args, xq, tstream)
     first, _ = xd.shard_games(rank, n_games)
     cfg = xq.TrainerConfig(n_games=n_games, layer_sizes=LAYERS, learning_rate=0.001, gamma=0.99, epsilon=0.1,
                            replay_capacity=max(REPLAY, n_games), minibatch=minibatch, td_net=_capi.TD_TARGET_NET,

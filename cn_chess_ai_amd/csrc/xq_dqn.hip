@@ -34,6 +34,7 @@ struct xq_dqn {
     // s'-chain + column-max GEMM; the layer-0 gradient beside the other gradient GEMMs); `cur` = stream launches go to
     hipStream_t side = nullptr;
     hipStream_t cur = nullptr;
+    int ncu = 256;                              // compute units of the device (persistent-kernel grid = 2 per CU)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float* params[2] = {nullptr, nullptr};
     // workspaces sized for `cap` samples
@@ -783,6 +784,11 @@ int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, dou
     if (hip_stream) d->stream = (hipStream_t)hip_stream;
     else { XQ_HIP(hipStreamCreate(&d->stream)); d->own_stream = true; }
     d->cur = d->stream;
+    {
+        hipDeviceProp_t prop; int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            d->ncu = prop.multiProcessorCount;
+    }
     XQ_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
     XQ_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
     XQ_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
@@ -1016,12 +1022,18 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
         if (big_tiles && (Hl % GBK) == 0 && vec_ok(g.A, g.lda) && vec_ok(g.B, g.ldb)) {
             // persistent form: 2 blocks per CU walk the tile list with the prefetch running across tile boundaries
             const int tiles_m = (NO + 127) / 128, total = tiles_m * ((n + 127) / 128);
-            int ncu = 256;
-            hipDeviceProp_t prop; int dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+            const int ncu = d->ncu;
             g.a_vec = g.b_vec = 1; g.k_chunk = Hl;
+            const int grid = std::min(total, 2 * ncu);
+            // static priority for the second half of the grid (see the kernel): each half walks its own half of the tiles
+            g.prio_split = 0; g.prio_tiles = 0;
+            if (grid >= 2 && (grid & 1) == 0 && total >= 4 * grid) {
+                g.prio_split = grid / 2;
+                g.prio_tiles = (total / 2) / tiles_m * tiles_m;
+                if (g.prio_tiles <= 0 || g.prio_tiles >= total) { g.prio_split = 0; g.prio_tiles = 0; }
+            }
             ProfScope ps(d, "gemm_qmax_rowmax", 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + 2.0 * tiles_m * g.N));
-            hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(std::min(total, 2 * ncu)), dim3(256), 0, d->cur, g,
+            hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(grid), dim3(256), 0, d->cur, g,
                                tiles_m, total);
             XQ_HIP(hipGetLastError());
         } else {

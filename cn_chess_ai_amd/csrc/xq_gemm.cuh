@@ -46,6 +46,8 @@ struct GemmArgs {
     int k_chunk;                  // split-K: k range of blockIdx.z is [z*k_chunk, min(K,(z+1)*k_chunk))
     long long slab_stride;        // split-K: C of split z = C + z*slab_stride
     int a_vec, b_vec;             // 16-byte vector loads allowed (base and ld aligned)
+    int prio_split;               // persistent kernel: blocks >= prio_split run at s_setprio 1 (0 = off) ...
+    int prio_tiles;               // ... and own tiles [0, prio_tiles); the other blocks own [prio_tiles, total)
 };
 
 // ---- global -> register staging (4 x float4 per thread per operand) --------------------------------------------
@@ -357,8 +359,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
-    int t = (int)blockIdx.x;
-    if (t >= total) return;
+    // Two blocks share every SIMD.  With equal priority their waves alternate MFMAs, finish each k-step together and
+    // then sit in their load/barrier phase together — the matrix pipe idles.  Static priority for the second half of
+    // the grid (the blocks that land in the second slot of each CU) makes those run their MFMAs back to back while the
+    // others fill exactly their gaps; the prioritised half therefore gets the larger share of the tile list
+    // (g.prio_tiles of `total`), each half walking its own range with its own stride.
+    int t, tend, stride;
+    if (g.prio_split > 0) {
+        const bool hi = (int)blockIdx.x >= g.prio_split;
+        if (hi) __builtin_amdgcn_s_setprio(1);
+        stride = hi ? (int)gridDim.x - g.prio_split : g.prio_split;
+        t = hi ? (int)blockIdx.x - g.prio_split : g.prio_tiles + (int)blockIdx.x;
+        tend = hi ? g.prio_tiles : total;
+    } else {
+        t = (int)blockIdx.x; tend = total; stride = (int)gridDim.x;
+    }
+    if (t >= tend) return;
     int tm = t % tiles_m, tn = t / tiles_m;
     float4 va[BM / 32], vb[BN / 32];
     stage_load<L_KCONTIG, BM, true>(g, g.A, g.lda, 1, tm * BM, g.M, 0, g.K, va);
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-        const int tnext = t + (int)gridDim.x;
+        const int tnext = t + stride;
         for (int k0 = 0; k0 < g.K; k0 += GBK) {
             __syncthreads();
             stage_store<L_KCONTIG, BM>(As, va);
@@ -380,14 +396,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             if (k0 + GBK < g.K) {
                 stage_load<L_KCONTIG, BM, true>(g, g.A, g.lda, 1, tm * BM, g.M, k0 + GBK, g.K, va);
                 stage_load<L_KCONTIG, BN, true>(g, g.B, g.ldb, 1, tn * BN, g.N, k0 + GBK, g.K, vb);
-            } else if (tnext < total) {          // first k-tile of the NEXT output tile
+            } else if (tnext < tend) {           // first k-tile of the NEXT output tile
                 stage_load<L_KCONTIG, BM, true>(g, g.A, g.lda, 1, (tnext % tiles_m) * BM, g.M, 0, g.K, va);
                 stage_load<L_KCONTIG, BN, true>(g, g.B, g.ldb, 1, (tnext / tiles_m) * BN, g.N, 0, g.K, vb);
             }
             tile_mma<L_KCONTIG, L_KCONTIG, BM, BN, TM, TN>(As, Bs, wm, wn, r, h, acc);
         }
         epilogue_colmax<TM, TN>(g, acc, tm * BM, tn * BN, tm);
-        if (tnext >= total) break;
+        if (tnext >= tend) break;
         t = tnext; tm = t % tiles_m; tn = t / tiles_m;
     }
 }
