@@ -90,18 +90,41 @@ struct ProfScope {
 // kernels
 // ---------------------------------------------------------------------------------------------------------------
 
+// where sample b of a minibatch lives: identity, an explicit slot list, or the replay sampler's Philox stream recomputed
+// in place (ctr = {b, 0, call, 1}, key = seed, % size — identical to replay_sample_kernel)
+struct SlotSrc {
+    const int32_t* slots;
+    uint32_t implicit, call, seed_lo, seed_hi, size;
+};
+__device__ __forceinline__ int slot_of(const SlotSrc& s, int b) {
+    if (s.implicit) return (int)(philox4x32_10((uint32_t)b, 0u, s.call, 1u, s.seed_lo, s.seed_hi).v[0] % s.size);
+    return s.slots ? s.slots[b] : b;
+}
+// the two forward chains of a TD step (s on the online net, s' on the TD net) share one launch per layer
+struct L0Jobs {
+    const uint32_t* boards[2];
+    const float* W0T[2];
+    const float* b0[2];
+    float* out[2];
+    uint32_t* gathered[2];
+    int njobs;
+};
+
 // Layer 0 from packed boards: a_1 = tanh(b_0 + sum over occupied squares of W0^T[sq*14 + piece-1][:]).
 // One wave per sample; ascending square order = the reference's i-ascending accumulation with the zeros skipped.
-__global__ __launch_bounds__(256) void l0_forward_kernel(const uint32_t* __restrict__ boards, const int32_t* __restrict__ slots,
-                                                         int n, const float* __restrict__ W0T, const float* __restrict__ b0,
-                                                         int H, float* __restrict__ out, uint32_t* __restrict__ gathered) {
+__global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, int n, int H) {
     __shared__ int rows[4][96];
     const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int b = (int)blockIdx.x * 4 + wid;
     if (b >= n) return;
-    const int srow = slots ? slots[b] : b;
-    const uint32_t* bw = boards + (long long)srow * kBoardWords;
-    if (gathered != nullptr && lane < kBoardWords)      // the minibatch's boards, contiguous, for the one-hot gradient GEMM
+    const int job = (int)blockIdx.y;
+    const float* __restrict__ W0T = J.W0T[job];
+    const float* __restrict__ b0 = J.b0[job];
+    float* __restrict__ out = J.out[job];
+    uint32_t* __restrict__ gathered = J.gathered[job];
+    const int srow = slot_of(src, b);
+    const uint32_t* bw = J.boards[job] + (long long)srow * kBoardWords;
+    if (gathered != nullptr && lane < kBoardWords)      // the minibatch's boards, contiguous, for the layer-0 gradient
         gathered[(long long)b * kBoardWords + lane] = bw[lane];
     const int s0 = lane, s1 = 64 + lane;
     const uint32_t n0 = (bw[s0 >> 3] >> (4 * (s0 & 7))) & 15u;
@@ -236,7 +259,7 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
 // View[a][i] = view[a*view_ld + i] is the as-written (reference mode: a < view_kmax = width of the last hidden layer,
 // stride = width of the layer below) or the textbook (row a of W_out) operand.  Also emits, per sample, the scalar
 // delta and the action (gathered through `slots`) for the segmented output-layer gradient.
-__global__ __launch_bounds__(256) void td_delta_kernel(int n, const int32_t* __restrict__ slots,
+__global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
                                                        const int32_t* __restrict__ action_to, const float* __restrict__ reward,
                                                        const uint8_t* __restrict__ done, const float* __restrict__ a_last, int H,
                                                        const float* __restrict__ w_out, const float* __restrict__ b_out,
@@ -247,7 +270,7 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, const int32_t* __r
     const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int b = (int)blockIdx.x * 4 + wid;
     if (b >= n) return;
-    const int s = slots ? slots[b] : b;
+    const int s = slot_of(src, b);
     const int a = action_to[s];
     const bool live = a >= 0 && a < 96;
     float delta = 0.f, q = 0.f, y = 0.f;
@@ -488,14 +511,21 @@ static int launch_gemm(xq_dqn* d, GemmArgs g, int splits, const char* name, int*
     g.k_chunk = round_up((g.K + splits - 1) / splits, GBK);
     splits = (g.K + g.k_chunk - 1) / g.k_chunk;
     if (splits < 1) splits = 1;
-    const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * splits;
+    const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.grouped ? 2 : splits);
     const bool big = force_big || (!force_small && t128 >= 512);
     ProfScope ps(d, name, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    if (g.grouped) {
+        if (splits != 1) return fail(XQ_ERR_INVALID_ARGUMENT, "grouped GEMM cannot be split-K");
+        g.b_vec = g.b_vec && vec_ok(g.B2, g.ldb);
+        g.a_vec = g.a_vec && vec_ok(g.A2, g.lda);
+        ps.flops *= 2; ps.bytes *= 2;
+    }
+    const int gz = g.grouped ? 2 : splits;
     if (big) {
-        dim3 grid((g.M + 127) / 128, (g.N + 127) / 128, splits);
+        dim3 grid((g.M + 127) / 128, (g.N + 127) / 128, gz);
         hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI, 2, 2>), grid, dim3(256), 0, d->cur, g);
     } else {
-        dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, splits);
+        dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, gz);
         hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI, 1, 1>), grid, dim3(256), 0, d->cur, g);
     }
     XQ_HIP(hipGetLastError());
@@ -551,15 +581,25 @@ static int ensure_capacity(xq_dqn* d, int n) {
     return XQ_OK;
 }
 
-// a_1 .. a_{nl-1} for n packed boards; outs[l] receives a_{l+1}
-static int chain_boards(xq_dqn* d, int net, const uint32_t* boards, const int32_t* slots, int n, float* const* outs,
-                        uint32_t* gathered = nullptr) {
+static SlotSrc explicit_slots(const int32_t* slots) {
+    SlotSrc s; memset(&s, 0, sizeof s); s.slots = slots; return s;
+}
+
+// a_1 .. a_{nl-1} for n packed boards; outs[l] receives a_{l+1}.  With a second job (boards2/net2/outs2) both chains run
+// in the same launches: one gather grid with blockIdx.y = job, grouped GEMMs with blockIdx.z = job.
+static int chain_boards(xq_dqn* d, int net, const uint32_t* boards, SlotSrc src, int n, float* const* outs,
+                        uint32_t* gathered = nullptr, int net2 = -1, const uint32_t* boards2 = nullptr,
+                        float* const* outs2 = nullptr) {
     if (d->L[0] != kStateSize) return fail(XQ_ERR_INVALID_ARGUMENT, "board input needs layer_sizes[0] == 1260 (got %d)", d->L[0]);
+    const int jobs = net2 >= 0 ? 2 : 1;
     {
         const int H = d->L[1];
-        ProfScope ps(d, "l0_forward_gather", 2.0 * n * 32 * H, (double)n * (48 + 32.0 * H * 4 + H * 4));
-        hipLaunchKernelGGL(l0_forward_kernel, dim3((n + 3) / 4), dim3(256), 0, d->cur, boards, slots, n, d->w0t(net),
-                           d->bl(net, 0), H, outs[0], gathered);
+        L0Jobs J; memset(&J, 0, sizeof J);
+        J.njobs = jobs;
+        J.boards[0] = boards; J.W0T[0] = d->w0t(net); J.b0[0] = d->bl(net, 0); J.out[0] = outs[0]; J.gathered[0] = gathered;
+        if (jobs == 2) { J.boards[1] = boards2; J.W0T[1] = d->w0t(net2); J.b0[1] = d->bl(net2, 0); J.out[1] = outs2[0]; J.gathered[1] = nullptr; }
+        ProfScope ps(d, "l0_forward_gather", 2.0 * jobs * n * 32 * H, (double)jobs * n * (48 + 32.0 * H * 4 + H * 4));
+        hipLaunchKernelGGL(l0_forward_kernel, dim3((n + 3) / 4, jobs), dim3(256), 0, d->cur, J, src, n, H);
         XQ_HIP(hipGetLastError());
     }
     for (int l = 1; l + 1 < d->nl; ++l) {
@@ -569,6 +609,10 @@ static int chain_boards(xq_dqn* d, int net, const uint32_t* boards, const int32_
         g.B = d->wl(net, l); g.ldb = d->L[l];
         g.C = outs[l]; g.ldc = d->L[l + 1];
         g.bias = d->bl(net, l);
+        if (jobs == 2) {
+            g.grouped = 1;
+            g.A2 = outs2[l - 1]; g.B2 = d->wl(net2, l); g.C2 = outs2[l]; g.bias2 = d->bl(net2, l);
+        }
         XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH>(d, g, 1, "gemm_hidden_fwd")));
     }
     return XQ_OK;
@@ -591,7 +635,7 @@ int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev
     if (d->nout() < 96) return fail(XQ_ERR_INVALID_ARGUMENT, "self-play select needs >= 96 outputs");
     float* outs[XQ_MAX_LAYERS];
     for (int l = 0; l + 1 < d->nl; ++l) outs[l] = d->acts[l];
-    XQ_TRY(chain_boards(d, XQ_NET_ONLINE, boards_dev, nullptr, n, outs));
+    XQ_TRY(chain_boards(d, XQ_NET_ONLINE, boards_dev, explicit_slots(nullptr), n, outs));
     XQ_TRY(q_head(d, XQ_NET_ONLINE, outs[d->nl - 2], n, 96, d->q90, 96, "gemm_q90_select"));
     *q90_dev = d->q90;
     *q_stride = 96;
@@ -927,7 +971,7 @@ int xq_dqn_forward_boards_dev(xq_dqn* d, int net, const uint32_t* boards_dev, in
     XQ_TRY(ensure_capacity(d, n));
     float* outs[XQ_MAX_LAYERS];
     for (int l = 0; l + 1 < d->nl; ++l) outs[l] = d->acts[l];
-    XQ_TRY(chain_boards(d, net, boards_dev, nullptr, n, outs));
+    XQ_TRY(chain_boards(d, net, boards_dev, explicit_slots(nullptr), n, outs));
     return q_head(d, net, outs[d->nl - 2], n, n_out, q_dev, ldq, n_out <= 96 ? "gemm_q90_select" : "gemm_q_full");
 }
 
@@ -981,8 +1025,16 @@ int xq_dqn_backpropagate(xq_dqn* d, const double* states, const double* targets,
     return XQ_OK;
 }
 
+static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boards, const int32_t* action_to,
+                         const float* reward, const uint8_t* done, SlotSrc slots, int n, int td_net, int mode);
+
 int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boards, const int32_t* action_to,
                     const float* reward, const uint8_t* done, const int32_t* slots, int n, int td_net, int mode) {
+    return td_grads_impl(d, boards, next_boards, action_to, reward, done, explicit_slots(slots), n, td_net, mode);
+}
+
+static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boards, const int32_t* action_to,
+                         const float* reward, const uint8_t* done, SlotSrc slots, int n, int td_net, int mode) {
     if (!d || !boards || !next_boards || !action_to || !reward || !done || n <= 0)
         return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_td_grads: bad argument");
     if (td_net != XQ_TD_ONLINE_NET && td_net != XQ_TD_TARGET_NET) return fail(XQ_ERR_INVALID_ARGUMENT, "bad td_net");
@@ -991,23 +1043,12 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
     if (mode == XQ_BACKPROP_REFERENCE) XQ_TRY(check_reference_topology(d));
     XQ_TRY(ensure_capacity(d, n));
     const int nl = d->nl, Hl = d->hlast(), NO = d->nout();
-    // fork: the s chain (online net, activations kept) is independent of the s' chain + column-max GEMM — it runs on
-    // the side stream and fills the issue slots the MFMA-bound GEMM leaves idle
+    // 1. both forward chains in the same launches (one gather grid, grouped hidden GEMMs): s on the online net with the
+    //    activations kept for the backward pass, s' on the TD net
     float* outs[XQ_MAX_LAYERS];
-    for (int l = 0; l + 1 < nl; ++l) outs[l] = d->acts[l];
-    XQ_HIP(hipEventRecord(d->ev_fork, d->stream));
-    XQ_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
-    d->cur = d->side;
-    {
-        const int rc = chain_boards(d, XQ_NET_ONLINE, boards, slots, n, outs, d->gboards);
-        d->cur = d->stream;
-        if (rc != XQ_OK) return rc;
-    }
-    XQ_HIP(hipEventRecord(d->ev_join, d->side));
-    // 1. s' chain on the TD net, row max of the full output layer (never written to HBM)
     float* touts[XQ_MAX_LAYERS];
-    for (int l = 0; l + 1 < nl; ++l) touts[l] = d->tacts[l & 1];
-    XQ_TRY(chain_boards(d, td_net, next_boards, slots, n, touts));
+    for (int l = 0; l + 1 < nl; ++l) { outs[l] = d->acts[l]; touts[l] = d->tacts[l & 1]; }
+    XQ_TRY(chain_boards(d, XQ_NET_ONLINE, boards, slots, n, outs, d->gboards, td_net, next_boards, touts));
     // launched transposed (rows = output neurons, columns = samples): the max over the 8100 outputs then runs over
     // accumulator registers inside one lane instead of across the 32 lanes of a row
     const bool big_tiles = (long long)((NO + 127) / 128) * ((n + 127) / 128) >= 512;
@@ -1040,8 +1081,6 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
             XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_COLMAX>(d, g, 1, "gemm_qmax_rowmax")));
         }
     }
-    // 2. join the s chain
-    XQ_HIP(hipStreamWaitEvent(d->stream, d->ev_join, 0));
     // 3. Q(s, a), target, the scalar output delta and the delta of the last hidden layer (one launch, no GEMM)
     {
         const int lt = nl - 2;                               // last hidden layer
@@ -1129,16 +1168,22 @@ int xq_dqn_grad_buffer(xq_dqn* d, float** grads_dev, size_t* n_floats) {
 
 int xq_dqn_td_grads_replay(xq_dqn* d, xq_replay* r, int batch, int td_net, int mode) {
     if (!d || !r) return fail(XQ_ERR_INVALID_ARGUMENT, "null handle");
-    const int32_t* slots = nullptr;
+    SlotSrc src = explicit_slots(nullptr);
     if (batch > 0) {
-        if (r->last_batch != batch || !r->slots_dev) return fail(XQ_ERR_INVALID_ARGUMENT, "call xq_replay_sample(batch) first");
-        slots = r->slots_dev;
+        if (r->last_batch != batch) return fail(XQ_ERR_INVALID_ARGUMENT, "call xq_replay_sample(batch) first");
+        if (r->implicit) {                  // the trainer's virtual sample: slots recomputed inside the consumer kernels
+            src.implicit = 1; src.call = r->implicit_call; src.size = (uint32_t)r->implicit_size;
+            src.seed_lo = (uint32_t)r->seed; src.seed_hi = (uint32_t)(r->seed >> 32);
+        } else {
+            if (!r->slots_dev) return fail(XQ_ERR_INVALID_ARGUMENT, "call xq_replay_sample(batch) first");
+            src.slots = r->slots_dev;
+        }
     } else {
         batch = r->size;       // identity over the filled part of the ring (on-policy use)
     }
     if (batch <= 0) return fail(XQ_ERR_RUNTIME, "replay is empty");
-    return xq_dqn_td_grads(d, r->dev.boards, r->dev.next_boards, r->dev.action_to, r->dev.reward, r->dev.done, slots, batch,
-                           td_net, mode);
+    return td_grads_impl(d, r->dev.boards, r->dev.next_boards, r->dev.action_to, r->dev.reward, r->dev.done, src, batch, td_net,
+                         mode);
 }
 
 int xq_dqn_td_update_host(xq_dqn* d, int n, const uint8_t* boards90, const uint8_t* next_boards90, const int32_t* action_to,

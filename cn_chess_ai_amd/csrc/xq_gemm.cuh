@@ -46,6 +46,9 @@ struct GemmArgs {
     int k_chunk;                  // split-K: k range of blockIdx.z is [z*k_chunk, min(K,(z+1)*k_chunk))
     long long slab_stride;        // split-K: C of split z = C + z*slab_stride
     int a_vec, b_vec;             // 16-byte vector loads allowed (base and ld aligned)
+    // grouped launch (two independent products of the same shape in one grid, blockIdx.z = 0/1; no split-K then):
+    int grouped;
+    const float* A2; const float* B2; float* C2; const float* bias2;
     int prio_split;               // persistent kernel: blocks >= prio_split run at s_setprio 1 (0 = off) ...
     int prio_tiles;               // ... and own tiles [0, prio_tiles); the other blocks own [prio_tiles, total)
 };
@@ -260,8 +263,10 @@ __device__ __forceinline__ void epilogue_colmax(const GemmArgs& g, const f32x16 
 }
 
 template <int AL, int BL, int EPI, int TM, int TN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_f32_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_f32_kernel(const GemmArgs g_in) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
+    GemmArgs g = g_in;
+    if (g_in.grouped && blockIdx.z == 1) { g.A = g_in.A2; g.B = g_in.B2; g.C = g_in.C2; g.bias = g_in.bias2; }
     __shared__ __attribute__((aligned(16))) float As[g_tile_floats(BM)];
     __shared__ __attribute__((aligned(16))) float Bs[g_tile_floats(BN)];
 
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int r = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
     const int m0 = (int)blockIdx.x * BM, n0 = (int)blockIdx.y * BN;
-    const int kbeg = (int)blockIdx.z * g.k_chunk;
+    const int kbeg = g.grouped ? 0 : (int)blockIdx.z * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
 
     f32x16 acc[TM][TN];
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         epilogue_colmax<TM, TN>(g, acc, m0, n0, (int)blockIdx.x);
         return;
     }
-    float* Cz = g.C + (long long)blockIdx.z * g.slab_stride;
+    float* Cz = g.grouped ? g.C : g.C + (long long)blockIdx.z * g.slab_stride;
     if ((m0 + BM <= g.M) && (n0 + BN <= g.N)) {
         // tile fully inside the output: no per-element bounds logic, so the epilogue's loads (bias / activation for the
         // delta) are issued as one batch instead of a load + wait per row

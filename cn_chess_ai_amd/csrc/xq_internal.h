@@ -25,6 +25,9 @@ struct xq_replay {
     int32_t* slots_dev = nullptr;     // last sample()
     int slots_cap = 0;
     int last_batch = 0;
+    bool implicit = false;            // last sample() was "virtual": consumers derive slot i = philox(i, call) % size themselves
+    uint32_t implicit_call = 0;
+    int implicit_size = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
 };
@@ -103,6 +106,10 @@ struct Profiler {
 Profiler* dqn_profiler(xq_dqn* d);
 int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride);
 hipStream_t dqn_stream(xq_dqn* d);
+
+// "virtual" replay sample: same slots as xq_replay_sample would write (Philox ctr = {i, 0, call, 1}, key = seed, % size),
+// but no kernel and no slot buffer — the consumer kernels recompute them.  Used by the trainer's hot loop.
+int replay_sample_implicit(xq_replay* r, int batch);
 
 // env-side launchers used by the trainer
 int env_selfplay_launch(xq_env* env, const float* q90_dev, int q_stride, uint32_t eps_u32, xq_step_result* results_dev,

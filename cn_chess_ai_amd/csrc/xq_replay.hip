@@ -14,6 +14,17 @@ __global__ void replay_sample_kernel(int32_t* slots, int batch, int size, uint32
     slots[i] = (int32_t)(r.v[0] % (uint32_t)size);
 }
 
+int replay_sample_implicit(xq_replay* r, int batch) {
+    if (!r || batch <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "replay_sample_implicit: batch must be > 0");
+    if (r->size <= 0) return fail(XQ_ERR_RUNTIME, "xq_replay_sample: buffer is empty");
+    r->implicit = true;
+    r->implicit_call = (uint32_t)r->sample_calls;
+    r->implicit_size = r->size;
+    r->sample_calls++;
+    r->last_batch = batch;
+    return XQ_OK;
+}
+
 }  // namespace xq
 
 using namespace xq;
@@ -99,6 +110,7 @@ int xq_replay_sample(xq_replay* r, int batch, int32_t* slots_host) {
     XQ_HIP(hipGetLastError());
     r->sample_calls++;
     r->last_batch = batch;
+    r->implicit = false;
     if (slots_host) {
         XQ_HIP(hipMemcpyAsync(slots_host, r->slots_dev, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
         XQ_HIP(hipStreamSynchronize(r->stream));

@@ -88,7 +88,7 @@ int xq_trainer_learn_grads(xq_trainer* t) {
     int batch = 0;
     if (t->cfg.replay_capacity > 0) {
         batch = t->cfg.minibatch;
-        XQ_TRY(xq_replay_sample(t->replay, batch, nullptr));
+        XQ_TRY(replay_sample_implicit(t->replay, batch));     // no sampling kernel: the consumers recompute the slots
     }
     return xq_dqn_td_grads_replay(t->dqn, t->replay, batch, t->cfg.td_net, t->cfg.backprop_mode);
 }
