@@ -246,3 +246,58 @@ def test_replay_ring_receives_transitions(xq):
     assert slots[:10].tolist() == want
     rp.push(prev[:3], [5, 6, 7], [1.5, -2.0, 0.0], [0, 1, 0], nxt[:3])
     env.close(); rp.close()
+
+
+def test_side_without_any_action_ends_the_episode(xq):
+    """chessai.cpp:100-103: an empty action list breaks the loop.  Black (to move): general hemmed in by its own horses,
+    every horse leg blocked by a red piece -> no pseudo-legal move at all."""
+    b = np.zeros(90, dtype=np.uint8)
+    sq = lambda r, c: r * 9 + c
+    b[sq(0, 4)] = 1                                   # red general
+    b[sq(9, 4)] = 8                                   # black general
+    for r, c in ((9, 3), (9, 5), (8, 4)):
+        b[sq(r, c)] = 11                              # black horses
+    for r, c in ((9, 2), (8, 3), (9, 6), (8, 5), (7, 4)):
+        b[sq(r, c)] = 7                               # red soldiers on every leg square
+    ob = xo.board_from(b, 17, 1, 30, 40)
+    codes, n = xo.all_valid_actions(ob, 1)
+    assert n == 0
+    env = xq.VecEnv(2, seed=3)
+    env.set_state(np.stack([b, b]), np.array([[17, 1, 30, 40], [17, 0, 30, 40]], dtype=np.int32))
+    codes, counts = env.legal_moves(-1)
+    assert counts[0] == 0 and counts[1] > 0
+    res = env.selfplay_step(None)
+    o = xo.selfplay_step(ob, None, 3, 0, 0, 0)
+    assert (res[0]["action"], res[0]["n_moves"], res[0]["terminated"], res[0]["done"], res[0]["winner"]) == (-1, 0, 1, 1, 0)
+    assert (o.action_code, o.n_moves, o.terminated, o.done, o.winner) == (-1, 0, 1, 1, 0)
+    boards, meta = env.get_state()
+    assert np.array_equal(boards[0], xq.START_BOARD) and not meta[0].any()       # auto-reset
+    assert res[1]["action"] >= 0 and res[1]["terminated"] == 0
+    rec, total = env.drain_episodes()
+    assert total == 1 and rec[0]["reserved"] == 1 and rec[0]["move_count"] == 17
+    env.close()
+
+
+def test_replay_ring_wraps_and_skips_empty_transitions(xq):
+    n, cap = 48, 100                                   # capacity not a multiple of n: the write position wraps mid-batch
+    env = xq.VecEnv(n, seed=21)
+    rp = xq.ReplayBuffer(cap, seed=1)
+    snaps = []
+    for t in range(5):
+        prev, _ = env.get_state()
+        env.selfplay_step_dev(replay=rp)
+        nxt, _ = env.get_state()
+        snaps.append((prev, nxt))
+    size, capacity, total = rp.stats()
+    assert (size, capacity, total) == (cap, cap, 5 * n)
+    # transition g of step t sits in slot (t*n + g) % cap unless a later step overwrote it
+    for t, g in ((4, 0), (4, 47), (3, 10), (2, 40)):
+        slot = (t * n + g) % cap
+        later = [(tt, gg) for tt in range(t + 1, 5) for gg in range(n) if (tt * n + gg) % cap == slot]
+        if later:
+            continue
+        bd, a, r, d, nb = rp.get(slot)
+        assert np.array_equal(bd, snaps[t][0][g]) and 0 <= a < 90
+        if not d:
+            assert np.array_equal(nb, snaps[t][1][g])
+    env.close(); rp.close()
