@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with HIP events (diagnostic)")
     ap.add_argument("--games", type=int, default=N_GAMES, help="games per GPU (default = BASELINE's 8192; other values are diagnostic)")
     ap.add_argument("--minibatch", type=int, default=0, help="transitions per update (default = games per GPU)")
+    ap.add_argument("--check-replicas", action="store_true",
+                    help="N > 1: assert that every rank ends with bit-identical parameters (diagnostic)")
     ap.add_argument("--env-only", action="store_true",
                     help="diagnostic: time only the fused self-play kernel with the uniform-random policy (no Q-network)")
     args = ap.parse_args()
@@ -134,9 +136,13 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available() or _capi.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    _capi.call("xq_set_device", local_rank)
-    xd.init_process_group("nccl" if world > 1 else None)
+    # rehearsal hooks (one-GPU box only): XQ_FORCE_DEVICE pins every rank to one device, XQ_DIST_BACKEND=gloo replaces RCCL —
+    # lets the N > 1 code path (sharding, zero-copy gradient view, all-reduce per update, barriers) run on a single GPU
+    device = int(os.environ.get("XQ_FORCE_DEVICE", local_rank))
+    backend = os.environ.get("XQ_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(device)
+    _capi.call("xq_set_device", device)
+    xd.init_process_group(backend if world > 1 else None)
     # library kernels and RCCL share ONE torch stream (a real stream object: the legacy default stream has handle 0,
     # which the C ABI reads as "create your own")
     tstream = torch.cuda.Stream()
@@ -181,6 +187,17 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = xd.max_over_ranks(elapsed, device="cuda" if world > 1 else "cpu")
     stats = {s["name"]: s for s in t.dqn.kernel_stats(enable=0)}
+    if args.check_replicas and world > 1:
+        import numpy as np
+        w, b = t.dqn.get_params()
+        digest = torch.tensor([float(np.abs(w).sum()), float(np.abs(b).sum()), float(w[::997].sum())], dtype=torch.float64,
+                              device="cuda")
+        lo, hi = digest.clone(), digest.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), f"replicas diverged: {lo.tolist()} vs {hi.tolist()}"
+        if rank == 0:
+            print(f"replicas identical on {world} ranks: {digest.tolist()}", file=sys.stderr)
 
     if rank == 0:
         env_steps = world * n_games * args.steps

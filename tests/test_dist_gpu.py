@@ -37,3 +37,26 @@ def test_gradient_buffer_is_visible_to_torch_zero_copy():
     assert np.array_equal(w1, w2) and np.array_equal(b1, b2) and not np.array_equal(w1, w0)
     t.close(); t2.close()
     torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_two_rank_rehearsal_on_one_gpu():
+    """The whole N > 1 path of bench.py (game sharding, zero-copy gradient view, all-reduce per update, barriers, max-over-
+    ranks timing) with two ranks pinned to the one GPU of the box and gloo standing in for RCCL; the replicas must end
+    with bit-identical parameters."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, XQ_FORCE_DEVICE="0", XQ_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--check-replicas"],
+                         capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "replicas identical on 2 ranks" in out.stderr
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["parallelism"].startswith("dp2")
