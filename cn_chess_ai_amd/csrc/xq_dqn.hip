@@ -42,7 +42,6 @@ struct xq_dqn {
     float* acts[XQ_MAX_LAYERS] = {nullptr};     // online hidden activations a_{l+1} = tanh(z_l), l = 0..nl-2
     float* tacts[2] = {nullptr, nullptr};       // ping-pong chain for s' / inference
     float* deltas[XQ_MAX_LAYERS] = {nullptr};   // delta_l of hidden layer l
-    float* d2 = nullptr;                        // [cap][96] dense output delta (kept for diagnostics; TD path is sparse)
     float* dsc = nullptr;                       // [cap] the one non-zero output delta of each TD sample
     int32_t* act_mb = nullptr;                  // [cap] action.to of each TD sample (gathered), -1 = empty slot
     float* q90 = nullptr;                       // [cap][96]
@@ -569,9 +568,9 @@ static int ensure_capacity(xq_dqn* d, int n) {
         XQ_HIP(hipMemsetAsync(d->tacts[i], 0, rows * (size_t)maxh * sizeof(float), d->stream));
     }
     const int ntn = (d->nout() + 63) / 64;             // column-max partials: 2 per 64- or 128-row tile
-    float** bufs[] = {&d->d2, &d->q90, &d->partial, &d->qsa, &d->yv, &d->lossv, &d->dsc, reinterpret_cast<float**>(&d->act_mb)};
-    const size_t sizes[] = {cap * 96, cap * 96, cap * (size_t)ntn * 2, cap, cap, cap, cap, cap};
-    for (int i = 0; i < 8; ++i) {
+    float** bufs[] = {&d->q90, &d->partial, &d->qsa, &d->yv, &d->lossv, &d->dsc, reinterpret_cast<float**>(&d->act_mb)};
+    const size_t sizes[] = {cap * 96, cap * (size_t)ntn * 2, cap, cap, cap, cap, cap};
+    for (int i = 0; i < 7; ++i) {
         if (*bufs[i]) XQ_HIP(hipFree(*bufs[i]));
         XQ_HIP(hipMalloc(bufs[i], sizes[i] * sizeof(float)));
     }
@@ -863,7 +862,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     hipStreamSynchronize(d->stream);
     for (int i = 0; i < 2; ++i) { hipFree(d->params[i]); hipFree(d->tacts[i]); }
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts[l]); hipFree(d->deltas[l]); }
-    hipFree(d->gboards); hipFree(d->dsc); hipFree(d->act_mb); hipFree(d->d2); hipFree(d->q90); hipFree(d->partial); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
+    hipFree(d->gboards); hipFree(d->dsc); hipFree(d->act_mb); hipFree(d->q90); hipFree(d->partial); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
     hipFree(d->grads_td); hipFree(d->grads_full); hipFree(d->slabs); hipFree(d->bias_work); hipFree(d->xdense); hipFree(d->qfull); hipFree(d->tfull);
     hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
     d->prof.collect();
