@@ -49,6 +49,7 @@ struct GemmArgs {
     // grouped launch (two independent products of the same shape in one grid, blockIdx.z = 0/1; no split-K then):
     int grouped;
     const float* A2; const float* B2; float* C2; const float* bias2;
+    int bias_padded;              // EPI_COLMAX: bias[] is 16-byte aligned and readable up to the last tile's edge
     int prio_split;               // persistent kernel: blocks >= prio_split run at s_setprio 1 (0 = off) ...
     int prio_tiles;               // ... and own tiles [0, prio_tiles); the other blocks own [prio_tiles, total)
 };
@@ -232,28 +233,34 @@ __device__ __forceinline__ void epilogue_colmax(const GemmArgs& g, const f32x16 
     const int r = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
     const float NEG = -__builtin_inff();
-    // all bias values of this lane's rows in ONE batch of loads (clamped index, masked by select): a branch per row
-    // compiles to 32 serialised load + wait pairs
-    float bm[TM][16];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int m = m0 + wm * 32 * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            bm[i][q] = g.bias[m < g.M ? m : g.M - 1];
-        }
     float cm[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) cm[j] = NEG;
+    // The 16 rows a lane holds of one 32x32 tile are four runs of 4 consecutive rows (reg 4g..4g+3 -> row 8g + 4h + 0..3):
+    // their biases come as four 16-byte loads per tile, issued together (a branch per row compiles to 32 serialised
+    // load + wait pairs; one wide batch keeps the register footprint of the epilogue small).  Rows >= M are masked by
+    // select; when `bias_padded` the bias array is readable up to the tile edge (caller pads), else indices are clamped.
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * 32 * TM + i * 32 + 4 * h;
+        float bm[16];
+        if (g.bias_padded) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 x = *reinterpret_cast<const float4*>(g.bias + mb + 8 * gq);
+                bm[4 * gq] = x.x; bm[4 * gq + 1] = x.y; bm[4 * gq + 2] = x.z; bm[4 * gq + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const int m = mb + (q & 3) + 8 * (q >> 2); bm[q] = g.bias[m < g.M ? m : g.M - 1]; }
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int m = m0 + wm * 32 * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            const bool ok = m < g.M;
+            const bool ok = mb + (q & 3) + 8 * (q >> 2) < g.M;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) cm[j] = fmaxf(cm[j], ok ? acc[i][j][q] + bm[i][q] : NEG);
+            for (int j = 0; j < TN; ++j) cm[j] = fmaxf(cm[j], ok ? acc[i][j][q] + bm[q] : NEG);
         }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const float v = fmaxf(cm[j], __shfl_xor(cm[j], 32, 64));      // the other 4-row groups live in the other half-wave
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // the current one.  Requires K % 32 == 0, 16-byte aligned operands, and both operands readable up to the next multiple of
 // 128 rows (the callers pad their allocations); rows/columns beyond M/N are masked in the epilogue.
 template <int TM, int TN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_colmax_persistent_kernel(const GemmArgs g,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_colmax_persistent_kernel(const GemmArgs g,
                                                                                                         int tiles_m, int total) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     __shared__ __attribute__((aligned(16))) float As[g_tile_floats(BM)];

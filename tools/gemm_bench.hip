@@ -19,20 +19,91 @@ float run(GemmArgs g, int iters) {
     return ms / iters;
 }
 
+
+// probes: how fast can the MFMA pipe run with (0) registers only, (1) + the LDS fragment reads of tile_mma, (2) + one
+// barrier per k-step, (3) + LDS restaging from registers between two barriers, (4) + global loads of the next tile
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void mfma_probe_kernel(float* out, int iters, GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[g_tile_floats(128)];
+    __shared__ __attribute__((aligned(16))) float Bs[g_tile_floats(128)];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < g_tile_floats(128); i += 256) { As[i] = 0.001f * (i % 97); Bs[i] = 0.002f * (i % 89); }
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    if (MODE == 0) {
+        float a = 0.5f + lane, b = 0.25f;
+        for (int it = 0; it < iters * 16; ++it) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+        }
+    } else if (MODE <= 2) {
+        for (int it = 0; it < iters; ++it) {
+            tile_mma<L_KCONTIG, L_KCONTIG, 128, 128, 2, 2>(As, Bs, wid >> 1, wid & 1, r, h, acc);
+            if (MODE == 2) __syncthreads();
+        }
+    } else {
+        float4 va[4], vb[4];
+        const int tm = blockIdx.x % 64, tn = (blockIdx.x / 64) % 64;
+        stage_load<L_KCONTIG, 128, true>(g, g.A, g.lda, 1, tm * 128, g.M, 0, g.K, va);
+        stage_load<L_KCONTIG, 128, true>(g, g.B, g.ldb, 1, tn * 128, g.N, 0, g.K, vb);
+        for (int it = 0; it < iters; ++it) {
+            __syncthreads();
+            stage_store<L_KCONTIG, 128>(As, va);
+            stage_store<L_KCONTIG, 128>(Bs, vb);
+            __syncthreads();
+            if (MODE >= 4) {
+                const int k0 = ((it + 1) & 7) * 32;
+                stage_load<L_KCONTIG, 128, true>(g, g.A, g.lda, 1, tm * 128, g.M, k0, g.K, va);
+                stage_load<L_KCONTIG, 128, true>(g, g.B, g.ldb, 1, ((tn + (it >> 3)) & 63) * 128, g.N, k0, g.K, vb);
+            }
+            tile_mma<L_KCONTIG, L_KCONTIG, 128, 128, 2, 2>(As, Bs, wid >> 1, wid & 1, r, h, acc);
+            if (MODE == 5 && (it & 7) == 7) {
+                epilogue_colmax<2, 2>(g, acc, tm * 128, ((tn + (it >> 3)) & 63) * 128, tm);
+                for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+            }
+        }
+    }
+    float s = 0; for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 16; ++q) s += acc[i][j][q];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
 int main(int argc, char** argv) {
     const int M = 8100, N = argc > 1 ? atoi(argv[1]) : 8192, K = argc > 2 ? atoi(argv[2]) : 256;
     float *A, *B, *C, *bias, *partial;
     CK(hipMalloc(&A, (size_t)(M + 128) * K * 4)); CK(hipMalloc(&B, (size_t)(N + 128) * K * 4)); CK(hipMalloc(&C, (size_t)M * N * 4));
-    CK(hipMalloc(&bias, (size_t)M * 4)); CK(hipMalloc(&partial, (size_t)N * 2 * ((M + 63) / 64) * 4));
+    CK(hipMalloc(&bias, (size_t)(M + 256) * 4)); CK(hipMalloc(&partial, (size_t)N * 2 * ((M + 63) / 64) * 4));
     std::vector<float> h((size_t)std::max(M, N) * K);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
     CK(hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice));
-    CK(hipMemset(bias, 0, (size_t)M * 4));
+    CK(hipMemset(bias, 0, (size_t)(M + 256) * 4));
     GemmArgs g; memset(&g, 0, sizeof g);
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = K; g.B = B; g.ldb = K; g.C = C; g.ldc = N; g.bias = bias; g.partial = partial;
-    g.k_chunk = K; g.a_vec = 1; g.b_vec = 1;
+    g.k_chunk = K; g.a_vec = 1; g.b_vec = 1; g.bias_padded = 1;
     const double fl = 2.0 * M * N * K;
+    {
+        float* o; CK(hipMalloc(&o, 1024 * 256 * 4));
+        const int iters = 512;                          // k-steps per block; each = 64 MFMAs per wave
+        for (int mode = 3; mode < 6; ++mode) for (int grid : {512}) {
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            auto launch = [&]() {
+                if (mode == 0) hipLaunchKernelGGL((mfma_probe_kernel<0>), dim3(grid), dim3(256), 0, 0, o, iters, g);
+                else if (mode == 1) hipLaunchKernelGGL((mfma_probe_kernel<1>), dim3(grid), dim3(256), 0, 0, o, iters, g);
+                else if (mode == 2) hipLaunchKernelGGL((mfma_probe_kernel<2>), dim3(grid), dim3(256), 0, 0, o, iters, g);
+                else if (mode == 3) hipLaunchKernelGGL((mfma_probe_kernel<3>), dim3(grid), dim3(256), 0, 0, o, iters, g);
+                else if (mode == 4) hipLaunchKernelGGL((mfma_probe_kernel<4>), dim3(grid), dim3(256), 0, 0, o, iters, g);
+                else hipLaunchKernelGGL((mfma_probe_kernel<5>), dim3(grid), dim3(256), 0, 0, o, iters, g);
+            };
+            launch(); hipEventRecord(a, 0); launch(); launch(); hipEventRecord(b, 0); hipEventSynchronize(b);
+            float ms = 0; hipEventElapsedTime(&ms, a, b); ms /= 2;
+            const double f = (double)grid * 4 * iters * 64 * 4096.0;
+            printf("probe mode %d (0 regs, 1 +frag reads, 2 +barrier, 3 +LDS restage & 2 barriers, 4 +global loads) grid %d: %7.1f TF/s\n", mode, grid, f / ms / 1e9);
+        }
+
+    }
     {
         float t = run<EPI_COLMAX, 2, 2>(g, 20);
         printf("colmax 128x128          : %8.1f us  %6.1f TF/s\n", t * 1e3, fl / t / 1e9);
@@ -54,6 +125,7 @@ int main(int argc, char** argv) {
         printf("persistent prio share %2d%%: avg %8.1f us (%6.1f TF/s)  best %8.1f us\n", pct, sum / 20 * 1e3, fl / (sum / 20) / 1e9, best * 1e3);
     }
     g.prio_split = 256; g.prio_tiles = (int)(4096LL * 60 / 100) / 64 * 64;
+    g.prio_split = 256; g.prio_tiles = 2048;
     // check: persistent == plain
     {
         std::vector<float> p0((size_t)N * 2 * ((M + 127) / 128)), p1(p0.size());
