@@ -123,6 +123,8 @@ def main():
                     help="N > 1: assert that every rank ends with bit-identical parameters (diagnostic)")
     ap.add_argument("--env-only", action="store_true",
                     help="diagnostic: time only the fused self-play kernel with the uniform-random policy (no Q-network)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="queue collect and learn on one stream (collect -> learn -> apply) instead of running collect beside learn_grads")
     args = ap.parse_args()
 
     import torch
@@ -158,7 +160,7 @@ def main():
     cfg = xq.TrainerConfig(n_games=n_games, layer_sizes=LAYERS, learning_rate=0.001, gamma=0.99, epsilon=0.1,
                            replay_capacity=max(REPLAY, n_games), minibatch=minibatch, td_net=_capi.TD_TARGET_NET,
                            backprop_mode=_capi.BACKPROP_REFERENCE, target_sync_interval=100, mean_gradient=1,
-                           seed=0x5EED, first_game_id=first)
+                           seed=0x5EED, first_game_id=first, overlap_collect=0 if args.no_overlap else 1)
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
     grads = None
     if world > 1:
@@ -187,6 +189,15 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = xd.max_over_ranks(elapsed, device="cuda" if world > 1 else "cpu")
     stats = {s["name"]: s for s in t.dqn.kernel_stats(enable=0)}
+    iso = {}
+    if not args.no_overlap and world == 1:
+        # the same two kernels with nothing beside them (device-wide sync between collect and learn), outside the timed region:
+        # in the overlapped loop the env kernel shares the chip with the TD step, so its live duration is not its own
+        t.dqn.kernel_stats(enable=3)
+        for _ in range(10):
+            t.collect(); torch.cuda.synchronize()
+            t.learn_grads(); t.learn_apply(world); torch.cuda.synchronize()
+        iso = {s["name"]: s for s in t.dqn.kernel_stats(enable=0)}
     if args.check_replicas and world > 1:
         import numpy as np
         w, b = t.dqn.get_params()
@@ -212,6 +223,9 @@ def main():
                                    "replay 1M transitions, minibatch 8192, one update per ply",
                        "games_per_gpu": n_games, "layer_sizes": list(LAYERS), "replay_capacity": max(REPLAY, n_games),
                        "minibatch": minibatch, "epsilon": 0.1, "td_net": "target", "backprop": "reference-compatible",
+                       "schedule": "collect -> learn -> apply on one stream" if args.no_overlap else
+                                   "collect(t) on its own stream beside learn_grads(t), both on theta_t; minibatch from the ring minus "
+                                   "the slots collect(t) writes; apply joins both",
                        "parallelism": f"dp{world} (games sharded, gradient all-reduce per update)" if world > 1 else "1 GPU"},
         }
         g = stats.get("gemm_qmax_rowmax")
@@ -224,6 +238,10 @@ def main():
                                 "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                 "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, offline)",
                                 "traffic_source": src, "avg_launch_ms": ms, "flops_per_launch": fl, "launches": g["launches"]}
+            gi = iso.get("gemm_qmax_rowmax")
+            if gi and gi["launches"]:
+                line["roofline"]["isolated_avg_launch_ms"] = gi["ms"] / gi["launches"]
+                line["roofline"]["isolated_frac"] = fl / (gi["ms"] / gi["launches"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
         e = stats.get("env_selfplay_step")
         if e and e["launches"]:
             ms = e["ms"] / e["launches"]
@@ -233,6 +251,11 @@ def main():
                                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("env_kernel<2>")[0], "avg_launch_ms": ms,
                                     "bytes_per_launch": by, "launches": e["launches"]}
+            ei = iso.get("env_selfplay_step")
+            if ei and ei["launches"]:
+                line["roofline_env"]["co_scheduled"] = "runs on its own stream beside the TD step; avg_launch_ms is its stretched live duration"
+                line["roofline_env"]["isolated_avg_launch_ms"] = ei["ms"] / ei["launches"]
+                line["roofline_env"]["isolated_achieved"] = by / (ei["ms"] / ei["launches"] * 1e-3) / 1e9
         if args.profile_all:
             line["kernels"] = {k: {"ms_per_launch": v["ms"] / max(v["launches"], 1), "launches": v["launches"]}
                                for k, v in stats.items()}

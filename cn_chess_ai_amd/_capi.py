@@ -49,7 +49,7 @@ class TrainerConfig(C.Structure):
                 ("learning_rate", C.c_double), ("gamma", C.c_double), ("epsilon", C.c_double),
                 ("replay_capacity", C.c_int), ("minibatch", C.c_int), ("td_net", C.c_int), ("backprop_mode", C.c_int),
                 ("target_sync_interval", C.c_int), ("mean_gradient", C.c_int), ("seed", C.c_uint64),
-                ("first_game_id", C.c_uint32), ("collects_per_update", C.c_int)]
+                ("first_game_id", C.c_uint32), ("collects_per_update", C.c_int), ("overlap_collect", C.c_int)]
 
 
 assert C.sizeof(StepResult) == 24 and C.sizeof(EpisodeRecord) == 16
@@ -92,6 +92,7 @@ PROTOTYPES = {
     "xq_replay_size": [_vp, _pi, _pi, _pu64],
     "xq_replay_push_host": [_vp, _i, _pu8, _pi, _pf, _pu8, _pu8],
     "xq_replay_sample": [_vp, _i, _pi],
+    "xq_replay_sample_window": [_vp, _i, _i, _i, _pi],
     "xq_replay_get": [_vp, _i, _pu8, _pi, _pf, _pu8, _pu8],
     "xq_dqn_create": [_pi, _i, _d, _d, _u64, _vp, _pvp],
     "xq_dqn_destroy": [_vp],

@@ -45,6 +45,11 @@ struct xq_dqn {
     float* dsc = nullptr;                       // [cap] the one non-zero output delta of each TD sample
     int32_t* act_mb = nullptr;                  // [cap] action.to of each TD sample (gathered), -1 = empty slot
     float* q90 = nullptr;                       // [cap][96]
+    // second workspace for the action-select chain, so that it can run on its own stream beside a TD step
+    float* sel_acts[XQ_MAX_LAYERS] = {nullptr};
+    float* sel_q90 = nullptr;
+    int sel_cap = 0;
+    bool small_tiles = false;                   // force 64x64 GEMM tiles (<= 80 VGPRs: fits beside the persistent GEMM)
     float* partial = nullptr;                   // row-max partials
     float* qsa = nullptr;
     float* yv = nullptr;
@@ -90,13 +95,18 @@ struct ProfScope {
 // ---------------------------------------------------------------------------------------------------------------
 
 // where sample b of a minibatch lives: identity, an explicit slot list, or the replay sampler's Philox stream recomputed
-// in place (ctr = {b, 0, call, 1}, key = seed, % size — identical to replay_sample_kernel)
+// in place (ctr = {b, 0, call, 1}, key = seed, % size — identical to replay_sample_kernel).  A windowed sample draws from the
+// `size` ring slots that start at `start` (the overlapped trainer excludes the slots a concurrent collect is writing).
 struct SlotSrc {
     const int32_t* slots;
-    uint32_t implicit, call, seed_lo, seed_hi, size;
+    uint32_t implicit, call, seed_lo, seed_hi, size, start, cap;
 };
 __device__ __forceinline__ int slot_of(const SlotSrc& s, int b) {
-    if (s.implicit) return (int)(philox4x32_10((uint32_t)b, 0u, s.call, 1u, s.seed_lo, s.seed_hi).v[0] % s.size);
+    if (s.implicit) {
+        uint32_t v = s.start + philox4x32_10((uint32_t)b, 0u, s.call, 1u, s.seed_lo, s.seed_hi).v[0] % s.size;
+        if (v >= s.cap) v -= s.cap;
+        return (int)v;
+    }
     return s.slots ? s.slots[b] : b;
 }
 // the two forward chains of a TD step (s on the online net, s' on the TD net) share one launch per layer
@@ -511,7 +521,7 @@ static int launch_gemm(xq_dqn* d, GemmArgs g, int splits, const char* name, int*
     splits = (g.K + g.k_chunk - 1) / g.k_chunk;
     if (splits < 1) splits = 1;
     const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.grouped ? 2 : splits);
-    const bool big = force_big || (!force_small && t128 >= 512);
+    const bool big = force_big || (!force_small && !d->small_tiles && t128 >= 512);
     ProfScope ps(d, name, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
     if (g.grouped) {
         if (splits != 1) return fail(XQ_ERR_INVALID_ARGUMENT, "grouped GEMM cannot be split-K");
@@ -629,14 +639,42 @@ static int q_head(xq_dqn* d, int net, const float* a_last, int n, int n_out, flo
     return XQ_OK;
 }
 
-int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride) {
-    XQ_TRY(ensure_capacity(d, n));
+static int ensure_select_capacity(xq_dqn* d, int n) {
+    if (n <= d->sel_cap) return XQ_OK;
+    XQ_HIP(hipDeviceSynchronize());
+    for (int l = 0; l + 1 < d->nl; ++l) {
+        if (d->sel_acts[l]) XQ_HIP(hipFree(d->sel_acts[l]));
+        XQ_HIP(hipMalloc(&d->sel_acts[l], (size_t)n * d->L[l + 1] * sizeof(float)));
+    }
+    if (d->sel_q90) XQ_HIP(hipFree(d->sel_q90));
+    XQ_HIP(hipMalloc(&d->sel_q90, (size_t)n * 96 * sizeof(float)));
+    d->sel_cap = n;
+    return XQ_OK;
+}
+
+// Q(s)[0..95] of n packed boards on the online net.  `on` != nullptr queues the chain on that stream with its own
+// workspace and 64x64 tiles, so it can run concurrently with a TD step queued on the handle's stream.
+int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride, hipStream_t on) {
     if (d->nout() < 96) return fail(XQ_ERR_INVALID_ARGUMENT, "self-play select needs >= 96 outputs");
     float* outs[XQ_MAX_LAYERS];
-    for (int l = 0; l + 1 < d->nl; ++l) outs[l] = d->acts[l];
-    XQ_TRY(chain_boards(d, XQ_NET_ONLINE, boards_dev, explicit_slots(nullptr), n, outs));
-    XQ_TRY(q_head(d, XQ_NET_ONLINE, outs[d->nl - 2], n, 96, d->q90, 96, "gemm_q90_select"));
-    *q90_dev = d->q90;
+    float* q = nullptr;
+    if (on) {
+        XQ_TRY(ensure_select_capacity(d, n));
+        for (int l = 0; l + 1 < d->nl; ++l) outs[l] = d->sel_acts[l];
+        q = d->sel_q90;
+        d->cur = on;
+        d->small_tiles = true;
+    } else {
+        XQ_TRY(ensure_capacity(d, n));
+        for (int l = 0; l + 1 < d->nl; ++l) outs[l] = d->acts[l];
+        q = d->q90;
+    }
+    int rc = chain_boards(d, XQ_NET_ONLINE, boards_dev, explicit_slots(nullptr), n, outs);
+    if (rc == XQ_OK) rc = q_head(d, XQ_NET_ONLINE, outs[d->nl - 2], n, 96, q, 96, "gemm_q90_select");
+    d->cur = d->stream;
+    d->small_tiles = false;
+    XQ_TRY(rc);
+    *q90_dev = q;
     *q_stride = 96;
     return XQ_OK;
 }
@@ -861,8 +899,8 @@ int xq_dqn_destroy(xq_dqn* d) {
     if (!d) return XQ_OK;
     hipStreamSynchronize(d->stream);
     for (int i = 0; i < 2; ++i) { hipFree(d->params[i]); hipFree(d->tacts[i]); }
-    for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts[l]); hipFree(d->deltas[l]); }
-    hipFree(d->gboards); hipFree(d->dsc); hipFree(d->act_mb); hipFree(d->q90); hipFree(d->partial); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
+    for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts[l]); hipFree(d->deltas[l]); hipFree(d->sel_acts[l]); }
+    hipFree(d->gboards); hipFree(d->dsc); hipFree(d->act_mb); hipFree(d->q90); hipFree(d->sel_q90); hipFree(d->partial); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
     hipFree(d->grads_td); hipFree(d->grads_full); hipFree(d->slabs); hipFree(d->bias_work); hipFree(d->xdense); hipFree(d->qfull); hipFree(d->tfull);
     hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
     d->prof.collect();
@@ -1173,6 +1211,7 @@ int xq_dqn_td_grads_replay(xq_dqn* d, xq_replay* r, int batch, int td_net, int m
         if (r->last_batch != batch) return fail(XQ_ERR_INVALID_ARGUMENT, "call xq_replay_sample(batch) first");
         if (r->implicit) {                  // the trainer's virtual sample: slots recomputed inside the consumer kernels
             src.implicit = 1; src.call = r->implicit_call; src.size = (uint32_t)r->implicit_size;
+            src.start = (uint32_t)r->implicit_start; src.cap = (uint32_t)r->dev.capacity;
             src.seed_lo = (uint32_t)r->seed; src.seed_hi = (uint32_t)(r->seed >> 32);
         } else {
             if (!r->slots_dev) return fail(XQ_ERR_INVALID_ARGUMENT, "call xq_replay_sample(batch) first");

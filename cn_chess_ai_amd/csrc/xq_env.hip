@@ -289,7 +289,7 @@ static EnvParams base_params(xq_env* e) {
 }
 
 int env_selfplay_launch(xq_env* e, const float* q90_dev, int q_stride, uint32_t eps_u32, xq_step_result* results_dev,
-                        xq_replay* replay) {
+                        xq_replay* replay, hipStream_t on) {
     EnvParams P = base_params(e);
     P.q90 = q90_dev;
     P.q_stride = q_stride;
@@ -302,7 +302,7 @@ int env_selfplay_launch(xq_env* e, const float* q90_dev, int q_stride, uint32_t 
         P.rp_write_base = replay->write_pos;
     }
     const int blocks = (e->n + 3) / 4;
-    hipLaunchKernelGGL(env_kernel<MODE_SELFPLAY>, dim3(blocks), dim3(256), 0, e->stream, P);
+    hipLaunchKernelGGL(env_kernel<MODE_SELFPLAY>, dim3(blocks), dim3(256), 0, on ? on : e->stream, P);
     XQ_HIP(hipGetLastError());
     if (replay != nullptr) {
         replay->write_pos = (replay->write_pos + e->n) % replay->dev.capacity;

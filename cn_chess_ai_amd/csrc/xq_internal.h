@@ -28,6 +28,7 @@ struct xq_replay {
     bool implicit = false;            // last sample() was "virtual": consumers derive slot i = philox(i, call) % size themselves
     uint32_t implicit_call = 0;
     int implicit_size = 0;
+    int implicit_start = 0;           // windowed sample: slot = (start + philox % size) % capacity
     hipStream_t stream = nullptr;
     bool own_stream = false;
 };
@@ -104,15 +105,16 @@ struct Profiler {
 
 // dqn-side entry points used by the trainer (defined in xq_dqn.hip)
 Profiler* dqn_profiler(xq_dqn* d);
-int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride);
+int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride, hipStream_t on = nullptr);
 hipStream_t dqn_stream(xq_dqn* d);
 
 // "virtual" replay sample: same slots as xq_replay_sample would write (Philox ctr = {i, 0, call, 1}, key = seed, % size),
 // but no kernel and no slot buffer — the consumer kernels recompute them.  Used by the trainer's hot loop.
-int replay_sample_implicit(xq_replay* r, int batch);
+// (start, count) restricts the draw to `count` ring slots from `start` (count < 0: the whole filled part).
+int replay_sample_implicit(xq_replay* r, int batch, int start = 0, int count = -1);
 
 // env-side launchers used by the trainer
 int env_selfplay_launch(xq_env* env, const float* q90_dev, int q_stride, uint32_t eps_u32, xq_step_result* results_dev,
-                        xq_replay* replay);
+                        xq_replay* replay, hipStream_t on = nullptr);
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 }  // namespace xq

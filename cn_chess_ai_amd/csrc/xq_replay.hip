@@ -7,19 +7,25 @@
 
 namespace xq {
 
-__global__ void replay_sample_kernel(int32_t* slots, int batch, int size, uint32_t call, uint32_t seed_lo, uint32_t seed_hi) {
+__global__ void replay_sample_kernel(int32_t* slots, int batch, uint32_t start, uint32_t size, uint32_t cap, uint32_t call,
+                                     uint32_t seed_lo, uint32_t seed_hi) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= batch) return;
     const Philox4 r = philox4x32_10((uint32_t)i, 0u, call, 1u, seed_lo, seed_hi);
-    slots[i] = (int32_t)(r.v[0] % (uint32_t)size);
+    uint32_t v = start + r.v[0] % size;
+    if (v >= cap) v -= cap;
+    slots[i] = (int32_t)v;
 }
 
-int replay_sample_implicit(xq_replay* r, int batch) {
+int replay_sample_implicit(xq_replay* r, int batch, int start, int count) {
     if (!r || batch <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "replay_sample_implicit: batch must be > 0");
-    if (r->size <= 0) return fail(XQ_ERR_RUNTIME, "xq_replay_sample: buffer is empty");
+    if (count < 0) { start = 0; count = r->size; }
+    if (count <= 0 || count > r->size || start < 0 || start >= r->dev.capacity)
+        return fail(XQ_ERR_RUNTIME, "xq_replay_sample: buffer is empty");
     r->implicit = true;
     r->implicit_call = (uint32_t)r->sample_calls;
-    r->implicit_size = r->size;
+    r->implicit_size = count;
+    r->implicit_start = start;
     r->sample_calls++;
     r->last_batch = batch;
     return XQ_OK;
@@ -98,15 +104,22 @@ int xq_replay_push_host(xq_replay* r, int n, const uint8_t* boards90, const int3
 }
 
 int xq_replay_sample(xq_replay* r, int batch, int32_t* slots_host) {
+    if (!r) return fail(XQ_ERR_INVALID_ARGUMENT, "null replay");
+    return xq_replay_sample_window(r, batch, 0, r->size, slots_host);
+}
+
+int xq_replay_sample_window(xq_replay* r, int batch, int start, int count, int32_t* slots_host) {
     if (!r || batch <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_replay_sample: batch must be > 0");
-    if (r->size <= 0) return fail(XQ_ERR_RUNTIME, "xq_replay_sample: buffer is empty");
+    if (r->size <= 0 || count <= 0) return fail(XQ_ERR_RUNTIME, "xq_replay_sample: buffer is empty");
+    if (count > r->size || start < 0 || start >= r->dev.capacity)
+        return fail(XQ_ERR_INVALID_ARGUMENT, "xq_replay_sample_window: window (%d, %d) outside the %d filled slots", start, count, r->size);
     if (batch > r->slots_cap) {
         if (r->slots_dev) { XQ_HIP(hipStreamSynchronize(r->stream)); XQ_HIP(hipFree(r->slots_dev)); }
         XQ_HIP(hipMalloc(&r->slots_dev, (size_t)batch * sizeof(int32_t)));
         r->slots_cap = batch;
     }
     hipLaunchKernelGGL(replay_sample_kernel, dim3((batch + 255) / 256), dim3(256), 0, r->stream, r->slots_dev, batch,
-                       r->size, (uint32_t)r->sample_calls, (uint32_t)r->seed, (uint32_t)(r->seed >> 32));
+                       (uint32_t)start, (uint32_t)count, (uint32_t)r->dev.capacity, (uint32_t)r->sample_calls, (uint32_t)r->seed, (uint32_t)(r->seed >> 32));
     XQ_HIP(hipGetLastError());
     r->sample_calls++;
     r->last_batch = batch;

@@ -6,7 +6,9 @@
 //             transition written straight into the replay ring;
 //   learn   : sample -> TD gradients (xq_dqn_td_grads) -> [caller all-reduces the gradient buffer over RCCL] -> SGD;
 //   target  : updateTargetNetwork() every target_sync_interval updates (chessai.cpp:140 uses moveCount % 100).
-// No host round trip inside an iteration; everything is queued on one HIP stream.
+// No host round trip inside an iteration; everything is queued on one HIP stream — or, with cfg.overlap_collect, collect
+// goes to a second stream: collect(t) and learn_grads(t) both read theta_t, learn_grads(t) samples the ring minus the
+// slots collect(t) is writing, learn_apply(t) joins both before theta_{t+1} is written.
 #include "xq_internal.h"
 
 struct xq_trainer {
@@ -18,6 +20,11 @@ struct xq_trainer {
     xq_replay* replay = nullptr;
     uint64_t env_steps = 0, updates = 0;
     uint32_t eps_u32 = 0;
+    // overlap_collect
+    hipStream_t cstream = nullptr;          // collect stream
+    hipEvent_t ev_params = nullptr;         // main: parameters of the next iteration are final (after learn_apply)
+    hipEvent_t ev_collect = nullptr;        // cstream: the collects of this iteration are done
+    int inflight = 0;                       // ring slots written by collects since the last learn_apply
 };
 
 using namespace xq;
@@ -31,6 +38,8 @@ int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer
     if (cfg->replay_capacity != 0 && cfg->replay_capacity < cfg->n_games)
         return fail(XQ_ERR_INVALID_ARGUMENT, "replay_capacity must be 0 (on-policy) or >= n_games");
     if (cfg->replay_capacity != 0 && cfg->minibatch <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "minibatch must be > 0");
+    if (cfg->overlap_collect && cfg->replay_capacity == 0)
+        return fail(XQ_ERR_INVALID_ARGUMENT, "overlap_collect needs a replay ring (on-policy learns on the ply just played)");
     int ndev = 0;
     XQ_TRY(xq_device_count(&ndev));
     if (ndev == 0) return fail(XQ_ERR_NO_DEVICE, "no HIP device: libxqhip has no CPU fallback");
@@ -46,13 +55,21 @@ int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer
     const double e = cfg->epsilon < 0 ? 0 : cfg->epsilon;
     const double v = e * 4294967296.0;
     t->eps_u32 = v >= 4294967295.0 ? 4294967295u : (uint32_t)v;
+    if (cfg->overlap_collect) {
+        XQ_HIP(hipStreamCreateWithFlags(&t->cstream, hipStreamNonBlocking));
+        XQ_HIP(hipEventCreateWithFlags(&t->ev_params, hipEventDisableTiming));
+        XQ_HIP(hipEventCreateWithFlags(&t->ev_collect, hipEventDisableTiming));
+        XQ_HIP(hipEventRecord(t->ev_params, t->stream));      // orders the first collect after the handles' initialisation
+    }
     *out = t;
     return XQ_OK;
 }
 
 int xq_trainer_destroy(xq_trainer* t) {
     if (!t) return XQ_OK;
+    if (t->cstream) hipStreamSynchronize(t->cstream);
     hipStreamSynchronize(t->stream);
+    if (t->cstream) { hipStreamDestroy(t->cstream); hipEventDestroy(t->ev_params); hipEventDestroy(t->ev_collect); }
     xq_env_destroy(t->env);
     xq_dqn_destroy(t->dqn);
     xq_replay_destroy(t->replay);
@@ -69,17 +86,27 @@ int xq_trainer_collect(xq_trainer* t) {
     if (!t) return fail(XQ_ERR_INVALID_ARGUMENT, "null trainer");
     float* q90 = nullptr;
     int stride = 0;
-    XQ_TRY(dqn_q90_boards(t->dqn, t->env->boards, t->env->n, &q90, &stride));
+    hipStream_t on = nullptr;
+    if (t->cstream) {
+        on = t->cstream;
+        if (t->inflight == 0) XQ_HIP(hipStreamWaitEvent(on, t->ev_params, 0));
+    }
+    hipStream_t s = on ? on : t->stream;
+    XQ_TRY(dqn_q90_boards(t->dqn, t->env->boards, t->env->n, &q90, &stride, on));
     if (t->cfg.replay_capacity == 0) {           // on-policy: the ring is exactly one batch, refilled every ply
         t->replay->write_pos = 0;
         t->replay->size = 0;
     }
     Profiler* p = dqn_profiler(t->dqn);
-    const int h = p->begin("env_selfplay_step", t->stream);
-    XQ_TRY(env_selfplay_launch(t->env, q90, stride, t->eps_u32, nullptr, t->replay));
+    const int h = p->begin("env_selfplay_step", s);
+    XQ_TRY(env_selfplay_launch(t->env, q90, stride, t->eps_u32, nullptr, t->replay, on));
     // algorithmic HBM bytes per game and ply: board+meta in/out (2*(48+16)), Q row 360, transition 48+48+4+4+1
-    p->end(h, t->stream, 0.0, (double)t->env->n * (2.0 * (48 + 16) + 360 + 105));
+    p->end(h, s, 0.0, (double)t->env->n * (2.0 * (48 + 16) + 360 + 105));
     t->env_steps += (uint64_t)t->env->n;
+    if (on) {
+        t->inflight += t->env->n;
+        XQ_HIP(hipEventRecord(t->ev_collect, on));
+    }
     return XQ_OK;
 }
 
@@ -88,7 +115,21 @@ int xq_trainer_learn_grads(xq_trainer* t) {
     int batch = 0;
     if (t->cfg.replay_capacity > 0) {
         batch = t->cfg.minibatch;
-        XQ_TRY(replay_sample_implicit(t->replay, batch));     // no sampling kernel: the consumers recompute the slots
+        int start = 0, count = -1;
+        if (t->cstream && t->inflight > 0) {
+            // the ring minus the window [write_pos - inflight, write_pos) that the collects on cstream are filling
+            const xq_replay* r = t->replay;
+            const int cap = r->dev.capacity;
+            if (r->size < cap) { start = 0; count = r->size - t->inflight; }
+            else { start = r->write_pos; count = cap - t->inflight; }
+            if (count <= 0 || t->inflight > cap) {
+                // nothing older than the plies in flight (first iteration): wait for them and learn on those
+                XQ_HIP(hipStreamWaitEvent(t->stream, t->ev_collect, 0));
+                t->inflight = 0;
+                start = 0; count = -1;
+            }
+        }
+        XQ_TRY(replay_sample_implicit(t->replay, batch, start, count));     // no sampling kernel: the consumers recompute the slots
     }
     return xq_dqn_td_grads_replay(t->dqn, t->replay, batch, t->cfg.td_net, t->cfg.backprop_mode);
 }
@@ -97,10 +138,15 @@ int xq_trainer_learn_apply(xq_trainer* t, int world_size) {
     if (!t || world_size < 1) return fail(XQ_ERR_INVALID_ARGUMENT, "bad argument");
     const int batch = t->cfg.replay_capacity > 0 ? t->cfg.minibatch : t->cfg.n_games;
     const double scale = t->cfg.mean_gradient ? 1.0 / ((double)batch * world_size) : 1.0;
+    if (t->cstream && t->inflight > 0) XQ_HIP(hipStreamWaitEvent(t->stream, t->ev_collect, 0));   // the select chain reads theta_t
     XQ_TRY(xq_dqn_apply_grads(t->dqn, t->cfg.learning_rate, scale));
     t->updates += 1;
     if (t->cfg.target_sync_interval > 0 && t->updates % (uint64_t)t->cfg.target_sync_interval == 0)
         XQ_TRY(xq_dqn_update_target(t->dqn));
+    if (t->cstream) {
+        XQ_HIP(hipEventRecord(t->ev_params, t->stream));
+        t->inflight = 0;
+    }
     return XQ_OK;
 }
 
@@ -123,6 +169,7 @@ int xq_trainer_counters(xq_trainer* t, uint64_t* env_steps, uint64_t* updates, u
     if (updates) *updates = t->updates;
     if (episodes) {
         unsigned long long head = 0;
+        if (t->cstream) XQ_HIP(hipStreamSynchronize(t->cstream));
         XQ_HIP(hipStreamSynchronize(t->stream));
         XQ_HIP(hipMemcpy(&head, t->env->ep_head, sizeof head, hipMemcpyDeviceToHost));
         *episodes = head;

@@ -168,7 +168,7 @@ class DQN:
 def TrainerConfig(n_games=8192, layer_sizes=(1260, 256, 256, 8100), learning_rate=0.001, gamma=0.99, epsilon=0.1,
                   replay_capacity=1 << 20, minibatch=8192, td_net=_capi.TD_TARGET_NET,
                   backprop_mode=_capi.BACKPROP_REFERENCE, target_sync_interval=100, mean_gradient=1, seed=0x5EED,
-                  first_game_id=0, collects_per_update=1):
+                  first_game_id=0, collects_per_update=1, overlap_collect=0):
     c = _CConfig()
     c.n_games = n_games
     for i, s in enumerate(layer_sizes):
@@ -180,6 +180,7 @@ def TrainerConfig(n_games=8192, layer_sizes=(1260, 256, 256, 8100), learning_rat
     c.target_sync_interval, c.mean_gradient = target_sync_interval, mean_gradient
     c.seed, c.first_game_id = seed, first_game_id
     c.collects_per_update = collects_per_update
+    c.overlap_collect = overlap_collect
     return c
 
 

@@ -88,6 +88,12 @@ class ReplayBuffer:
         call("xq_replay_sample", self._h, int(batch), _ptr(slots, C.c_int32))
         return slots
 
+    def sample_window(self, batch, start, count):
+        """sample(B) from the `count` ring slots that start at `start` (wrapping)."""
+        slots = np.zeros(batch, dtype=np.int32)
+        call("xq_replay_sample_window", self._h, int(batch), int(start), int(count), _ptr(slots, C.c_int32))
+        return slots
+
     def get(self, slot):
         b, nb = np.zeros(90, np.uint8), np.zeros(90, np.uint8)
         a, r, d = C.c_int32(), C.c_float(), C.c_uint8()

@@ -140,6 +140,9 @@ int xq_replay_push_host(xq_replay* r, int n, const uint8_t* boards90, const int3
 /* sample(B): uniform with replacement, Philox(ctr = {draw, 0, sample call #, 1}, key = seed) % size.
  * Returns the chosen slots; xq_dqn_train_replay consumes them on device. */
 int xq_replay_sample(xq_replay* r, int batch, int32_t* slots_host /* optional */);
+/* sample(B) restricted to the `count` ring slots that start at `start` (wrapping): slot = (start + Philox % count) % capacity.
+ * The overlapped trainer uses it to leave out the slots a concurrent collect is writing; (0, size) == xq_replay_sample. */
+int xq_replay_sample_window(xq_replay* r, int batch, int start, int count, int32_t* slots_host /* optional */);
 int xq_replay_get(xq_replay* r, int slot, uint8_t* board90, int32_t* action_to, float* reward, uint8_t* done,
                   uint8_t* next_board90);
 
@@ -216,6 +219,8 @@ int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_st
  *   collect : Q(s)[0..89] for every game -> xq_env_selfplay_step -> transitions into the replay ring
  *   learn   : sample minibatch -> xq_dqn_td_grads  [caller may all-reduce xq_dqn_grad_buffer] -> apply
  *   target sync every target_sync_interval learn steps (chessai.cpp:140 uses moveCount % 100).
+ * With overlap_collect the same three calls are issued in the same order; collect is queued on a second stream and
+ * learn_apply joins it, so env stepping hides behind the TD step (and behind the caller's gradient all-reduce).
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct xq_trainer xq_trainer;
 typedef struct {
@@ -232,6 +237,9 @@ typedef struct {
     uint64_t seed;
     uint32_t first_game_id;
     int collects_per_update;                /* plies played in every game per learn step (0 or 1 = one; BASELINE configs[3] uses 4) */
+    int overlap_collect;                    /* 1: collect runs on its own HIP stream beside learn_grads of the same iteration; both
+                                             * read the same parameters, and the minibatch is drawn from the ring minus the slots the
+                                             * collect is writing (they become eligible one iteration later).  Needs a replay ring. */
 } xq_trainer_config;
 
 int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer** out);

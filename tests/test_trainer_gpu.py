@@ -2,7 +2,9 @@
 
 (1) the loop composed from C-ABI calls vs the CPU oracle's restatement of chessai.cpp:96-143, same Q inputs;
 (2) xq_trainer_step == that composition, bit for bit (the trainer adds no arithmetic of its own);
-(3) BASELINE config 2 shape (8192 games, (256,256) net) runs and stays finite.
+(3) BASELINE config 2 shape (8192 games, (256,256) net) runs and stays finite;
+(4) overlap_collect (collect on its own stream beside learn_grads) == its sequential definition, bit for bit — a race between
+    the two streams would show up as a difference.
 """
 import ctypes as C
 
@@ -131,3 +133,82 @@ def test_collects_per_update(xq):
     with pytest.raises(xq.XqError):
         bad.step(1)
     t.close(); bad.close()
+
+
+def overlap_window(size, total, cap, m):
+    """Eligible ring slots while a collect of m transitions is in flight: (start, count) from the pre-collect state."""
+    w = total % cap
+    if size + m < cap:
+        return 0, size
+    return (w + m) % cap, cap - m
+
+
+@pytest.mark.parametrize("n,cap,minibatch,plies,iters", [(64, 256, 48, 1, 9), (32, 200, 64, 2, 8), (2048, 1 << 15, 2048, 1, 6)])
+def test_overlapped_trainer_equals_its_sequential_definition(xq, n, cap, minibatch, plies, iters):
+    """Iteration t: minibatch drawn from the ring minus the slots collect(t) writes, gradients with theta_t; collect(t) acts with
+    theta_t; then apply.  First iteration (nothing older in the ring): collect, then learn on what was just played."""
+    import torch
+    seed, first, sizes = 99, 7, CFG2_NET
+    cfg = xq.TrainerConfig(n_games=n, layer_sizes=sizes, learning_rate=0.01, gamma=0.99, epsilon=0.2, replay_capacity=cap,
+                           minibatch=minibatch, td_net=1, backprop_mode=0, target_sync_interval=3, mean_gradient=1, seed=seed,
+                           first_game_id=first, collects_per_update=plies, overlap_collect=1)
+    t = xq.Trainer(cfg)
+    w0, b0 = t.dqn.get_params()
+    t.step(iters)
+    tw, tb = t.dqn.get_params()
+    tboards, tmeta = t.env.get_state()
+    c = t.counters()
+    assert c["env_steps"] == n * plies * iters and c["updates"] == iters
+
+    env = xq.VecEnv(n, seed=seed, first_game_id=first)
+    d = xq.DQN(sizes, 0.01, 0.99, seed=1)
+    d.set_params(w0, b0); d.updateTargetNetwork()
+    rp = xq.ReplayBuffer(cap, seed=seed + 0x1234567 + first)
+    m = n * plies
+
+    def collect():
+        for _ in range(plies):
+            q = d.q_boards(env, 96)
+            env.selfplay_step_dev(q.data_ptr(), 96, 0.2, replay=rp)
+            torch.cuda.synchronize()
+
+    for it in range(iters):
+        size, _, total = rp.stats()
+        start, count = overlap_window(size, total, cap, m)
+        if count <= 0:
+            collect()
+            rp.sample(minibatch)
+            d.td_grads_replay(rp, minibatch, td_net=1, mode=0)
+        else:
+            slots = rp.sample_window(minibatch, start, count)
+            inflight = {(total + i) % cap for i in range(m)}
+            assert not inflight.intersection(slots.tolist())
+            d.td_grads_replay(rp, minibatch, td_net=1, mode=0)
+            collect()
+        d.apply_grads(0.01, 1.0 / minibatch)
+        if (it + 1) % 3 == 0:
+            d.updateTargetNetwork()
+    w, b = d.get_params()
+    boards, meta = env.get_state()
+    assert np.array_equal(boards, tboards) and np.array_equal(meta, tmeta)
+    assert np.array_equal(w, tw) and np.array_equal(b, tb)
+    assert np.abs(w - w0).max() > 0
+    t.close(); env.close(); d.close(); rp.close()
+
+
+def test_overlap_needs_a_replay_ring(xq):
+    with pytest.raises(xq.XqError):
+        xq.Trainer(xq.TrainerConfig(n_games=16, layer_sizes=REF_NET, replay_capacity=0, minibatch=16, overlap_collect=1))
+
+
+def test_sample_window_matches_the_oracle_philox(xq):
+    rp = xq.ReplayBuffer(50, seed=0xABCDEF0123)
+    b = np.tile(xq.START_BOARD, (40, 1))
+    rp.push(b, np.arange(40) % 90, np.zeros(40), np.zeros(40), b)
+    for call, (start, count) in enumerate([(0, 40), (35, 5), (10, 17)]):
+        got = rp.sample_window(64, start, count)
+        want = [(start + xo.philox((i, 0, call, 1), (0xCDEF0123, 0xAB))[0] % count) % 50 for i in range(64)]
+        assert got.tolist() == want
+    with pytest.raises(xq.XqError):
+        rp.sample_window(8, 0, 41)
+    rp.close()
