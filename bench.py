@@ -183,6 +183,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    host_enqueue = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -218,6 +219,7 @@ def main():
             "updates_per_s": args.steps / elapsed,
             "transitions_trained_per_s": world * minibatch * args.steps / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 8192 self-play games per GPU, DQN 1260-256-256-8100 fp32, "
                                    "replay 1M transitions, minibatch 8192, one update per ply",

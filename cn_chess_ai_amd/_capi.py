@@ -39,6 +39,10 @@ class EpisodeRecord(C.Structure):
                 ("black_score", C.c_int16), ("move_count", C.c_uint16), ("winner", C.c_uint8), ("reserved", C.c_uint8)]
 
 
+class KernelSpan(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("start_ms", C.c_float), ("end_ms", C.c_float)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("ms", C.c_float), ("launches", C.c_int), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -112,6 +116,7 @@ PROTOTYPES = {
     "xq_dqn_td_update_host": [_vp, _i, _pu8, _pu8, _pi, _pf, _pu8, _i, _i, _d, _d, _pf, _pf],
     "xq_dqn_last_loss": [_vp, _pd],
     "xq_dqn_kernel_stats": [_vp, _i, C.POINTER(KernelStat), _i, _pi],
+    "xq_dqn_kernel_timeline": [_vp, C.POINTER(KernelSpan), _i, _pi],
     "xq_trainer_create": [C.POINTER(TrainerConfig), _vp, _pvp],
     "xq_trainer_destroy": [_vp],
     "xq_trainer_env": [_vp, _pvp],

@@ -35,7 +35,7 @@ struct xq_dqn {
     hipStream_t side = nullptr;
     hipStream_t cur = nullptr;
     int ncu = 256;                              // compute units of the device (persistent-kernel grid = 2 per CU)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_delta = nullptr;
     float* params[2] = {nullptr, nullptr};
     // workspaces sized for `cap` samples
     int cap = 0;
@@ -873,6 +873,7 @@ int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, dou
     XQ_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
     XQ_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
     XQ_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
+    XQ_HIP(hipEventCreateWithFlags(&d->ev_delta, hipEventDisableTiming));
     // + 128 rows of the widest layer: the persistent column-max GEMM reads whole 128-row tiles of W_out (rows beyond the
     // last output are masked in its epilogue, but must be readable)
     int widest = 0;
@@ -908,6 +909,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     if (d->side) { hipStreamSynchronize(d->side); hipStreamDestroy(d->side); }
     if (d->ev_fork) hipEventDestroy(d->ev_fork);
     if (d->ev_join) hipEventDestroy(d->ev_join);
+    if (d->ev_delta) hipEventDestroy(d->ev_delta);
     if (d->own_stream) hipStreamDestroy(d->stream);
     delete d;
     return XQ_OK;
@@ -1070,6 +1072,47 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
     return td_grads_impl(d, boards, next_boards, action_to, reward, done, explicit_slots(slots), n, td_net, mode);
 }
 
+// gradients that run on the side stream (d->cur == d->side), see td_grads_impl
+static int side_gradients(xq_dqn* d, int n, float* const* outs, float* G) {
+    const int nl = d->nl, Hl = d->hlast();
+    BiasJobs bj;
+    {   // output layer rows 0..95 + their biases: segmented sums by action
+        const int chunk = 1024;
+        const int nchunks = (n + chunk - 1) / chunk;
+        const long long len = 96LL * Hl + 96;
+        float* dst = G + d->g_wout;                      // g_bout follows directly
+        float* out = dst;
+        if (nchunks > 1) { XQ_TRY(ensure_slabs(d, (size_t)nchunks * (size_t)len)); out = d->slabs; }
+        {
+            ProfScope ps(d, "out_grad_segsum", 2.0 * n * Hl, (double)n * (Hl * 4 + 8) + 4.0 * nchunks * len);
+            const size_t shmem = (size_t)16 * Hl * sizeof(float) + (size_t)chunk * sizeof(uint16_t);
+            if (shmem > 64 * 1024 || (Hl & 3)) return fail(XQ_ERR_INVALID_ARGUMENT, "last hidden layer width %d unsupported by the output-gradient kernel (multiple of 4, <= 960)", Hl);
+            hipLaunchKernelGGL(out_grad_kernel, dim3(24, nchunks), dim3(256), shmem, d->cur, d->act_mb, d->dsc, outs[nl - 2], n, Hl,
+                               chunk, out);
+            XQ_HIP(hipGetLastError());
+        }
+        if (nchunks > 1) {
+            ProfScope ps(d, "reduce_slabs", (double)nchunks * len, 4.0 * (nchunks + 1) * len);
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, d->cur, d->slabs, nchunks, len,
+                               len, dst);
+            XQ_HIP(hipGetLastError());
+        }
+    }
+    bool waited = false;
+    for (int l = nl - 2; l >= 1; --l) {
+        if (l < nl - 2 && !waited) { XQ_HIP(hipStreamWaitEvent(d->cur, d->ev_delta, 0)); waited = true; }   // delta_l, l < top, comes from the GEMMs
+        GemmArgs g; memset(&g, 0, sizeof g);
+        g.M = d->L[l + 1]; g.N = d->L[l]; g.K = n;
+        g.A = d->deltas[l]; g.lda = d->L[l + 1];
+        g.B = outs[l - 1]; g.ldb = d->L[l];
+        XQ_TRY((grad_gemm<L_MCONTIG>(d, g, G + d->g_wh[l], "gemm_grad_hidden")));
+        bj.add(d->deltas[l], d->L[l + 1], d->L[l + 1], G + d->g_bh[l]);
+    }
+    bj.add(d->deltas[0], d->L[1], d->L[1], G + d->g_bh[0]);
+    if (!waited) XQ_HIP(hipStreamWaitEvent(d->cur, d->ev_delta, 0));
+    return bias_grads(d, bj, n);
+}
+
 static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boards, const int32_t* action_to,
                          const float* reward, const uint8_t* done, SlotSrc slots, int n, int td_net, int mode) {
     if (!d || !boards || !next_boards || !action_to || !reward || !done || n <= 0)
@@ -1132,52 +1175,21 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         XQ_HIP(hipGetLastError());
     }
     d->last_n = n;
-    // 4. the remaining hidden deltas (GEMMs)
-    if (nl >= 3) XQ_TRY(hidden_deltas(d, n, d->deltas[nl - 2], d->L[nl - 1], d->L[nl - 1], mode, nl - 3));
-    // 5. gradients (compact layout).  The layer-0 segmented sum (side stream) overlaps the other gradient kernels.
+    // From here two chains run side by side.  Critical (handle stream): the remaining hidden deltas (GEMMs) and the
+    // layer-0 segmented sum that consumes delta_0.  Side stream: everything that only needs what td_delta_kernel wrote —
+    // the output-layer gradient, the top hidden layer's gradient GEMM — and, once the deltas exist, the lower gradient
+    // GEMMs and the bias column sums.
     float* G = d->grads_td;
-    BiasJobs bj;
     XQ_HIP(hipEventRecord(d->ev_fork, d->stream));
     XQ_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+    if (nl >= 3) XQ_TRY(hidden_deltas(d, n, d->deltas[nl - 2], d->L[nl - 1], d->L[nl - 1], mode, nl - 3));
+    XQ_HIP(hipEventRecord(d->ev_delta, d->stream));
+    XQ_TRY(l0_gradient(d, n, G + d->g_w0));
     d->cur = d->side;
-    {
-        const int rc = l0_gradient(d, n, G + d->g_w0);
-        d->cur = d->stream;
-        if (rc != XQ_OK) return rc;
-    }
+    const int rc = side_gradients(d, n, outs, G);
+    d->cur = d->stream;
+    if (rc != XQ_OK) return rc;
     XQ_HIP(hipEventRecord(d->ev_join, d->side));
-    {   // output layer rows 0..95 + their biases: segmented sums by action
-        const int chunk = 1024;
-        const int nchunks = (n + chunk - 1) / chunk;
-        const long long len = 96LL * Hl + 96;
-        float* dst = G + d->g_wout;                      // g_bout follows directly
-        float* out = dst;
-        if (nchunks > 1) { XQ_TRY(ensure_slabs(d, (size_t)nchunks * (size_t)len)); out = d->slabs; }
-        {
-            ProfScope ps(d, "out_grad_segsum", 2.0 * n * Hl, (double)n * (Hl * 4 + 8) + 4.0 * nchunks * len);
-            const size_t shmem = (size_t)16 * Hl * sizeof(float) + (size_t)chunk * sizeof(uint16_t);
-            if (shmem > 64 * 1024 || (Hl & 3)) return fail(XQ_ERR_INVALID_ARGUMENT, "last hidden layer width %d unsupported by the output-gradient kernel (multiple of 4, <= 960)", Hl);
-            hipLaunchKernelGGL(out_grad_kernel, dim3(24, nchunks), dim3(256), shmem, d->cur, d->act_mb, d->dsc, outs[nl - 2], n, Hl,
-                               chunk, out);
-            XQ_HIP(hipGetLastError());
-        }
-        if (nchunks > 1) {
-            ProfScope ps(d, "reduce_slabs", (double)nchunks * len, 4.0 * (nchunks + 1) * len);
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, d->cur, d->slabs, nchunks, len,
-                               len, dst);
-            XQ_HIP(hipGetLastError());
-        }
-    }
-    for (int l = nl - 2; l >= 1; --l) {
-        GemmArgs g; memset(&g, 0, sizeof g);
-        g.M = d->L[l + 1]; g.N = d->L[l]; g.K = n;
-        g.A = d->deltas[l]; g.lda = d->L[l + 1];
-        g.B = outs[l - 1]; g.ldb = d->L[l];
-        XQ_TRY((grad_gemm<L_MCONTIG>(d, g, G + d->g_wh[l], "gemm_grad_hidden")));
-        bj.add(d->deltas[l], d->L[l + 1], d->L[l + 1], G + d->g_bh[l]);
-    }
-    bj.add(d->deltas[0], d->L[1], d->L[1], G + d->g_bh[0]);
-    XQ_TRY(bias_grads(d, bj, n));
     XQ_HIP(hipStreamWaitEvent(d->stream, d->ev_join, 0));
     return XQ_OK;
 }
@@ -1287,6 +1299,19 @@ int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_st
         d->prof.enabled = enable != 0;
         d->prof.roofline_only = enable == 3;
     }
+    return XQ_OK;
+}
+
+int xq_dqn_kernel_timeline(xq_dqn* d, xq_kernel_span* spans, int max_spans, int* n_spans) {
+    if (!d || !n_spans) return fail(XQ_ERR_INVALID_ARGUMENT, "null pointer");
+    int n = 0;
+    for (size_t i = 0; i < d->prof.spans.size() && spans && n < max_spans; ++i, ++n) {
+        const Profiler::Span& sp = d->prof.spans[i];
+        memset(&spans[n], 0, sizeof spans[n]);
+        memcpy(spans[n].name, sp.name, sizeof spans[n].name);
+        spans[n].start_ms = sp.start_ms; spans[n].end_ms = sp.end_ms;
+    }
+    *n_spans = n;
     return XQ_OK;
 }
 

@@ -60,6 +60,8 @@ namespace xq {
 struct Profiler {
     struct Cat { char name[48]; double flops = 0, bytes = 0; int launches = 0; float ms = 0; };
     struct Rec { int cat; hipEvent_t a, b; };
+    struct Span { char name[48]; float start_ms, end_ms; };      // relative to the first bracket of the batch (live timeline)
+    std::vector<Span> spans;
     bool enabled = false;
     bool roofline_only = false;   // bracket only the two kernels bench.py prices (keeps the timed region undisturbed)
     std::vector<Cat> cats;
@@ -90,13 +92,20 @@ struct Profiler {
         c.flops += flops; c.bytes += bytes; c.launches += 1;
     }
     void collect() {
+        if (!recs.empty()) spans.clear();
         for (auto& r : recs) {
             float ms = 0;
             (void)hipEventSynchronize(r.b);
             (void)hipEventElapsedTime(&ms, r.a, r.b);
             cats[r.cat].ms += ms;
-            pool.push_back(r.a); pool.push_back(r.b);
+            if (!roofline_only && spans.size() < 8192) {
+                Span sp; memcpy(sp.name, cats[r.cat].name, sizeof sp.name); sp.start_ms = 0; sp.end_ms = 0;
+                (void)hipEventElapsedTime(&sp.start_ms, recs[0].a, r.a);
+                (void)hipEventElapsedTime(&sp.end_ms, recs[0].a, r.b);
+                spans.push_back(sp);
+            }
         }
+        for (auto& r : recs) { pool.push_back(r.a); pool.push_back(r.b); }
         recs.clear();
     }
     void reset() { collect(); cats.clear(); }

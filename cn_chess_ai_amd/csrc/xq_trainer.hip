@@ -56,7 +56,9 @@ int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer
     const double v = e * 4294967296.0;
     t->eps_u32 = v >= 4294967295.0 ? 4294967295u : (uint32_t)v;
     if (cfg->overlap_collect) {
-        XQ_HIP(hipStreamCreateWithFlags(&t->cstream, hipStreamNonBlocking));
+        int lo = 0, hi = 0;
+        XQ_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));        // lo = least urgent: collect has slack until learn_apply,
+        XQ_HIP(hipStreamCreateWithPriority(&t->cstream, hipStreamNonBlocking, lo));   // the TD step is the critical path
         XQ_HIP(hipEventCreateWithFlags(&t->ev_params, hipEventDisableTiming));
         XQ_HIP(hipEventCreateWithFlags(&t->ev_collect, hipEventDisableTiming));
         XQ_HIP(hipEventRecord(t->ev_params, t->stream));      // orders the first collect after the handles' initialisation

@@ -8,7 +8,7 @@ import random
 import numpy as np
 
 from . import _capi
-from ._capi import call, KernelStat, TrainerConfig as _CConfig
+from ._capi import call, KernelStat, KernelSpan, TrainerConfig as _CConfig
 from .vecenv import VecEnv, ReplayBuffer, _ptr
 
 REFERENCE_LAYERS = (1260, 128, 8100)     # ChessAI::initializeDQN, chessai.cpp:395-404
@@ -163,6 +163,17 @@ class DQN:
         call("xq_dqn_kernel_stats", self._h, int(enable), arr, 64, C.byref(n))
         return [dict(name=arr[i].name.decode(), ms=arr[i].ms, launches=arr[i].launches, flops=arr[i].flops,
                      bytes=arr[i].bytes) for i in range(n.value)]
+
+
+def _timeline(self, max_spans=8192):
+    """(name, start_ms, end_ms) of every launch bracketed in the session closed by the last kernel_stats() call."""
+    arr = (KernelSpan * max_spans)()
+    n = C.c_int32()
+    call("xq_dqn_kernel_timeline", self._h, arr, max_spans, C.byref(n))
+    return [(arr[i].name.decode(), arr[i].start_ms, arr[i].end_ms) for i in range(n.value)]
+
+
+DQN.kernel_timeline = _timeline
 
 
 def TrainerConfig(n_games=8192, layer_sizes=(1260, 256, 256, 8100), learning_rate=0.001, gamma=0.99, epsilon=0.1,

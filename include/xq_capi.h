@@ -213,6 +213,11 @@ int xq_dqn_last_loss(xq_dqn* d, double* loss);
  * enable: -1 leave, 0 off, 1 on, 2 on + clear, 3 on + clear but bracket only gemm_qmax_rowmax and env_selfplay_step. */
 typedef struct { char name[48]; float ms; int launches; double flops; double bytes; } xq_kernel_stat;
 int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_stats, int* n_stats);
+/* Live timeline of the brackets gathered by the last xq_dqn_kernel_stats call (enable 1/2 sessions): start/end of every
+ * bracketed launch in ms relative to the first one, across the handle's streams — what a kernel trace shows, without a
+ * profiler attached.  Diagnostic. */
+typedef struct { char name[48]; float start_ms; float end_ms; } xq_kernel_span;
+int xq_dqn_kernel_timeline(xq_dqn* d, xq_kernel_span* spans, int max_spans, int* n_spans);
 
 /* ------------------------------------------------------------------------------------------------------------
  * xq_trainer — the ChessAI::train() loop (chessai.cpp:85-170) for n_games boards at once, on device.
