@@ -168,8 +168,12 @@ def main():
         grads = xd.wrap_device_floats(ptr, n)
 
     def one_step():
-        t.collect()
-        t.learn_grads()
+        if args.no_overlap:
+            t.collect()
+            t.learn_grads()
+        else:                   # collect is queued behind the column-max GEMM of learn_grads and runs beside the gradient chain
+            t.learn_grads()
+            t.collect()
         if grads is not None:
             xd.allreduce_gradients(grads, world)
         t.learn_apply(world)

@@ -36,6 +36,7 @@ struct xq_dqn {
     hipStream_t cur = nullptr;
     int ncu = 256;                              // compute units of the device (persistent-kernel grid = 2 per CU)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_delta = nullptr;
+    hipEvent_t ev_qmax = nullptr;               // recorded behind the column-max GEMM of the last TD step (trainer: collect starts here)
     float* params[2] = {nullptr, nullptr};
     // workspaces sized for `cap` samples
     int cap = 0;
@@ -83,6 +84,7 @@ namespace xq {
 
 Profiler* dqn_profiler(xq_dqn* d) { return &d->prof; }
 hipStream_t dqn_stream(xq_dqn* d) { return d->stream; }
+hipEvent_t dqn_qmax_event(xq_dqn* d) { return d->ev_qmax; }
 
 struct ProfScope {
     Profiler& p; hipStream_t s; int h; double flops, bytes;
@@ -874,6 +876,7 @@ int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, dou
     XQ_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
     XQ_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
     XQ_HIP(hipEventCreateWithFlags(&d->ev_delta, hipEventDisableTiming));
+    XQ_HIP(hipEventCreateWithFlags(&d->ev_qmax, hipEventDisableTiming));
     // + 128 rows of the widest layer: the persistent column-max GEMM reads whole 128-row tiles of W_out (rows beyond the
     // last output are masked in its epilogue, but must be readable)
     int widest = 0;
@@ -910,6 +913,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     if (d->ev_fork) hipEventDestroy(d->ev_fork);
     if (d->ev_join) hipEventDestroy(d->ev_join);
     if (d->ev_delta) hipEventDestroy(d->ev_delta);
+    if (d->ev_qmax) hipEventDestroy(d->ev_qmax);
     if (d->own_stream) hipStreamDestroy(d->stream);
     delete d;
     return XQ_OK;
@@ -1140,12 +1144,13 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         g.B = touts[nl - 2]; g.ldb = Hl;
         g.bias = d->bl(td_net, nl - 1);
         g.partial = d->partial;
-        if (big_tiles && (Hl % GBK) == 0 && vec_ok(g.A, g.lda) && vec_ok(g.B, g.ldb)) {
+        // the persistent kernel keeps the whole bias vector in LDS beside its operand tiles (2 blocks per CU must fit)
+        const size_t bias_lds = (size_t)((NO + 127) / 128) * 128 * sizeof(float);
+        if (big_tiles && (Hl % GBK) == 0 && vec_ok(g.A, g.lda) && vec_ok(g.B, g.ldb) && bias_lds <= 40 * 1024) {
             // persistent form: 2 blocks per CU walk the tile list with the prefetch running across tile boundaries
             const int tiles_m = (NO + 127) / 128, total = tiles_m * ((n + 127) / 128);
             const int ncu = d->ncu;
             g.a_vec = g.b_vec = 1; g.k_chunk = Hl;
-            g.bias_padded = (((uintptr_t)g.bias) % 16 == 0) ? 1 : 0;     // the parameter buffer is padded behind the biases
             const int grid = std::min(total, 2 * ncu);
             // static priority for the second half of the grid (see the kernel): each half walks its own half of the tiles
             g.prio_split = 0; g.prio_tiles = 0;
@@ -1155,13 +1160,14 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
                 if (g.prio_tiles <= 0 || g.prio_tiles >= total) { g.prio_split = 0; g.prio_tiles = 0; }
             }
             ProfScope ps(d, "gemm_qmax_rowmax", 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + 2.0 * tiles_m * g.N));
-            hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(grid), dim3(256), 0, d->cur, g,
+            hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(grid), dim3(256), bias_lds, d->cur, g,
                                tiles_m, total);
             XQ_HIP(hipGetLastError());
         } else {
             XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_COLMAX>(d, g, 1, "gemm_qmax_rowmax")));
         }
     }
+    XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
     // 3. Q(s, a), target, the scalar output delta and the delta of the last hidden layer (one launch, no GEMM)
     {
         const int lt = nl - 2;                               // last hidden layer

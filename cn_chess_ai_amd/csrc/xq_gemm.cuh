@@ -360,7 +360,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // the tile list (t, t+grid, ...: same row tile = same weight panel, resident in L2) and the register prefetch runs
 // ACROSS tile boundaries: the first k-tile of the next output tile is in flight under the last MFMAs and the epilogue of
 // the current one.  Requires K % 32 == 0, 16-byte aligned operands, and both operands readable up to the next multiple of
-// 128 rows (the callers pad their allocations); rows/columns beyond M/N are masked in the epilogue.
+// 128 rows (the callers pad their allocations, finite contents); rows beyond M never win the max (their bias is -inf in
+// LDS), columns beyond N are not stored.  Dynamic LDS: tiles_m * 128 floats (the bias vector).
 template <int TM, int TN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_colmax_persistent_kernel(const GemmArgs g,
                                                                                                         int tiles_m, int total) {
@@ -389,8 +390,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (t >= tend) return;
     int tm = t % tiles_m, tn = t / tiles_m;
     float4 va[BM / 32], vb[BN / 32];
+    // The whole bias vector lives in LDS for the lifetime of the block (rows >= M hold -inf so they never win the max):
+    // the steady-state loop then has no global loads except the operand prefetch — a bias load inside the loop makes the
+    // compiler's vmcnt bookkeeping conservative across the back edge and costs 5 % — and the epilogue needs no masks.
+    extern __shared__ __attribute__((aligned(16))) float Bias_s[];          // [tiles_m * BM]
     stage_load<L_KCONTIG, BM, true>(g, g.A, g.lda, 1, tm * BM, g.M, 0, g.K, va);
     stage_load<L_KCONTIG, BN, true>(g, g.B, g.ldb, 1, tn * BN, g.N, 0, g.K, vb);
+    for (int m0 = 0; m0 < tiles_m * BM; m0 += 256 * 8) {            // 8 loads in flight per thread, then 8 LDS stores
+        float bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int m = m0 + u * 256 + tid; bv[u] = m < g.M ? g.bias[m] : -__builtin_inff(); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int m = m0 + u * 256 + tid; if (m < tiles_m * BM) Bias_s[m] = bv[u]; }
+    }
     for (;;) {
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -414,7 +426,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             tile_mma<L_KCONTIG, L_KCONTIG, BM, BN, TM, TN>(As, Bs, wm, wn, r, h, acc);
         }
-        epilogue_colmax<TM, TN>(g, acc, tm * BM, tn * BN, tm);
+        // epilogue: partial[(tile_m*2 + wm)][n] = max over the wave's rows of (acc + bias[m]).  32x32 accumulator map:
+        // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) — four runs of 4 consecutive rows per tile, one ds_read_b128 each; the
+        // other 4-row groups live in the other half-wave.  (The first k-step's barrier orders the Bias_s fill before this.)
+        const float* bt = Bias_s + tm * BM + wm * 32 * TM + 4 * h;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float c = -__builtin_inff();
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 x = *reinterpret_cast<const float4*>(bt + i * 32 + 8 * gq);
+                    c = fmaxf(c, acc[i][j][4 * gq] + x.x); c = fmaxf(c, acc[i][j][4 * gq + 1] + x.y);
+                    c = fmaxf(c, acc[i][j][4 * gq + 2] + x.z); c = fmaxf(c, acc[i][j][4 * gq + 3] + x.w);
+                }
+            c = fmaxf(c, __shfl_xor(c, 32, 64));
+            const int n = tn * BN + wn * 32 * TN + j * 32 + r;
+            if (h == 0 && n < g.N) g.partial[((long long)tm * 2 + wm) * g.N + n] = c;
+        }
         if (tnext >= tend) break;
         t = tnext; tm = t % tiles_m; tn = t / tiles_m;
     }

@@ -116,6 +116,7 @@ struct Profiler {
 Profiler* dqn_profiler(xq_dqn* d);
 int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride, hipStream_t on = nullptr);
 hipStream_t dqn_stream(xq_dqn* d);
+hipEvent_t dqn_qmax_event(xq_dqn* d);      // recorded behind the column-max GEMM of the last xq_dqn_td_grads*
 
 // "virtual" replay sample: same slots as xq_replay_sample would write (Philox ctr = {i, 0, call, 1}, key = seed, % size),
 // but no kernel and no slot buffer — the consumer kernels recompute them.  Used by the trainer's hot loop.

@@ -8,7 +8,9 @@
 //   target  : updateTargetNetwork() every target_sync_interval updates (chessai.cpp:140 uses moveCount % 100).
 // No host round trip inside an iteration; everything is queued on one HIP stream — or, with cfg.overlap_collect, collect
 // goes to a second stream: collect(t) and learn_grads(t) both read theta_t, learn_grads(t) samples the ring minus the
-// slots collect(t) is writing, learn_apply(t) joins both before theta_{t+1} is written.
+// slots collect(t) is writing, learn_apply(t) joins both before theta_{t+1} is written.  Preferred call order there:
+// learn_grads, collect, learn_apply — collect then starts behind the column-max GEMM (which wants the chip to itself) and
+// runs beside the gradient chain, which is a string of small latency-bound kernels.  collect-first is also accepted.
 #include "xq_internal.h"
 
 struct xq_trainer {
@@ -25,6 +27,8 @@ struct xq_trainer {
     hipEvent_t ev_params = nullptr;         // main: parameters of the next iteration are final (after learn_apply)
     hipEvent_t ev_collect = nullptr;        // cstream: the collects of this iteration are done
     int inflight = 0;                       // ring slots written by collects since the last learn_apply
+    bool grads_queued = false;              // learn_grads already queued in this iteration: collect starts behind its big GEMM
+    int prepaid_collects = 0;               // collects learn_grads had to run itself (empty ring), owed to the next collect() calls
 };
 
 using namespace xq;
@@ -84,14 +88,14 @@ int xq_trainer_env(xq_trainer* t, xq_env** e) { if (!t || !e) return fail(XQ_ERR
 int xq_trainer_dqn(xq_trainer* t, xq_dqn** d) { if (!t || !d) return fail(XQ_ERR_INVALID_ARGUMENT, "null"); *d = t->dqn; return XQ_OK; }
 int xq_trainer_replay(xq_trainer* t, xq_replay** r) { if (!t || !r) return fail(XQ_ERR_INVALID_ARGUMENT, "null"); *r = t->replay; return XQ_OK; }
 
-int xq_trainer_collect(xq_trainer* t) {
-    if (!t) return fail(XQ_ERR_INVALID_ARGUMENT, "null trainer");
+static int collect_impl(xq_trainer* t) {
     float* q90 = nullptr;
     int stride = 0;
     hipStream_t on = nullptr;
     if (t->cstream) {
         on = t->cstream;
         if (t->inflight == 0) XQ_HIP(hipStreamWaitEvent(on, t->ev_params, 0));
+        if (t->grads_queued && t->inflight == 0) XQ_HIP(hipStreamWaitEvent(on, dqn_qmax_event(t->dqn), 0));
     }
     hipStream_t s = on ? on : t->stream;
     XQ_TRY(dqn_q90_boards(t->dqn, t->env->boards, t->env->n, &q90, &stride, on));
@@ -112,20 +116,35 @@ int xq_trainer_collect(xq_trainer* t) {
     return XQ_OK;
 }
 
+int xq_trainer_collect(xq_trainer* t) {
+    if (!t) return fail(XQ_ERR_INVALID_ARGUMENT, "null trainer");
+    if (t->prepaid_collects > 0) { t->prepaid_collects--; return XQ_OK; }     // already played by learn_grads (empty ring)
+    return collect_impl(t);
+}
+
 int xq_trainer_learn_grads(xq_trainer* t) {
     if (!t) return fail(XQ_ERR_INVALID_ARGUMENT, "null trainer");
     int batch = 0;
     if (t->cfg.replay_capacity > 0) {
         batch = t->cfg.minibatch;
         int start = 0, count = -1;
-        if (t->cstream && t->inflight > 0) {
-            // the ring minus the window [write_pos - inflight, write_pos) that the collects on cstream are filling
+        if (t->cstream) {
+            // the ring minus the window the collects of this iteration write: [write_pos - inflight, write_pos) when they are
+            // already queued, else the next `plies * n_games` slots from write_pos (they will be queued behind the GEMM)
             const xq_replay* r = t->replay;
             const int cap = r->dev.capacity;
-            if (r->size < cap) { start = 0; count = r->size - t->inflight; }
-            else { start = r->write_pos; count = cap - t->inflight; }
-            if (count <= 0 || t->inflight > cap) {
-                // nothing older than the plies in flight (first iteration): wait for them and learn on those
+            const int plies = t->cfg.collects_per_update > 1 ? t->cfg.collects_per_update : 1;
+            const int m = t->inflight > 0 ? t->inflight : plies * t->cfg.n_games;
+            const int size_after = t->inflight > 0 ? r->size : std::min(cap, r->size + m);
+            const int wpos_after = t->inflight > 0 ? r->write_pos : (r->write_pos + m) % cap;
+            if (size_after < cap) { start = 0; count = size_after - m; }
+            else { start = wpos_after; count = cap - m; }
+            if (count <= 0 || m > cap) {
+                // nothing older than this iteration's plies (first iteration): play them now, wait, learn on those
+                if (t->inflight == 0) {
+                    for (int c = 0; c < plies; ++c) XQ_TRY(collect_impl(t));
+                    t->prepaid_collects = plies;
+                }
                 XQ_HIP(hipStreamWaitEvent(t->stream, t->ev_collect, 0));
                 t->inflight = 0;
                 start = 0; count = -1;
@@ -133,7 +152,9 @@ int xq_trainer_learn_grads(xq_trainer* t) {
         }
         XQ_TRY(replay_sample_implicit(t->replay, batch, start, count));     // no sampling kernel: the consumers recompute the slots
     }
-    return xq_dqn_td_grads_replay(t->dqn, t->replay, batch, t->cfg.td_net, t->cfg.backprop_mode);
+    XQ_TRY(xq_dqn_td_grads_replay(t->dqn, t->replay, batch, t->cfg.td_net, t->cfg.backprop_mode));
+    t->grads_queued = true;
+    return XQ_OK;
 }
 
 int xq_trainer_learn_apply(xq_trainer* t, int world_size) {
@@ -149,6 +170,7 @@ int xq_trainer_learn_apply(xq_trainer* t, int world_size) {
         XQ_HIP(hipEventRecord(t->ev_params, t->stream));
         t->inflight = 0;
     }
+    t->grads_queued = false;
     return XQ_OK;
 }
 
@@ -158,8 +180,13 @@ int xq_trainer_step(xq_trainer* t, int n_iterations) {
     if (plies > 1 && t->cfg.replay_capacity == 0)
         return fail(XQ_ERR_INVALID_ARGUMENT, "collects_per_update > 1 needs a replay ring (on-policy keeps one ply)");
     for (int i = 0; i < n_iterations; ++i) {
-        for (int c = 0; c < plies; ++c) XQ_TRY(xq_trainer_collect(t));
-        XQ_TRY(xq_trainer_learn_grads(t));
+        if (t->cstream) {
+            XQ_TRY(xq_trainer_learn_grads(t));
+            for (int c = 0; c < plies; ++c) XQ_TRY(xq_trainer_collect(t));
+        } else {
+            for (int c = 0; c < plies; ++c) XQ_TRY(xq_trainer_collect(t));
+            XQ_TRY(xq_trainer_learn_grads(t));
+        }
         XQ_TRY(xq_trainer_learn_apply(t, 1));
     }
     return XQ_OK;

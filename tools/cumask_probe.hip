@@ -35,7 +35,7 @@ int main() {
         const int rest = big < 256 ? 256 - big : 256;
         if (masked_stream(&sc, big < 256 ? big : 0, rest)) { printf("CU mask stream creation failed\n"); return 1; }
         const int grid = 2 * big;
-        auto gemm = [&]() { hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(grid), dim3(256), 0, sg, g, tiles_m, total); };
+        auto gemm = [&]() { hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(grid), dim3(256), (size_t)tiles_m * 128 * 4, sg, g, tiles_m, total); };
         auto chain = [&]() { for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((gemm_f32_kernel<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH, 1, 1>), dim3(128, 4, 1), dim3(256), 0, sc, s); };
         float tg = 0, tc = 0, tboth_g = 0, tboth_c = 0;
         for (int i = 0; i < 3; ++i) { gemm(); chain(); }

@@ -13,10 +13,10 @@ cfg = xq.TrainerConfig(n_games=8192, layer_sizes=(1260, 256, 256, 8100), replay_
                        td_net=_capi.TD_TARGET_NET, overlap_collect=overlap)
 t = xq.Trainer(cfg, stream=C.c_void_p(ts.cuda_stream))
 for _ in range(20):
-    t.collect(); t.learn_grads(); t.learn_apply(1)
+    (t.learn_grads(), t.collect()) if overlap else (t.collect(), t.learn_grads()); t.learn_apply(1)
 t.dqn.kernel_stats(enable=2)
 for _ in range(6):
-    t.collect(); t.learn_grads(); t.learn_apply(1)
+    (t.learn_grads(), t.collect()) if overlap else (t.collect(), t.learn_grads()); t.learn_apply(1)
 torch.cuda.synchronize()
 t.dqn.kernel_stats(enable=0)
 spans = sorted(t.dqn.kernel_timeline(), key=lambda s: s[1])
