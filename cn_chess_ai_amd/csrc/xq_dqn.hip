@@ -1151,6 +1151,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             const int tiles_m = (NO + 127) / 128, total = tiles_m * ((n + 127) / 128);
             const int ncu = d->ncu;
             g.a_vec = g.b_vec = 1; g.k_chunk = Hl;
+            g.bias_padded = ((((uintptr_t)g.bias) % 16 == 0) && (NO % 4) == 0) ? 1 : 0;     // wide bias preload
             const int grid = std::min(total, 2 * ncu);
             // static priority for the second half of the grid (see the kernel): each half walks its own half of the tiles
             g.prio_split = 0; g.prio_tiles = 0;

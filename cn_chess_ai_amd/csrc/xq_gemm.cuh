@@ -396,12 +396,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     extern __shared__ __attribute__((aligned(16))) float Bias_s[];          // [tiles_m * BM]
     stage_load<L_KCONTIG, BM, true>(g, g.A, g.lda, 1, tm * BM, g.M, 0, g.K, va);
     stage_load<L_KCONTIG, BN, true>(g, g.B, g.ldb, 1, tn * BN, g.N, 0, g.K, vb);
-    for (int m0 = 0; m0 < tiles_m * BM; m0 += 256 * 8) {            // 8 loads in flight per thread, then 8 LDS stores
-        float bv[8];
+    if (g.bias_padded) {            // bias 16-byte aligned and M % 4 == 0: unconditional (clamped) float4 loads, 8 in flight per thread
+        const int n4 = tiles_m * BM / 4, m4 = g.M / 4;
+        const float NEGF = -__builtin_inff();
+        for (int c0 = 0; c0 < n4; c0 += 256 * 8) {
+            float4 bv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int m = m0 + u * 256 + tid; bv[u] = m < g.M ? g.bias[m] : -__builtin_inff(); }
+            for (int u = 0; u < 8; ++u) bv[u] = reinterpret_cast<const float4*>(g.bias)[min(c0 + u * 256 + tid, m4 - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int m = m0 + u * 256 + tid; if (m < tiles_m * BM) Bias_s[m] = bv[u]; }
+            for (int u = 0; u < 8; ++u) {
+                const int idx = c0 + u * 256 + tid;
+                if (idx < n4) reinterpret_cast<float4*>(Bias_s)[idx] = idx < m4 ? bv[u] : make_float4(NEGF, NEGF, NEGF, NEGF);
+            }
+        }
+    } else {
+        for (int m = tid; m < tiles_m * BM; m += 256) Bias_s[m] = m < g.M ? g.bias[m] : -__builtin_inff();
     }
     for (;;) {
         f32x16 acc[TM][TN];
