@@ -390,3 +390,41 @@ def test_td_update_full_batch_properties(xq):
     w1, b1 = d1.get_params(); w2, b2 = d2.get_params()
     assert np.abs(w1 - w2).max() < 1e-5 and np.abs(b1 - b2).max() < 1e-5
     env.close(); d1.close(); d2.close()
+
+
+def test_td_targets_on_the_persistent_gemm_match_oracle(xq):
+    """The column-max GEMM's persistent form (>= 512 output tiles; here 64 x 9 for a ragged batch of 1100) against the oracle:
+    y = r + gamma * max_k Q_target(s')[k] per sample, target net with large random biases on every layer (the bias vector is
+    staged through LDS there, rows >= 8100 padded with -inf), Q(s, a) from the online net."""
+    sizes = CFG2_NET
+    n = 1100
+    env = xq.VecEnv(n, seed=4321)
+    for _ in range(25):
+        env.selfplay_step(None)
+    S, _ = env.get_state()
+    res = env.selfplay_step(None)
+    S2, _ = env.get_state()
+    A = (res["action"] % 90).astype(np.int32)
+    R = (res["reward"] / 100.0).astype(np.float32)
+    D = res["done"].copy()
+    D[::7] = 1                                           # plenty of terminal samples in the mix
+    d, w, b = make_net(xq, sizes, seed=31)
+    wt, _ = xo.init_weights(sizes, 77)
+    wt = wt * 3.0                                         # spread the pre-activations so that the arg-max is not a bias artefact
+    bt = np.random.default_rng(5).uniform(-0.4, 0.4, size=len(b))
+    d.set_params(wt, bt, net=1)
+    qsa, y = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+    want_y = np.empty(n)
+    want_q = np.empty(n)
+    arg = set()
+    for i in range(n):
+        want_q[i] = xo.nn_forward(sizes, w, b, xo.state_repr(xo.board_from(S[i])))[A[i]]
+        if D[i]:
+            want_y[i] = float(R[i])
+        else:
+            q2 = xo.nn_forward(sizes, wt, bt, xo.state_repr(xo.board_from(S2[i])))
+            arg.add(int(q2.argmax()))
+            want_y[i] = float(R[i]) + 0.99 * q2.max()
+    assert len(arg) > 20 and max(arg) >= 96              # the max really ranges over all 8100 outputs
+    assert np.abs(y - want_y).max() < QTOL and np.abs(qsa - want_q).max() < QTOL
+    env.close(); d.close()
