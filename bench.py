@@ -123,6 +123,8 @@ def main():
                     help="N > 1: assert that every rank ends with bit-identical parameters (diagnostic)")
     ap.add_argument("--env-only", action="store_true",
                     help="diagnostic: time only the fused self-play kernel with the uniform-random policy (no Q-network)")
+    ap.add_argument("--independent", action="store_true",
+                    help="BASELINE configs[2]: N > 1 ranks train independent replicas on their own game shards, no gradient all-reduce")
     ap.add_argument("--no-overlap", action="store_true",
                     help="queue collect and learn on one stream (collect -> learn -> apply) instead of running collect beside learn_grads")
     args = ap.parse_args()
@@ -174,9 +176,9 @@ def main():
         else:                   # collect is queued behind the column-max GEMM of learn_grads and runs beside the gradient chain
             t.learn_grads()
             t.collect()
-        if grads is not None:
+        if grads is not None and not args.independent:
             xd.allreduce_gradients(grads, world)
-        t.learn_apply(world)
+        t.learn_apply(1 if args.independent else world)
 
     for _ in range(args.warmup):
         one_step()
@@ -232,7 +234,9 @@ def main():
                        "schedule": "collect -> learn -> apply on one stream" if args.no_overlap else
                                    "collect(t) on its own stream beside learn_grads(t), both on theta_t; minibatch from the ring minus "
                                    "the slots collect(t) writes; apply joins both",
-                       "parallelism": f"dp{world} (games sharded, gradient all-reduce per update)" if world > 1 else "1 GPU"},
+                       "parallelism": ("1 GPU" if world == 1 else
+                                       f"{world} independent shards, no all-reduce (BASELINE configs[2])" if args.independent else
+                                       f"dp{world} (games sharded, gradient all-reduce per update)")},
         }
         g = stats.get("gemm_qmax_rowmax")
         if g and g["launches"]:

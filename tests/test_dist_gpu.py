@@ -39,6 +39,29 @@ def test_gradient_buffer_is_visible_to_torch_zero_copy():
     torch.cuda.set_stream(torch.cuda.default_stream())
 
 
+def _rehearse(extra):
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, XQ_FORCE_DEVICE="0", XQ_DIST_BACKEND="gloo")
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                           "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"] + extra,
+                          capture_output=True, text=True, env=env, cwd=root, timeout=600)
+
+
+def test_two_rank_independent_shards_on_one_gpu():
+    """BASELINE configs[2]: two ranks, own game shards, no all-reduce."""
+    import json
+    out = _rehearse(["--independent"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "independent shards" in line["config"]["parallelism"]
+
+
 def test_two_rank_rehearsal_on_one_gpu():
     """The whole N > 1 path of bench.py (game sharding, zero-copy gradient view, all-reduce per update, barriers, max-over-
     ranks timing) with two ranks pinned to the one GPU of the box and gloo standing in for RCCL; the replicas must end

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Runs ON the GPU box: one rocprofv3 --pmc pass of a short bench run, counters given as arguments.
+# usage: tools/pmc_pass.sh TAG COUNTER...     -> gpurun_out/pmc_TAG/
+set -e
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc "$@" --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-overlap > $OUT/bench.json 2> $OUT/err.txt
+ls $OUT/*/ | head
