@@ -165,6 +165,8 @@ def main():
                            seed=0x5EED, first_game_id=first, overlap_collect=0 if args.no_overlap else 1)
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
     grads = None
+    if world == 1 or args.independent:
+        t.dqn.set_fused_apply(True)          # nothing reads the gradient buffer between td_grads and apply_grads
     if world > 1:
         ptr, n = t.dqn.grad_buffer()
         grads = xd.wrap_device_floats(ptr, n)

@@ -116,6 +116,7 @@ PROTOTYPES = {
     "xq_dqn_td_update_host": [_vp, _i, _pu8, _pu8, _pi, _pf, _pu8, _i, _i, _d, _d, _pf, _pf],
     "xq_dqn_last_loss": [_vp, _pd],
     "xq_dqn_kernel_stats": [_vp, _i, C.POINTER(KernelStat), _i, _pi],
+    "xq_dqn_set_fused_apply": [_vp, _i],
     "xq_dqn_kernel_timeline": [_vp, C.POINTER(KernelSpan), _i, _pi],
     "xq_trainer_create": [C.POINTER(TrainerConfig), _vp, _pvp],
     "xq_trainer_destroy": [_vp],

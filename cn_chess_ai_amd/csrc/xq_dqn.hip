@@ -62,7 +62,9 @@ struct xq_dqn {
     size_t g_w0 = 0, g_wh[XQ_MAX_LAYERS] = {0}, g_wout = 0, g_bh[XQ_MAX_LAYERS] = {0}, g_bout = 0;
     float* grads_full = nullptr;
     float* slabs = nullptr;  size_t slabs_cap = 0;
-    float* slabs_l0 = nullptr;  size_t slabs_l0_cap = 0;     // layer-0 gradient partials (runs on the side stream)
+    float* slabs_l0 = nullptr;  size_t slabs_l0_cap = 0;     // layer-0 gradient partials
+    bool fused_apply = false;                   // xq_dqn_set_fused_apply: apply_grads may sum the layer-0 partials itself
+    int l0_pending = 0;                         // > 0: that many layer-0 slabs wait in slabs_l0, not yet reduced into grads_td
     float* bias_work = nullptr;  size_t bias_work_cap = 0;
     // dense API scratch
     float* xdense = nullptr;  size_t xdense_cap = 0;
@@ -493,7 +495,8 @@ struct SegTable {
     float* dst[16];
     const float* src[16];
     long long len[16];
-    int nseg;
+    int nslabs[16];            // > 0: src holds that many partial-sum slabs `len` apart; they are summed here, in the order of
+    int nseg;                  //      reduce_slabs_kernel (bit-identical to reducing first), instead of by a kernel of their own
 };
 // SGD: dst -= alpha * src per segment (updateWeightsBiasesKernel dqn.cu:310-319, batched form)
 __global__ void sgd_segments_kernel(SegTable t, float alpha) {
@@ -501,8 +504,25 @@ __global__ void sgd_segments_kernel(SegTable t, float alpha) {
     if (sgm >= t.nseg) return;
     float* d = t.dst[sgm];
     const float* s = t.src[sgm];
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < t.len[sgm]; i += (long long)gridDim.x * blockDim.x)
-        d[i] -= alpha * s[i];
+    const int nslabs = t.nslabs[sgm];
+    const long long len = t.len[sgm];
+    if (nslabs <= 0) {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
+            d[i] -= alpha * s[i];
+        return;
+    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = 0;
+        for (; z + 3 < nslabs; z += 4) {
+            s0 += s[(long long)z * len + i];
+            s1 += s[(long long)(z + 1) * len + i];
+            s2 += s[(long long)(z + 2) * len + i];
+            s3 += s[(long long)(z + 3) * len + i];
+        }
+        for (; z < nslabs; ++z) s0 += s[(long long)z * len + i];
+        d[i] -= alpha * ((s0 + s1) + (s2 + s3));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -806,7 +826,10 @@ static int l0_gradient(xq_dqn* d, int n, float* dst) {
                            chunk, nsets, out);
         XQ_HIP(hipGetLastError());
     }
-    if (nchunks > 1) {
+    d->l0_pending = 0;
+    if (nchunks > 1 && d->fused_apply) {
+        d->l0_pending = nchunks;                     // summed inside the SGD kernel: one kernel fewer on the critical chain
+    } else if (nchunks > 1) {
         ProfScope ps(d, "reduce_slabs", (double)nchunks * len, 4.0 * (nchunks + 1) * len);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)std::min<long long>((len + 255) / 256, 2048)), dim3(256), 0, d->cur,
                            d->slabs_l0, nchunks, len, len, dst);
@@ -1206,7 +1229,9 @@ int xq_dqn_apply_grads(xq_dqn* d, double lr, double grad_scale) {
     SegTable t; memset(&t, 0, sizeof t);
     const float* G = d->grads_td;
     int k = 0;
-    t.dst[k] = d->w0t(0); t.src[k] = G + d->g_w0; t.len[k] = (long long)d->L[0] * d->L[1]; ++k;
+    t.dst[k] = d->w0t(0); t.src[k] = G + d->g_w0; t.len[k] = (long long)d->L[0] * d->L[1];
+    if (d->l0_pending > 0) { t.src[k] = d->slabs_l0; t.nslabs[k] = d->l0_pending; d->l0_pending = 0; }
+    ++k;
     for (int l = 1; l + 1 < d->nl; ++l) { t.dst[k] = d->wl(0, l); t.src[k] = G + d->g_wh[l]; t.len[k] = (long long)d->L[l] * d->L[l + 1]; ++k; }
     t.dst[k] = d->wl(0, d->nl - 1); t.src[k] = G + d->g_wout; t.len[k] = 96LL * d->hlast(); ++k;
     // hidden biases are contiguous in both layouts
@@ -1214,6 +1239,13 @@ int xq_dqn_apply_grads(xq_dqn* d, double lr, double grad_scale) {
     t.dst[k] = d->bl(0, d->nl - 1); t.src[k] = G + d->g_bout; t.len[k] = 96; ++k;
     t.nseg = k;
     return sgd_apply(d, t, lr * grad_scale);
+}
+
+int xq_dqn_set_fused_apply(xq_dqn* d, int on) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    if (d->l0_pending > 0) return fail(XQ_ERR_RUNTIME, "xq_dqn_set_fused_apply: a TD step is waiting for its apply_grads");
+    d->fused_apply = on != 0;
+    return XQ_OK;
 }
 
 int xq_dqn_grad_buffer(xq_dqn* d, float** grads_dev, size_t* n_floats) {

@@ -179,6 +179,7 @@ int xq_trainer_step(xq_trainer* t, int n_iterations) {
     const int plies = t->cfg.collects_per_update > 1 ? t->cfg.collects_per_update : 1;
     if (plies > 1 && t->cfg.replay_capacity == 0)
         return fail(XQ_ERR_INVALID_ARGUMENT, "collects_per_update > 1 needs a replay ring (on-policy keeps one ply)");
+    XQ_TRY(xq_dqn_set_fused_apply(t->dqn, 1));      // single-GPU loop: nothing reads the gradient buffer between grads and apply
     for (int i = 0; i < n_iterations; ++i) {
         if (t->cstream) {
             XQ_TRY(xq_trainer_learn_grads(t));
@@ -189,6 +190,7 @@ int xq_trainer_step(xq_trainer* t, int n_iterations) {
         }
         XQ_TRY(xq_trainer_learn_apply(t, 1));
     }
+    XQ_TRY(xq_dqn_set_fused_apply(t->dqn, 0));
     return XQ_OK;
 }
 

@@ -165,6 +165,14 @@ class DQN:
                      bytes=arr[i].bytes) for i in range(n.value)]
 
 
+def _set_fused_apply(self, on=True):
+    """apply_grads sums the layer-0 gradient partials itself (single GPU: nothing reads the gradient buffer in between)."""
+    call("xq_dqn_set_fused_apply", self._h, 1 if on else 0)
+
+
+DQN.set_fused_apply = _set_fused_apply
+
+
 def _timeline(self, max_spans=8192):
     """(name, start_ms, end_ms) of every launch bracketed in the session closed by the last kernel_stats() call."""
     arr = (KernelSpan * max_spans)()

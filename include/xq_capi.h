@@ -201,6 +201,10 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards_dev, const uint32_t* next_
 int xq_dqn_apply_grads(xq_dqn* d, double learning_rate, double grad_scale);
 /* The flat gradient buffer xq_dqn_td_grads fills (fp32, *n_floats long) — what RCCL all-reduces over xGMI. */
 int xq_dqn_grad_buffer(xq_dqn* d, float** grads_dev, size_t* n_floats);
+/* on = 1: xq_dqn_apply_grads may sum the layer-0 gradient's partial sums itself (same order, bit-identical update, one
+ * kernel fewer); the layer-0 segment of the gradient buffer is then NOT filled by xq_dqn_td_grads.  Leave 0 (default) when
+ * anything reads the buffer between the two calls, e.g. a multi-GPU all-reduce. */
+int xq_dqn_set_fused_apply(xq_dqn* d, int on);
 /* Convenience: sample-free TD update straight from a replay ring (slots from the last xq_replay_sample). */
 int xq_dqn_td_grads_replay(xq_dqn* d, xq_replay* r, int batch, int td_net, int mode);
 /* Host-buffer TD step for tests: n transitions as 90-byte boards. Returns Q(s,a) and y per sample if non-NULL. */
