@@ -65,6 +65,8 @@ struct xq_dqn {
     float* slabs_l0 = nullptr;  size_t slabs_l0_cap = 0;     // layer-0 gradient partials
     bool fused_apply = false;                   // xq_dqn_set_fused_apply: apply_grads may sum the layer-0 partials itself
     int l0_pending = 0;                         // > 0: that many layer-0 slabs wait in slabs_l0, not yet reduced into grads_td
+    struct PendingSlab { const float* src = nullptr; int nslabs = 0; long long stride = 0; };
+    PendingSlab pend_hidden[XQ_MAX_LAYERS], pend_wout, pend_bout;   // same for the hidden / output-layer gradients (fused_apply)
     float* bias_work = nullptr;  size_t bias_work_cap = 0;
     // dense API scratch
     float* xdense = nullptr;  size_t xdense_cap = 0;
@@ -495,8 +497,9 @@ struct SegTable {
     float* dst[16];
     const float* src[16];
     long long len[16];
-    int nslabs[16];            // > 0: src holds that many partial-sum slabs `len` apart; they are summed here, in the order of
-    int nseg;                  //      reduce_slabs_kernel (bit-identical to reducing first), instead of by a kernel of their own
+    int nslabs[16];            // > 0: src holds that many partial-sum slabs `stride` apart; they are summed here, in the order
+    long long stride[16];      //      of reduce_slabs_kernel (bit-identical to reducing first), instead of by a kernel of their own
+    int nseg;
 };
 // SGD: dst -= alpha * src per segment (updateWeightsBiasesKernel dqn.cu:310-319, batched form)
 __global__ void sgd_segments_kernel(SegTable t, float alpha) {
@@ -505,7 +508,7 @@ __global__ void sgd_segments_kernel(SegTable t, float alpha) {
     float* d = t.dst[sgm];
     const float* s = t.src[sgm];
     const int nslabs = t.nslabs[sgm];
-    const long long len = t.len[sgm];
+    const long long len = t.len[sgm], st = t.stride[sgm];
     if (nslabs <= 0) {
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
             d[i] -= alpha * s[i];
@@ -515,12 +518,12 @@ __global__ void sgd_segments_kernel(SegTable t, float alpha) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int z = 0;
         for (; z + 3 < nslabs; z += 4) {
-            s0 += s[(long long)z * len + i];
-            s1 += s[(long long)(z + 1) * len + i];
-            s2 += s[(long long)(z + 2) * len + i];
-            s3 += s[(long long)(z + 3) * len + i];
+            s0 += s[(long long)z * st + i];
+            s1 += s[(long long)(z + 1) * st + i];
+            s2 += s[(long long)(z + 2) * st + i];
+            s3 += s[(long long)(z + 3) * st + i];
         }
-        for (; z < nslabs; ++z) s0 += s[(long long)z * len + i];
+        for (; z < nslabs; ++z) s0 += s[(long long)z * st + i];
         d[i] -= alpha * ((s0 + s1) + (s2 + s3));
     }
 }
@@ -746,22 +749,28 @@ static int pick_splits(int M, int N, int K) {
 
 // dst[M][N] = sum over the batch: A(m,k) B(k,n), split-K slabs + ordered reduction
 template <int AL>
-static int grad_gemm(xq_dqn* d, GemmArgs g, float* dst, const char* name) {
+static int grad_gemm(xq_dqn* d, GemmArgs g, float* dst, const char* name, float* slab_base = nullptr,
+                     xq_dqn::PendingSlab* defer = nullptr) {
     const bool big = false;    // 64-tiles: more tiles, fewer k-splits, cheaper ordered reduction
     int splits = pick_splits(g.M, g.N, g.K);
     const long long len = (long long)g.M * g.N;
+    float* slabs = slab_base;
     if (splits > 1) {
-        XQ_TRY(ensure_slabs(d, (size_t)splits * (size_t)len));
-        g.C = d->slabs; g.ldc = g.N; g.slab_stride = len;
+        if (!slabs) { XQ_TRY(ensure_slabs(d, (size_t)splits * (size_t)len)); slabs = d->slabs; }
+        g.C = slabs; g.ldc = g.N; g.slab_stride = len;
     } else {
         g.C = dst; g.ldc = g.N; g.slab_stride = 0;
     }
     int used = 0;
     XQ_TRY((launch_gemm<AL, L_MCONTIG, EPI_STORE>(d, g, splits, name, &used, !big, big)));
+    if (splits > 1 && defer) {             // summed by the SGD kernel (xq_dqn_set_fused_apply)
+        defer->src = slabs; defer->nslabs = used; defer->stride = len;
+        return XQ_OK;
+    }
     if (splits > 1) {
         ProfScope ps(d, "reduce_slabs", (double)used * len, 4.0 * (used + 1) * len);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)std::min<long long>((len + 255) / 256, 2048)), dim3(256), 0,
-                           d->cur, d->slabs, used, len, len, dst);
+                           d->cur, slabs, used, len, len, dst);
         XQ_HIP(hipGetLastError());
     }
     return XQ_OK;
@@ -1103,25 +1112,45 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
 static int side_gradients(xq_dqn* d, int n, float* const* outs, float* G) {
     const int nl = d->nl, Hl = d->hlast();
     BiasJobs bj;
+    const bool fused = d->fused_apply;
+    const int chunk = 1024;
+    const int nchunks = (n + chunk - 1) / chunk;
+    const long long len_out = 96LL * Hl + 96;
+    // fused_apply: every partial-sum slab of this step stays alive until the SGD kernel sums it => one region each
+    size_t off_out = 0, off_h[XQ_MAX_LAYERS] = {0}, need = 0;
+    if (fused) {
+        if (nchunks > 1) need += (size_t)nchunks * (size_t)len_out;
+        for (int l = nl - 2; l >= 1; --l) {
+            off_h[l] = need;
+            const int sp = pick_splits(d->L[l + 1], d->L[l], n);
+            if (sp > 1) need += (size_t)sp * (size_t)d->L[l + 1] * (size_t)d->L[l];
+        }
+        XQ_TRY(ensure_slabs(d, need));
+        for (int l = 0; l < XQ_MAX_LAYERS; ++l) d->pend_hidden[l] = xq_dqn::PendingSlab();
+        d->pend_wout = d->pend_bout = xq_dqn::PendingSlab();
+    }
     {   // output layer rows 0..95 + their biases: segmented sums by action
-        const int chunk = 1024;
-        const int nchunks = (n + chunk - 1) / chunk;
-        const long long len = 96LL * Hl + 96;
         float* dst = G + d->g_wout;                      // g_bout follows directly
         float* out = dst;
-        if (nchunks > 1) { XQ_TRY(ensure_slabs(d, (size_t)nchunks * (size_t)len)); out = d->slabs; }
+        if (nchunks > 1) {
+            if (fused) out = d->slabs + off_out;
+            else { XQ_TRY(ensure_slabs(d, (size_t)nchunks * (size_t)len_out)); out = d->slabs; }
+        }
         {
-            ProfScope ps(d, "out_grad_segsum", 2.0 * n * Hl, (double)n * (Hl * 4 + 8) + 4.0 * nchunks * len);
+            ProfScope ps(d, "out_grad_segsum", 2.0 * n * Hl, (double)n * (Hl * 4 + 8) + 4.0 * nchunks * len_out);
             const size_t shmem = (size_t)16 * Hl * sizeof(float) + (size_t)chunk * sizeof(uint16_t);
             if (shmem > 64 * 1024 || (Hl & 3)) return fail(XQ_ERR_INVALID_ARGUMENT, "last hidden layer width %d unsupported by the output-gradient kernel (multiple of 4, <= 960)", Hl);
             hipLaunchKernelGGL(out_grad_kernel, dim3(24, nchunks), dim3(256), shmem, d->cur, d->act_mb, d->dsc, outs[nl - 2], n, Hl,
                                chunk, out);
             XQ_HIP(hipGetLastError());
         }
-        if (nchunks > 1) {
-            ProfScope ps(d, "reduce_slabs", (double)nchunks * len, 4.0 * (nchunks + 1) * len);
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, d->cur, d->slabs, nchunks, len,
-                               len, dst);
+        if (nchunks > 1 && fused) {
+            d->pend_wout.src = out; d->pend_wout.nslabs = nchunks; d->pend_wout.stride = len_out;
+            d->pend_bout.src = out + 96LL * Hl; d->pend_bout.nslabs = nchunks; d->pend_bout.stride = len_out;
+        } else if (nchunks > 1) {
+            ProfScope ps(d, "reduce_slabs", (double)nchunks * len_out, 4.0 * (nchunks + 1) * len_out);
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len_out + 255) / 256)), dim3(256), 0, d->cur, out, nchunks, len_out,
+                               len_out, dst);
             XQ_HIP(hipGetLastError());
         }
     }
@@ -1132,7 +1161,8 @@ static int side_gradients(xq_dqn* d, int n, float* const* outs, float* G) {
         g.M = d->L[l + 1]; g.N = d->L[l]; g.K = n;
         g.A = d->deltas[l]; g.lda = d->L[l + 1];
         g.B = outs[l - 1]; g.ldb = d->L[l];
-        XQ_TRY((grad_gemm<L_MCONTIG>(d, g, G + d->g_wh[l], "gemm_grad_hidden")));
+        XQ_TRY((grad_gemm<L_MCONTIG>(d, g, G + d->g_wh[l], "gemm_grad_hidden", fused ? d->slabs + off_h[l] : nullptr,
+                                     fused ? &d->pend_hidden[l] : nullptr)));
         bj.add(d->deltas[l], d->L[l + 1], d->L[l + 1], G + d->g_bh[l]);
     }
     bj.add(d->deltas[0], d->L[1], d->L[1], G + d->g_bh[0]);
@@ -1229,21 +1259,30 @@ int xq_dqn_apply_grads(xq_dqn* d, double lr, double grad_scale) {
     SegTable t; memset(&t, 0, sizeof t);
     const float* G = d->grads_td;
     int k = 0;
+    auto take = [&](xq_dqn::PendingSlab& p) {
+        if (p.nslabs > 0) { t.src[k] = p.src; t.nslabs[k] = p.nslabs; t.stride[k] = p.stride; }
+        p = xq_dqn::PendingSlab();
+    };
     t.dst[k] = d->w0t(0); t.src[k] = G + d->g_w0; t.len[k] = (long long)d->L[0] * d->L[1];
-    if (d->l0_pending > 0) { t.src[k] = d->slabs_l0; t.nslabs[k] = d->l0_pending; d->l0_pending = 0; }
+    if (d->l0_pending > 0) { t.src[k] = d->slabs_l0; t.nslabs[k] = d->l0_pending; t.stride[k] = t.len[k]; d->l0_pending = 0; }
     ++k;
-    for (int l = 1; l + 1 < d->nl; ++l) { t.dst[k] = d->wl(0, l); t.src[k] = G + d->g_wh[l]; t.len[k] = (long long)d->L[l] * d->L[l + 1]; ++k; }
-    t.dst[k] = d->wl(0, d->nl - 1); t.src[k] = G + d->g_wout; t.len[k] = 96LL * d->hlast(); ++k;
+    for (int l = 1; l + 1 < d->nl; ++l) {
+        t.dst[k] = d->wl(0, l); t.src[k] = G + d->g_wh[l]; t.len[k] = (long long)d->L[l] * d->L[l + 1];
+        take(d->pend_hidden[l]);
+        ++k;
+    }
+    t.dst[k] = d->wl(0, d->nl - 1); t.src[k] = G + d->g_wout; t.len[k] = 96LL * d->hlast(); take(d->pend_wout); ++k;
     // hidden biases are contiguous in both layouts
     t.dst[k] = d->bl(0, 0); t.src[k] = G + d->g_bh[0]; t.len[k] = (long long)(d->bo[d->nl - 1]); ++k;
-    t.dst[k] = d->bl(0, d->nl - 1); t.src[k] = G + d->g_bout; t.len[k] = 96; ++k;
+    t.dst[k] = d->bl(0, d->nl - 1); t.src[k] = G + d->g_bout; t.len[k] = 96; take(d->pend_bout); ++k;
     t.nseg = k;
     return sgd_apply(d, t, lr * grad_scale);
 }
 
 int xq_dqn_set_fused_apply(xq_dqn* d, int on) {
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
-    if (d->l0_pending > 0) return fail(XQ_ERR_RUNTIME, "xq_dqn_set_fused_apply: a TD step is waiting for its apply_grads");
+    if (d->l0_pending > 0 || d->pend_wout.nslabs > 0)
+        return fail(XQ_ERR_RUNTIME, "xq_dqn_set_fused_apply: a TD step is waiting for its apply_grads");
     d->fused_apply = on != 0;
     return XQ_OK;
 }
