@@ -193,31 +193,51 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* acc = smem;                                  // [nsets][14][H]
     uint16_t* list = reinterpret_cast<uint16_t*>(smem + (long long)nsets * 14 * H);   // [chunk] (b_local | piece << 11)
-    __shared__ int wcount[4];
-    __shared__ int total;
     const int s = (int)blockIdx.x;
     const int c0 = (int)blockIdx.y * chunk;
     const int c1 = min(n, c0 + chunk);
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int i = tid; i < nsets * 14 * H; i += 256) acc[i] = 0.f;
-    if (tid == 0) total = 0;
-    __syncthreads();
-    // phase 1: ordered compaction of the occupied samples
-    for (int base = c0; base < c1; base += 256) {
-        const int b = base + tid;
+    // the chunk's piece codes first (up to 8 independent loads per thread in flight), accumulator zeroing under their latency
+    constexpr int kMaxIters = 8;                         // chunk <= 2048
+    uint32_t nibs = 0;
+#pragma unroll
+    for (int it = 0; it < kMaxIters; ++it) {
+        const int b = c0 + it * 256 + tid;
         uint32_t nib = 0;
         if (b < c1) nib = (gboards[(long long)b * kBoardWords + (s >> 3)] >> (4 * (s & 7))) & 15u;
-        const unsigned long long m = __ballot(nib != 0);
-        if (lane == 0) wcount[wid] = __popcll(m);
-        __syncthreads();
-        int off = total;
-        for (int w = 0; w < wid; ++w) off += wcount[w];
-        if (nib) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((b - c0) | (nib << 11));
-        __syncthreads();
-        if (tid == 0) total += wcount[0] + wcount[1] + wcount[2] + wcount[3];
-        __syncthreads();
+        nibs |= nib << (4 * it);
     }
-    const int cnt = total;
+    if (((nsets * 14 * H) & 3) == 0) {
+        float4* a4 = reinterpret_cast<float4*>(acc);
+        for (int i = tid; i < nsets * 14 * H / 4; i += 256) a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (int i = tid; i < nsets * 14 * H; i += 256) acc[i] = 0.f;
+    }
+    // phase 1: ordered compaction of the occupied samples with two barriers in all: the per-wave counts of every round are
+    // published first, the offsets are then prefix sums over (round, wave) that every thread computes for itself
+    __shared__ int wc[kMaxIters][4];
+    const int iters = (c1 - c0 + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < kMaxIters; ++it) {
+        const uint32_t nib = (nibs >> (4 * it)) & 15u;
+        const unsigned long long m = __ballot(nib != 0);
+        if (lane == 0) wc[it][wid] = __popcll(m);
+    }
+    __syncthreads();
+    int off = 0;
+#pragma unroll
+    for (int it = 0; it < kMaxIters; ++it) {
+        if (it < iters) {
+            const uint32_t nib = (nibs >> (4 * it)) & 15u;
+            const unsigned long long m = __ballot(nib != 0);
+            int o = off;
+            for (int w = 0; w < wid; ++w) o += wc[it][w];
+            if (nib) list[o + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((it * 256 + tid) | (nib << 11));
+        }
+        off += wc[it][0] + wc[it][1] + wc[it][2] + wc[it][3];
+    }
+    __syncthreads();
+    const int cnt = off;
     // phase 2: wave w streams list entries w, w+nsets, ... (whole 1-KB rows as float4 per lane, 16 rows in flight per
     // wave) into ITS OWN accumulator set; the sets are added in fixed order afterwards => bitwise reproducible
     if (wid < nsets && (H & 3) == 0) {
