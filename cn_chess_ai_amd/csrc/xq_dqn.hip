@@ -243,6 +243,18 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
     if (wid < nsets && (H & 3) == 0) {
         float* my = acc + (long long)wid * 14 * H;
         for (int col = lane * 4; col < H; col += 256) {
+            // rows of the same piece arrive in runs (a square mostly holds one or two piece kinds): a run is summed in
+            // registers and touches its LDS accumulator once, instead of one read-modify-write round trip per row
+            int cur = 0;                                   // piece code of the open run (wave-uniform), 0 = none
+            float rx = 0.f, ry = 0.f, rz = 0.f, rw = 0.f;
+            auto flush = [&]() {
+                if (cur != 0) {
+                    float4* a = reinterpret_cast<float4*>(my + (cur - 1) * H + col);
+                    float4 t = *a;
+                    t.x += rx; t.y += ry; t.z += rz; t.w += rw;
+                    *a = t;
+                }
+            };
             int i = wid;
             for (; i + 15 * nsets < cnt; i += 16 * nsets) {
                 int e[16];
@@ -255,20 +267,19 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
                 }
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    float4* a = reinterpret_cast<float4*>(my + ((e[u] >> 11) - 1) * H + col);
-                    float4 t = *a;
-                    t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w;
-                    *a = t;
+                    const int p = __builtin_amdgcn_readfirstlane(e[u] >> 11);
+                    if (p != cur) { flush(); cur = p; rx = v[u].x; ry = v[u].y; rz = v[u].z; rw = v[u].w; }
+                    else { rx += v[u].x; ry += v[u].y; rz += v[u].z; rw += v[u].w; }
                 }
             }
             for (; i < cnt; i += nsets) {
                 const int e1 = list[i];
                 const float4 x = *reinterpret_cast<const float4*>(delta0 + (long long)(c0 + (e1 & 2047)) * H + col);
-                float4* a = reinterpret_cast<float4*>(my + ((e1 >> 11) - 1) * H + col);
-                float4 t = *a;
-                t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
-                *a = t;
+                const int p = __builtin_amdgcn_readfirstlane(e1 >> 11);
+                if (p != cur) { flush(); cur = p; rx = x.x; ry = x.y; rz = x.z; rw = x.w; }
+                else { rx += x.x; ry += x.y; rz += x.z; rw += x.w; }
             }
+            flush();
         }
     } else if ((H & 3) != 0 && wid == 0) {
         for (int col = lane; col < H; col += 64)
