@@ -36,16 +36,14 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 ENV_BYTES_PER_GAME = 2 * (48 + 16) + 360 + 105   # board+meta r/w, Q row, transition record
 
 
-def cpu_baseline(seconds=15.0):
-    """CPU port of the reference loop (oracle/xq_oracle.c: xqo_train_episode = chessai.cpp:90-167 with the
-    {1260,128,8100} fp64 net, batch 1, bug-compatible backprop) on one host core, bounded to ~`seconds`."""
+def cpu_train_loop(seconds):
+    """(plies, episodes, elapsed) of the CPU port of ChessAI::train run for ~`seconds` on the calling core."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
     import xqoracle as xo
     L = xo.lib()
     sizes = xo.sizes_arr([1260, 128, 8100])
     w, b = xo.init_weights([1260, 128, 8100], 1)
-    rng = C.c_uint64(12345)
+    rng = C.c_uint64(12345 + os.getpid())
     st = xo.EpisodeStats()
     steps, episodes = 0, 0
     t0 = time.perf_counter()
@@ -54,10 +52,33 @@ def cpu_baseline(seconds=15.0):
                             b.ctypes.data_as(C.POINTER(C.c_double)), 0.001, 0.99, 0.1, C.byref(rng), 0, C.byref(st))
         steps += st.steps
         episodes += 1
-    el = time.perf_counter() - t0
+    return steps, episodes, time.perf_counter() - t0
+
+
+def cpu_all_cores(seconds=8.0):
+    """T independent instances of the same loop, T = the box's CPU share, for an all-cores figure."""
+    T = max(1, min(len(os.sched_getaffinity(0)), 16))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds)], stdout=subprocess.PIPE,
+                              text=True) for _ in range(T)]
+    total = 0.0
+    for p in procs:
+        out, _ = p.communicate(timeout=seconds * 6 + 60)
+        steps, _, el = json.loads(out.strip().splitlines()[-1])
+        total += steps / el
+    return {"value": total, "cores": T, "sample": f"{T} independent instances x {seconds:.0f} s"}
+
+
+def cpu_baseline(seconds=15.0):
+    """CPU port of the reference loop (oracle/xq_oracle.c: xqo_train_episode = chessai.cpp:90-167 with the
+    {1260,128,8100} fp64 net, batch 1, bug-compatible backprop) on one host core, bounded to ~`seconds`."""
+    steps, episodes, el = cpu_train_loop(seconds)
     out = {"value": steps / el, "unit": "env steps/s (= DQN updates/s, batch 1)", "cores": 1, "kind": "port",
            "sample": f"{episodes} episodes / {steps} plies of the ChessAI::train restatement, net 1260-128-8100 fp64, "
                      f"{el:.1f} s on one host core"}
+    try:
+        out["all_cores"] = cpu_all_cores()
+    except Exception as e:
+        out["all_cores_error"] = str(e)[:120]
     ref = os.path.join(ROOT, "oracle", "_ref", "xqref")
     if os.path.exists(ref):     # the real reference rules engine (env only: movegen + movePiece), when it travelled
         try:
@@ -116,6 +137,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # one instance of cpu_all_cores()
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with HIP events (diagnostic)")
     ap.add_argument("--games", type=int, default=N_GAMES, help="games per GPU (default = BASELINE's 8192; other values are diagnostic)")
     ap.add_argument("--minibatch", type=int, default=0, help="transitions per update (default = games per GPU)")
@@ -128,6 +150,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="queue collect and learn on one stream (collect -> learn -> apply) instead of running collect beside learn_grads")
     args = ap.parse_args()
+    if args.cpu_worker > 0:                      # child of cpu_all_cores(): CPU only, never touches the GPU
+        print(json.dumps(cpu_train_loop(args.cpu_worker)), flush=True)
+        return
 
     import torch
     import cn_chess_ai_amd as xq
