@@ -907,6 +907,9 @@ using namespace xq;
 // =================================================================================================================
 extern "C" {
 
+static int dqn_init(xq_dqn* d, const int* layer_sizes, int n_sizes, double learning_rate, double gamma, uint64_t seed,
+                    void* hip_stream);
+
 int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, double gamma, uint64_t seed, void* hip_stream,
                   xq_dqn** out) {
     if (!out || !layer_sizes) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_create: null pointer");
@@ -919,6 +922,14 @@ int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, dou
     XQ_TRY(xq_device_count(&c));
     if (c == 0) return fail(XQ_ERR_NO_DEVICE, "no HIP device: libxqhip has no CPU fallback");
     xq_dqn* d = new xq_dqn();
+    const int rc = dqn_init(d, layer_sizes, n_sizes, learning_rate, gamma, seed, hip_stream);
+    if (rc != XQ_OK) { xq_dqn_destroy(d); return rc; }      // a failed allocation must not leak the ones before it
+    *out = d;
+    return XQ_OK;
+}
+
+static int dqn_init(xq_dqn* d, const int* layer_sizes, int n_sizes, double learning_rate, double gamma, uint64_t seed,
+                    void* hip_stream) {
     d->ns = n_sizes; d->nl = n_sizes - 1;
     for (int i = 0; i < n_sizes; ++i) d->L[i] = layer_sizes[i];
     for (int l = 0; l < d->nl; ++l) {                       // offsets, dqn.cu:125-140
@@ -957,7 +968,6 @@ int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, dou
     std::mt19937_64 gen(seed);
     std::uniform_real_distribution<double> dis(-0.05, 0.05);
     for (size_t i = 0; i < d->nw; ++i) w[i] = dis(gen);
-    *out = d;
     XQ_TRY(xq_dqn_set_params(d, XQ_NET_ONLINE, w.data(), b.data()));
     return xq_dqn_update_target(d);                          // DQN ctor, dqn.cpp:18
 }

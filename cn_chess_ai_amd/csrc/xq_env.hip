@@ -354,12 +354,7 @@ int xq_event_elapsed_ms(void* a, void* b, float* ms) {
     return XQ_OK;
 }
 
-int xq_env_create(int n_games, uint64_t seed, uint32_t first_game_id, void* hip_stream, xq_env** out) {
-    if (!out || n_games <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_env_create: n_games must be > 0");
-    int c = 0;
-    XQ_TRY(xq_device_count(&c));
-    if (c == 0) return fail(XQ_ERR_NO_DEVICE, "no HIP device: libxqhip has no CPU fallback");
-    xq_env* e = new xq_env();
+static int env_init(xq_env* e, int n_games, uint64_t seed, uint32_t first_game_id, void* hip_stream) {
     e->n = n_games;
     e->seed = seed;
     e->first_id = first_game_id;
@@ -379,8 +374,19 @@ int xq_env_create(int n_games, uint64_t seed, uint32_t first_game_id, void* hip_
     XQ_HIP(hipMalloc(&e->ep_ring, (size_t)e->ep_cap * sizeof(xq_episode_record)));
     XQ_HIP(hipMalloc(&e->ep_head, sizeof(unsigned long long)));
     XQ_TRY(upload_start_words(e->stream));
-    *out = e;
     return xq_env_reset(e);
+}
+
+int xq_env_create(int n_games, uint64_t seed, uint32_t first_game_id, void* hip_stream, xq_env** out) {
+    if (!out || n_games <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_env_create: n_games must be > 0");
+    int c = 0;
+    XQ_TRY(xq_device_count(&c));
+    if (c == 0) return fail(XQ_ERR_NO_DEVICE, "no HIP device: libxqhip has no CPU fallback");
+    xq_env* e = new xq_env();
+    const int rc = env_init(e, n_games, seed, first_game_id, hip_stream);
+    if (rc != XQ_OK) { xq_env_destroy(e); return rc; }      // a failed allocation must not leak the ones before it
+    *out = e;
+    return XQ_OK;
 }
 
 int xq_env_destroy(xq_env* e) {

@@ -37,12 +37,21 @@ using namespace xq;
 
 extern "C" {
 
+static int replay_init(xq_replay* r, int capacity, uint64_t seed, void* hip_stream);
+
 int xq_replay_create(int capacity, uint64_t seed, void* hip_stream, xq_replay** out) {
     if (!out || capacity <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_replay_create: capacity must be > 0");
     int c = 0;
     XQ_TRY(xq_device_count(&c));
     if (c == 0) return fail(XQ_ERR_NO_DEVICE, "no HIP device: libxqhip has no CPU fallback");
     xq_replay* r = new xq_replay();
+    const int rc = replay_init(r, capacity, seed, hip_stream);
+    if (rc != XQ_OK) { xq_replay_destroy(r); return rc; }   // a failed allocation must not leak the ones before it
+    *out = r;
+    return XQ_OK;
+}
+
+static int replay_init(xq_replay* r, int capacity, uint64_t seed, void* hip_stream) {
     r->seed = seed;
     if (hip_stream) r->stream = (hipStream_t)hip_stream;
     else { XQ_HIP(hipStreamCreate(&r->stream)); r->own_stream = true; }
@@ -58,7 +67,6 @@ int xq_replay_create(int capacity, uint64_t seed, void* hip_stream, xq_replay** 
     XQ_HIP(hipMemsetAsync(r->dev.next_boards, 0, n * kBoardWords * sizeof(uint32_t), r->stream));
     XQ_HIP(hipMemsetAsync(r->dev.reward, 0, n * sizeof(float), r->stream));
     XQ_HIP(hipMemsetAsync(r->dev.done, 0, n, r->stream));
-    *out = r;
     return XQ_OK;
 }
 

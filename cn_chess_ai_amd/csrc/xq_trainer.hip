@@ -35,6 +35,8 @@ using namespace xq;
 
 extern "C" {
 
+static int trainer_init(xq_trainer* t, const xq_trainer_config* cfg, void* hip_stream);
+
 int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer** out) {
     if (!cfg || !out) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_trainer_create: null pointer");
     if (cfg->n_games <= 0 || cfg->n_sizes < 3 || cfg->n_sizes > XQ_MAX_LAYERS + 1)
@@ -48,6 +50,13 @@ int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer
     XQ_TRY(xq_device_count(&ndev));
     if (ndev == 0) return fail(XQ_ERR_NO_DEVICE, "no HIP device: libxqhip has no CPU fallback");
     xq_trainer* t = new xq_trainer();
+    const int rc = trainer_init(t, cfg, hip_stream);
+    if (rc != XQ_OK) { xq_trainer_destroy(t); return rc; }  // a failed allocation must not leak the handles before it
+    *out = t;
+    return XQ_OK;
+}
+
+static int trainer_init(xq_trainer* t, const xq_trainer_config* cfg, void* hip_stream) {
     t->cfg = *cfg;
     if (hip_stream) t->stream = (hipStream_t)hip_stream;
     else { XQ_HIP(hipStreamCreate(&t->stream)); t->own_stream = true; }
@@ -67,7 +76,6 @@ int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer
         XQ_HIP(hipEventCreateWithFlags(&t->ev_collect, hipEventDisableTiming));
         XQ_HIP(hipEventRecord(t->ev_params, t->stream));      // orders the first collect after the handles' initialisation
     }
-    *out = t;
     return XQ_OK;
 }
 
@@ -75,7 +83,9 @@ int xq_trainer_destroy(xq_trainer* t) {
     if (!t) return XQ_OK;
     if (t->cstream) hipStreamSynchronize(t->cstream);
     hipStreamSynchronize(t->stream);
-    if (t->cstream) { hipStreamDestroy(t->cstream); hipEventDestroy(t->ev_params); hipEventDestroy(t->ev_collect); }
+    if (t->cstream) hipStreamDestroy(t->cstream);
+    if (t->ev_params) hipEventDestroy(t->ev_params);
+    if (t->ev_collect) hipEventDestroy(t->ev_collect);
     xq_env_destroy(t->env);
     xq_dqn_destroy(t->dqn);
     xq_replay_destroy(t->replay);
