@@ -29,6 +29,8 @@ struct xq_trainer {
     int inflight = 0;                       // ring slots written by collects since the last learn_apply
     bool grads_queued = false;              // learn_grads already queued in this iteration: collect starts behind its big GEMM
     int prepaid_collects = 0;               // collects learn_grads had to run itself (empty ring), owed to the next collect() calls
+    int excluded = 0;                       // ring slots the queued learn_grads left out of its minibatch (from write_pos - inflight)
+    hipEvent_t ev_grads = nullptr;          // main: the queued learn_grads has finished reading the ring
 };
 
 using namespace xq;
@@ -74,6 +76,7 @@ static int trainer_init(xq_trainer* t, const xq_trainer_config* cfg, void* hip_s
         XQ_HIP(hipStreamCreateWithPriority(&t->cstream, hipStreamNonBlocking, lo));   // the TD step is the critical path
         XQ_HIP(hipEventCreateWithFlags(&t->ev_params, hipEventDisableTiming));
         XQ_HIP(hipEventCreateWithFlags(&t->ev_collect, hipEventDisableTiming));
+        XQ_HIP(hipEventCreateWithFlags(&t->ev_grads, hipEventDisableTiming));
         XQ_HIP(hipEventRecord(t->ev_params, t->stream));      // orders the first collect after the handles' initialisation
     }
     return XQ_OK;
@@ -86,6 +89,7 @@ int xq_trainer_destroy(xq_trainer* t) {
     if (t->cstream) hipStreamDestroy(t->cstream);
     if (t->ev_params) hipEventDestroy(t->ev_params);
     if (t->ev_collect) hipEventDestroy(t->ev_collect);
+    if (t->ev_grads) hipEventDestroy(t->ev_grads);
     xq_env_destroy(t->env);
     xq_dqn_destroy(t->dqn);
     xq_replay_destroy(t->replay);
@@ -106,6 +110,9 @@ static int collect_impl(xq_trainer* t) {
         on = t->cstream;
         if (t->inflight == 0) XQ_HIP(hipStreamWaitEvent(on, t->ev_params, 0));
         if (t->grads_queued && t->inflight == 0) XQ_HIP(hipStreamWaitEvent(on, dqn_qmax_event(t->dqn), 0));
+        // more plies than the queued learn_grads excluded from its minibatch (caller mixed the orders): these slots may be
+        // among the ones it samples, so they can only be overwritten once it has read them
+        if (t->grads_queued && t->inflight + t->env->n > t->excluded) XQ_HIP(hipStreamWaitEvent(on, t->ev_grads, 0));
     }
     hipStream_t s = on ? on : t->stream;
     XQ_TRY(dqn_q90_boards(t->dqn, t->env->boards, t->env->n, &q90, &stride, on));
@@ -158,11 +165,15 @@ int xq_trainer_learn_grads(xq_trainer* t) {
                 XQ_HIP(hipStreamWaitEvent(t->stream, t->ev_collect, 0));
                 t->inflight = 0;
                 start = 0; count = -1;
+                t->excluded = 0;
+            } else {
+                t->excluded = m;
             }
         }
         XQ_TRY(replay_sample_implicit(t->replay, batch, start, count));     // no sampling kernel: the consumers recompute the slots
     }
     XQ_TRY(xq_dqn_td_grads_replay(t->dqn, t->replay, batch, t->cfg.td_net, t->cfg.backprop_mode));
+    if (t->cstream) XQ_HIP(hipEventRecord(t->ev_grads, t->stream));
     t->grads_queued = true;
     return XQ_OK;
 }

@@ -212,3 +212,48 @@ def test_sample_window_matches_the_oracle_philox(xq):
     with pytest.raises(xq.XqError):
         rp.sample_window(8, 0, 41)
     rp.close()
+
+
+def test_overlapped_trainer_mixed_call_order(xq):
+    """collect, learn_grads, collect, learn_apply: the second collect overwrites ring slots the queued minibatch may contain
+    (the ring is small and full), so the trainer has to hold it back until learn_grads has read them.  Compared bit for bit
+    with the same sequence composed from synchronous C-ABI calls."""
+    import torch
+    n, cap, minibatch, iters, seed, first, sizes = 64, 192, 96, 8, 5, 3, CFG2_NET
+    cfg = xq.TrainerConfig(n_games=n, layer_sizes=sizes, learning_rate=0.01, gamma=0.99, epsilon=0.2, replay_capacity=cap,
+                           minibatch=minibatch, td_net=1, backprop_mode=0, target_sync_interval=0, mean_gradient=1, seed=seed,
+                           first_game_id=first, overlap_collect=1)
+    t = xq.Trainer(cfg)
+    w0, b0 = t.dqn.get_params()
+    for _ in range(iters):
+        t.collect(); t.learn_grads(); t.collect(); t.learn_apply(1)
+    tw, tb = t.dqn.get_params()
+    tboards, tmeta = t.env.get_state()
+
+    env = xq.VecEnv(n, seed=seed, first_game_id=first)
+    d = xq.DQN(sizes, 0.01, 0.99, seed=1)
+    d.set_params(w0, b0); d.updateTargetNetwork()
+    rp = xq.ReplayBuffer(cap, seed=seed + 0x1234567 + first)
+
+    def collect():
+        q = d.q_boards(env, 96)
+        env.selfplay_step_dev(q.data_ptr(), 96, 0.2, replay=rp)
+        torch.cuda.synchronize()
+
+    for it in range(iters):
+        size0, _, total0 = rp.stats()
+        collect()
+        start, count = overlap_window(size0, total0, cap, n)      # the ring minus the first collect's slots
+        if count <= 0:
+            rp.sample(minibatch)
+        else:
+            rp.sample_window(minibatch, start, count)
+        d.td_grads_replay(rp, minibatch, td_net=1, mode=0)
+        torch.cuda.synchronize()
+        collect()
+        d.apply_grads(0.01, 1.0 / minibatch)
+    w, b = d.get_params()
+    boards, meta = env.get_state()
+    assert np.array_equal(boards, tboards) and np.array_equal(meta, tmeta)
+    assert np.array_equal(w, tw) and np.array_equal(b, tb)
+    t.close(); env.close(); d.close(); rp.close()
