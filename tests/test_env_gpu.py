@@ -301,3 +301,24 @@ def test_replay_ring_wraps_and_skips_empty_transitions(xq):
         if not d:
             assert np.array_equal(nb, snaps[t][1][g])
     env.close(); rp.close()
+
+
+def test_game_id_sharding_at_config5_size(xq):
+    """131 072 games in one env (BASELINE configs[4] size) vs small envs created with first_game_id offsets: a game's
+    trajectory depends only on (seed, game id, ply), so any shard of the big batch must equal the same ids stepped alone —
+    the property the multi-GPU sharding (cn_chess_ai_amd/dist.py::shard_games) relies on."""
+    n_big, plies = 131072, 60
+    big = xq.VecEnv(n_big, seed=0xC0FFEE)
+    for _ in range(plies):
+        big.selfplay_step_dev()
+    bb, bm = big.get_state()
+    cb = big.counters()
+    assert cb["plies"] == n_big * plies
+    for first in (0, 8192 * 7 + 5, n_big - 64):
+        small = xq.VecEnv(64, seed=0xC0FFEE, first_game_id=first)
+        for _ in range(plies):
+            small.selfplay_step_dev()
+        sb, sm = small.get_state()
+        assert np.array_equal(sb, bb[first:first + 64]) and np.array_equal(sm, bm[first:first + 64])
+        small.close()
+    big.close()
