@@ -201,18 +201,19 @@ int xq_trainer_step(xq_trainer* t, int n_iterations) {
     if (plies > 1 && t->cfg.replay_capacity == 0)
         return fail(XQ_ERR_INVALID_ARGUMENT, "collects_per_update > 1 needs a replay ring (on-policy keeps one ply)");
     XQ_TRY(xq_dqn_set_fused_apply(t->dqn, 1));      // single-GPU loop: nothing reads the gradient buffer between grads and apply
-    for (int i = 0; i < n_iterations; ++i) {
+    int rc = XQ_OK;
+    for (int i = 0; i < n_iterations && rc == XQ_OK; ++i) {
         if (t->cstream) {
-            XQ_TRY(xq_trainer_learn_grads(t));
-            for (int c = 0; c < plies; ++c) XQ_TRY(xq_trainer_collect(t));
+            rc = xq_trainer_learn_grads(t);
+            for (int c = 0; c < plies && rc == XQ_OK; ++c) rc = xq_trainer_collect(t);
         } else {
-            for (int c = 0; c < plies; ++c) XQ_TRY(xq_trainer_collect(t));
-            XQ_TRY(xq_trainer_learn_grads(t));
+            for (int c = 0; c < plies && rc == XQ_OK; ++c) rc = xq_trainer_collect(t);
+            if (rc == XQ_OK) rc = xq_trainer_learn_grads(t);
         }
-        XQ_TRY(xq_trainer_learn_apply(t, 1));
+        if (rc == XQ_OK) rc = xq_trainer_learn_apply(t, 1);
     }
-    XQ_TRY(xq_dqn_set_fused_apply(t->dqn, 0));
-    return XQ_OK;
+    const int rc_off = xq_dqn_set_fused_apply(t->dqn, 0);     // also after a failed iteration
+    return rc != XQ_OK ? rc : rc_off;
 }
 
 int xq_trainer_counters(xq_trainer* t, uint64_t* env_steps, uint64_t* updates, uint64_t* episodes) {
