@@ -297,7 +297,10 @@ def main():
             line["kernels"] = {k: {"ms_per_launch": v["ms"] / max(v["launches"], 1), "launches": v["launches"]}
                                for k, v in stats.items()}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:           # never lose the measured line to the reporting leg
+                line["cpu_baseline"] = {"value": None, "unit": "env steps/s", "cores": 0, "kind": "port", "sample": "failed: " + str(e)[:160]}
         print(json.dumps(line), flush=True)
     t.close()
     if world > 1:
