@@ -84,6 +84,8 @@ PROTOTYPES = {
     "xq_env_legal_moves_dev": [_vp, _i, _vp, _vp],
     "xq_env_valid_matrix": [_vp, _i, _pu8],
     "xq_env_get_winner": [_vp, _i, _i, _pu8],
+    "xq_env_rule_matrix": [_vp, _i, _pu8],
+    "xq_env_rule_query": [_vp, _i, _i, _i, _i, _i, _i, _pi],
     "xq_env_step": [_vp, _pi, _i, C.POINTER(StepResult)],
     "xq_env_selfplay_step": [_vp, _vp, _i, _u32, _vp, _vp],
     "xq_env_selfplay_step_host": [_vp, _pf, _u32, C.POINTER(StepResult)],

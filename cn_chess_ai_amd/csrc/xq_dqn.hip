@@ -4,7 +4,7 @@
 // cudaMalloc/H2D/launch/sync/D2H round trip per layer).  Here the whole TD step of a minibatch stays in HBM:
 //   layer 0      : the 1260-wide one-hot input (chessai.cpp:268-289) is never built — rows of W0^T are gathered by
 //                  (square, piece) straight from the packed board (<= 32 rows of 1 KB per sample, L2-resident);
-//   hidden / Q   : xq_gemm.cuh MFMA GEMMs with fused bias+tanh;
+//   hidden / Q   : xq_gemm.hip.h MFMA GEMMs with fused bias+tanh;
 //   max_a' Q(s') : the 8100-wide output GEMM never writes Q — its epilogue reduces max(z) per row (tanh is monotone);
 //   backward     : the TD target equals Q(s) except at action.to < 90 (chessai.cpp:122-128), so the output delta
 //                  lives in columns 0..95: delta GEMM with K = 96, weight-gradient GEMM with M = 96;
@@ -15,7 +15,7 @@
 // bug-compatible hidden delta (dqn.cu:406-423 as written: wrong stride, reads across layer boundaries) be expressed
 // as the same GEMM with a different base/leading dimension.
 #include "xq_internal.h"
-#include "xq_gemm.cuh"
+#include "xq_gemm.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -87,6 +87,7 @@ struct xq_dqn {
 namespace xq {
 
 Profiler* dqn_profiler(xq_dqn* d) { return &d->prof; }
+int dqn_fused_apply(const xq_dqn* d) { return d->fused_apply ? 1 : 0; }
 hipStream_t dqn_stream(xq_dqn* d) { return d->stream; }
 hipEvent_t dqn_qmax_event(xq_dqn* d) { return d->ev_qmax; }
 
@@ -1361,6 +1362,8 @@ int xq_dqn_td_update_host(xq_dqn* d, int n, const uint8_t* boards90, const uint8
                           float* q_sa_out, float* y_out) {
     if (!d || n <= 0 || !boards90 || !next_boards90 || !action_to || !reward || !done)
         return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_td_update_host: bad argument");
+    for (size_t i = 0; i < (size_t)n * 90; ++i)       // code 15 would index one-hot plane 14 of 14 in the layer-0 kernels
+        if (boards90[i] > 14 || next_boards90[i] > 14) return fail(XQ_ERR_INVALID_ARGUMENT, "piece code > 14");
     if ((size_t)n > d->hb_cap) {
         XQ_HIP(hipStreamSynchronize(d->stream));
         hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);

@@ -6,7 +6,7 @@
 // the self-play path.  HBM traffic per game and ply: board 48 B + meta 16 B read and written,
 // 360 B of Q-values read, one transition record (48+48+4+4+1 B) written.
 #include "xq_internal.h"
-#include "xq_rules.cuh"
+#include "xq_rules.hip.h"
 
 #include <algorithm>
 
@@ -156,7 +156,10 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
     const bool no_action = (MODE == MODE_SELFPLAY) && !have_action;                 // chessai.cpp:100-103
     const bool done = over || no_action || (move_count + 1 >= 200);
     const bool terminated = over || no_action;
-    const bool do_reset = terminated && (MODE == MODE_SELFPLAY || P.auto_reset != 0);
+    // the episode ENDS on the ply that made it terminal; a rejected move on an already finished board (the facade's
+    // checkGameOver() probe, a retried step) reports `terminated` but changes nothing: no stats, no episode record, no reset
+    const bool ended_now = terminated && (MODE == MODE_SELFPLAY || valid);
+    const bool do_reset = ended_now && (MODE == MODE_SELFPLAY || P.auto_reset != 0);
     const int winner = terminated ? st.first_general_color : C_NONE;
 
     const uint32_t next_word = pack_from_slab(S.sq);               // s' = board after the move, before any reset
@@ -194,17 +197,17 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
         }
     }
 
-    if ((captured != 0 || terminated || (explored && P.q90 != nullptr)) && lane == 0) {
+    if ((captured != 0 || ended_now || (explored && P.q90 != nullptr)) && lane == 0) {
         uint4 s = P.stats[g];
-        if (terminated && winner == C_RED) s.x += 1;
-        if (terminated && winner == C_BLACK) s.y += 1;
+        if (ended_now && winner == C_RED) s.x += 1;
+        if (ended_now && winner == C_BLACK) s.y += 1;
         if (captured != 0) s.z += 1;
         if (explored && P.q90 != nullptr) s.w += 1;
         P.stats[g] = s;
     }
 
     uint32_t out_word = next_word;
-    if (terminated && lane == 0 && P.ep_ring != nullptr) {          // gameCompleted(game, red, black), chessai.cpp:162
+    if (ended_now && lane == 0 && P.ep_ring != nullptr) {           // gameCompleted(game, red, black), chessai.cpp:162
         const unsigned long long h = atomicAdd(P.ep_head, 1ull);
         xq_episode_record e;
         e.game_id = P.first_game_id + (uint32_t)g;
@@ -238,6 +241,30 @@ __global__ __launch_bounds__(256) void valid_matrix_kernel(const uint32_t* board
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < 8100; i += (int)(gridDim.x * blockDim.x)) {
         const int f = i / 90, t = i - f * 90;
         out[i] = is_valid_move(sq, f / 9, f % 9, t / 9, t % 9) ? 1 : 0;
+    }
+}
+
+// The seven public validators isValid{General..Soldier}Move (chessboard.h:50-56) of one game: out[(type-1)*8100 + f*90 + t]
+// for in-board (from, to); n_query > 0 instead evaluates `n_query` explicit (type, fr, fc, tr, tc) tuples (any coordinates).
+__global__ __launch_bounds__(256) void rule_matrix_kernel(const uint32_t* boards, int g, uint8_t* out, const int32_t* query, int n_query) {
+    __shared__ uint8_t sq[96];
+    if (threadIdx.x < kBoardWords) {
+        const uint32_t w = boards[(size_t)g * kBoardWords + threadIdx.x];
+        for (int k = 0; k < 8; ++k) sq[threadIdx.x * 8 + k] = (uint8_t)((w >> (4 * k)) & 15u);
+    }
+    __syncthreads();
+    if (n_query > 0) {
+        for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n_query; i += (int)(gridDim.x * blockDim.x)) {
+            const int32_t* q = query + 5 * i;
+            out[i] = piece_rule(sq, q[0], q[1], q[2], q[3], q[4]) ? 1 : 0;
+        }
+        return;
+    }
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < 7 * 8100; i += (int)(gridDim.x * blockDim.x)) {
+        const int type = 1 + i / 8100, ft = i % 8100;
+        const int f = ft / 90, t = ft - f * 90;
+        // from == to on a line piece runs into signed overflow upstream (loop `i != end` from start +- 1): reported as 0 here
+        out[i] = (f != t || type < T_CHARIOT || type > T_CANNON) && piece_rule(sq, type, f / 9, f % 9, t / 9, t % 9) ? 1 : 0;
     }
 }
 
@@ -369,7 +396,7 @@ static int env_init(xq_env* e, int n_games, uint64_t seed, uint32_t first_game_i
     XQ_HIP(hipMalloc(&e->counts, n * sizeof(int32_t)));
     XQ_HIP(hipMalloc(&e->actions, n * sizeof(int32_t)));
     XQ_HIP(hipMalloc(&e->q90, n * 96 * sizeof(float)));
-    XQ_HIP(hipMalloc(&e->validmat, 8100));
+    XQ_HIP(hipMalloc(&e->validmat, 8 * 8100));        // isValidMove matrix, or the 7 per-piece rule matrices (+ query scratch)
     e->ep_cap = std::max(4096, 4 * n_games);
     XQ_HIP(hipMalloc(&e->ep_ring, (size_t)e->ep_cap * sizeof(xq_episode_record)));
     XQ_HIP(hipMalloc(&e->ep_head, sizeof(unsigned long long)));
@@ -489,6 +516,36 @@ int xq_env_valid_matrix(xq_env* e, int game, uint8_t* valid8100_host) {
     XQ_HIP(hipGetLastError());
     XQ_HIP(hipMemcpyAsync(valid8100_host, e->validmat, 8100, hipMemcpyDeviceToHost, e->stream));
     XQ_HIP(hipStreamSynchronize(e->stream));
+    return XQ_OK;
+}
+
+int xq_env_rule_matrix(xq_env* e, int game, uint8_t* rules7x8100_host) {
+    if (!e || !rules7x8100_host || game < 0 || game >= e->n) return fail(XQ_ERR_INVALID_ARGUMENT, "bad game index");
+    hipLaunchKernelGGL(rule_matrix_kernel, dim3(64), dim3(256), 0, e->stream, e->boards, game, e->validmat, nullptr, 0);
+    XQ_HIP(hipGetLastError());
+    XQ_HIP(hipMemcpyAsync(rules7x8100_host, e->validmat, 7 * 8100, hipMemcpyDeviceToHost, e->stream));
+    XQ_HIP(hipStreamSynchronize(e->stream));
+    return XQ_OK;
+}
+
+int xq_env_rule_query(xq_env* e, int game, int piece_type, int fr, int fc, int tr, int tc, int* ok) {
+    if (!e || !ok || game < 0 || game >= e->n) return fail(XQ_ERR_INVALID_ARGUMENT, "bad game index");
+    if (piece_type < T_GENERAL || piece_type > T_SOLDIER) return fail(XQ_ERR_INVALID_ARGUMENT, "piece type must be 1..7");
+    const int lim = 1024;
+    if (fr < -lim || fr > lim || fc < -lim || fc > lim || tr < -lim || tr > lim || tc < -lim || tc > lim)
+        return fail(XQ_ERR_INVALID_ARGUMENT, "coordinate out of the supported range [-1024, 1024]");
+    if ((piece_type == T_CHARIOT || piece_type == T_CANNON) && fr == tr && fc == tc)
+        return fail(XQ_ERR_UNDEFINED_UPSTREAM, "from == to on a line piece: the upstream path loop overflows (chessboard.cpp:390/:410)");
+    const int32_t q[5] = {piece_type, fr, fc, tr, tc};
+    int32_t* qd = reinterpret_cast<int32_t*>(e->validmat + 7 * 8100 + 12);      // 4-byte aligned scratch behind the matrices
+    uint8_t* od = e->validmat + 7 * 8100;
+    XQ_HIP(hipMemcpyAsync(qd, q, sizeof q, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(rule_matrix_kernel, dim3(1), dim3(64), 0, e->stream, e->boards, game, od, qd, 1);
+    XQ_HIP(hipGetLastError());
+    uint8_t r = 0;
+    XQ_HIP(hipMemcpyAsync(&r, od, 1, hipMemcpyDeviceToHost, e->stream));
+    XQ_HIP(hipStreamSynchronize(e->stream));
+    *ok = r;
     return XQ_OK;
 }
 

@@ -1,4 +1,4 @@
-// xq_gemm.cuh — fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled for gfx950.
+// xq_gemm.hip.h — fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled for gfx950.
 //
 // One template serves every dense contraction of the Q-network (reference dqn.cu kernels forwardKernel :184/:275,
 // hiddenLayerDeltaKernel :297, updateWeightsBiasesKernel :310 — there one thread per output neuron with a serial

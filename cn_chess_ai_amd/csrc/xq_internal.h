@@ -114,6 +114,7 @@ struct Profiler {
 
 // dqn-side entry points used by the trainer (defined in xq_dqn.hip)
 Profiler* dqn_profiler(xq_dqn* d);
+int dqn_fused_apply(const xq_dqn* d);      // current xq_dqn_set_fused_apply setting
 int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride, hipStream_t on = nullptr);
 hipStream_t dqn_stream(xq_dqn* d);
 hipEvent_t dqn_qmax_event(xq_dqn* d);      // recorded behind the column-max GEMM of the last xq_dqn_td_grads*

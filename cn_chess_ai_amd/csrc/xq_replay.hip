@@ -93,6 +93,8 @@ int xq_replay_push_host(xq_replay* r, int n, const uint8_t* boards90, const int3
     if (!r || n < 0 || !boards90 || !action_to || !reward || !done || !next_boards90)
         return fail(XQ_ERR_INVALID_ARGUMENT, "xq_replay_push_host: null pointer");
     if (n > r->dev.capacity) return fail(XQ_ERR_INVALID_ARGUMENT, "push of %d exceeds capacity %d", n, r->dev.capacity);
+    for (size_t i = 0; i < (size_t)n * 90; ++i)       // code 15 would index one-hot plane 14 of 14 in the layer-0 kernels
+        if (boards90[i] > 14 || next_boards90[i] > 14) return fail(XQ_ERR_INVALID_ARGUMENT, "piece code > 14");
     uint32_t w[kBoardWords], nw[kBoardWords];
     XQ_HIP(hipStreamSynchronize(r->stream));
     for (int i = 0; i < n; ++i) {

@@ -1,4 +1,4 @@
-// xq_rules.cuh — Xiangqi rules engine for one wavefront = one board (gfx950, wave64).
+// xq_rules.hip.h — Xiangqi rules engine for one wavefront = one board (gfx950, wave64).
 //
 // Semantics follow the reference rules engine exactly (Qervas/cn_chess_ai, src/chessboard.cpp — cited per function);
 // the formulation is new: the 90-square board lives as bytes in a per-wave LDS slab plus 90-bit occupancy bitboards in
@@ -37,30 +37,27 @@ __device__ __forceinline__ int count_between(const uint8_t* sq, int fr, int fc, 
     int n = 0;
     if (fr == tr) {
         const int step = tc > fc ? 1 : -1;
-        for (int c = fc + step; c != tc; c += step) n += sq[fr * 9 + c] != 0;
+        for (int c = fc + step; c != tc; c += step) n += at(sq, fr, c) != 0;
     } else {
         const int step = tr > fr ? 1 : -1;
-        for (int r = fr + step; r != tr; r += step) n += sq[r * 9 + fc] != 0;
+        for (int r = fr + step; r != tr; r += step) n += at(sq, r, fc) != 0;
     }
     return n;
 }
 
-// ChessBoard::isValidMove (chessboard.cpp:66-93) with the per-piece validators (:328-440).
-// Pseudo-legal only: NO turn check, no check / flying-general rule (SURVEY E4).
-__device__ inline bool is_valid_move(const uint8_t* sq, int fr, int fc, int tr, int tc) {
-    if (!inside(fr, fc) || !inside(tr, tc)) return false;
-    const int f = sq[fr * 9 + fc], t = sq[tr * 9 + tc];
-    if (f == 0) return false;
-    if (t != 0 && same_side(f, t)) return false;
+// The seven public per-piece validators (chessboard.h:50-56, chessboard.cpp:328-440) as written: geometry + occupancy only,
+// no look at WHICH piece stands on `from` (the soldier rule reads its colour: anything not Red takes the Black branch),
+// coordinates outside the board read as Empty (getPieceAt, :31-36).  `type` = PieceType 1..7.
+__device__ inline bool piece_rule(const uint8_t* sq, int type, int fr, int fc, int tr, int tc) {
     const int dr = tr - fr, dc = tc - fc;
     const int adr = dr < 0 ? -dr : dr, adc = dc < 0 ? -dc : dc;
-    switch (code_type(f)) {
+    switch (type) {
         case T_GENERAL:                                                     // :328-343
             return in_any_palace(fr, fc) && in_any_palace(tr, tc) && adr + adc == 1;
         case T_ADVISOR:                                                     // :346-353
             return in_any_palace(tr, tc) && adr == 1 && adc == 1;
         case T_ELEPHANT:                                                    // :355-367
-            return adr == 2 && adc == 2 && ((fr < 5) == (tr < 5)) && at(sq, (fr + tr) / 2, (fc + tc) / 2) == 0;
+            return adr == 2 && adc == 2 && ((fr < 5 && tr < 5) || (fr >= 5 && tr >= 5)) && at(sq, (fr + tr) / 2, (fc + tc) / 2) == 0;
         case T_HORSE:                                                       // :369-380 (truncating /2 picks the leg)
             return ((adr == 2 && adc == 1) || (adr == 1 && adc == 2)) && at(sq, fr + dr / 2, fc + dc / 2) == 0;
         case T_CHARIOT:                                                     // :382-397
@@ -68,13 +65,25 @@ __device__ inline bool is_valid_move(const uint8_t* sq, int fr, int fc, int tr, 
         case T_CANNON: {                                                    // :399-421
             if (fr != tr && fc != tc) return false;
             const int n = count_between(sq, fr, fc, tr, tc);
-            return t == 0 ? n == 0 : n == 1;
+            return at(sq, tr, tc) == 0 ? n == 0 : n == 1;
         }
-        case T_SOLDIER:                                                     // :423-440
-            if (f <= 7) return fr < 5 ? (dr == 1 && adc == 0) : ((dr == 1 && adc == 0) || (dr == 0 && adc == 1));
+        case T_SOLDIER: {                                                   // :423-440
+            const int f = at(sq, fr, fc);
+            if (f >= 1 && f <= 7) return fr < 5 ? (dr == 1 && adc == 0) : ((dr == 1 && adc == 0) || (dr == 0 && adc == 1));
             return fr >= 5 ? (dr == -1 && adc == 0) : ((dr == -1 && adc == 0) || (dr == 0 && adc == 1));
+        }
         default: return false;
     }
+}
+
+// ChessBoard::isValidMove (chessboard.cpp:66-93) over the per-piece validators above.
+// Pseudo-legal only: NO turn check, no check / flying-general rule (SURVEY E4).
+__device__ inline bool is_valid_move(const uint8_t* sq, int fr, int fc, int tr, int tc) {
+    if (!inside(fr, fc) || !inside(tr, tc)) return false;
+    const int f = sq[fr * 9 + fc], t = sq[tr * 9 + tc];
+    if (f == 0) return false;
+    if (t != 0 && same_side(f, t)) return false;
+    return piece_rule(sq, code_type(f), fr, fc, tr, tc);
 }
 
 // inclusive wave prefix sum over 64 lanes

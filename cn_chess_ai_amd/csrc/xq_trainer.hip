@@ -200,6 +200,7 @@ int xq_trainer_step(xq_trainer* t, int n_iterations) {
     const int plies = t->cfg.collects_per_update > 1 ? t->cfg.collects_per_update : 1;
     if (plies > 1 && t->cfg.replay_capacity == 0)
         return fail(XQ_ERR_INVALID_ARGUMENT, "collects_per_update > 1 needs a replay ring (on-policy keeps one ply)");
+    const int fused_before = dqn_fused_apply(t->dqn);   // restored on every exit path: the caller's choice survives step()
     XQ_TRY(xq_dqn_set_fused_apply(t->dqn, 1));      // single-GPU loop: nothing reads the gradient buffer between grads and apply
     int rc = XQ_OK;
     for (int i = 0; i < n_iterations && rc == XQ_OK; ++i) {
@@ -212,7 +213,7 @@ int xq_trainer_step(xq_trainer* t, int n_iterations) {
         }
         if (rc == XQ_OK) rc = xq_trainer_learn_apply(t, 1);
     }
-    const int rc_off = xq_dqn_set_fused_apply(t->dqn, 0);     // also after a failed iteration
+    const int rc_off = xq_dqn_set_fused_apply(t->dqn, fused_before);     // also after a failed iteration
     return rc != XQ_OK ? rc : rc_off;
 }
 

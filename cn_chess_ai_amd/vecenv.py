@@ -160,6 +160,17 @@ class VecEnv:
         call("xq_env_valid_matrix", self._h, int(game), _ptr(m, C.c_uint8))
         return m
 
+    def rule_matrix(self, game):
+        """[7][8100] results of isValid{General..Soldier}Move (chessboard.h:50-56) for every in-board (from, to) of a game."""
+        m = np.zeros((7, 8100), dtype=np.uint8)
+        call("xq_env_rule_matrix", self._h, int(game), _ptr(m, C.c_uint8))
+        return m
+
+    def rule_query(self, game, piece_type, fr, fc, tr, tc):
+        ok = C.c_int32()
+        call("xq_env_rule_query", self._h, int(game), int(piece_type), int(fr), int(fc), int(tr), int(tc), C.byref(ok))
+        return bool(ok.value)
+
     def get_winner(self, first=0, n=None):
         """ChessBoard::getWinner() per game (colour of the first general in index order)."""
         n = self.n_games - first if n is None else n

@@ -65,8 +65,9 @@ class ChessBoard {
 public:
     ChessBoard() { check(xq_env_create(1, 0x5EED, 0, nullptr, &env_)); refresh(); }
     ~ChessBoard() { xq_env_destroy(env_); }
-    ChessBoard(const ChessBoard&) = delete;
-    ChessBoard& operator=(const ChessBoard&) = delete;
+    // plain value type like upstream (chessboard.h:33-88): a copy is a second device-resident game in the same state
+    ChessBoard(const ChessBoard& o) { check(xq_env_create(1, 0x5EED, 0, nullptr, &env_)); assign(o); }
+    ChessBoard& operator=(const ChessBoard& o) { if (this != &o) assign(o); return *this; }
 
     void initializeBoard() { reset(); }
     ChessPiece getPieceAt(int row, int col) const {             // Empty outside the board, chessboard.cpp:31-36
@@ -80,6 +81,7 @@ public:
             a = (fromRow * 9 + fromCol) * 90 + toRow * 9 + toCol;
         check(xq_env_step(env_, &a, 0, &last_));
         refresh();
+        over_ = last_.terminated != 0; over_ok_ = true;
         return pieceFromCode(last_.captured);
     }
     bool isValidMove(int fromRow, int fromCol, int toRow, int toCol) const {   // chessboard.cpp:66-93
@@ -90,7 +92,12 @@ public:
     void reset() { check(xq_env_reset(env_)); refresh(); }
     int getRedScore() const { return meta_[2]; }
     int getBlackScore() const { return meta_[3]; }
-    bool checkGameOver() const { return probe().terminated != 0; }             // chessboard.cpp:286-309, on device
+    // chessboard.cpp:286-309, evaluated on device: the result of the last movePiece() is kept; after reset()/setState() one
+    // probe (a rejected move: evaluates, changes nothing) refreshes it
+    bool checkGameOver() const {
+        if (!over_ok_) { over_ = probe().terminated != 0; over_ok_ = true; }
+        return over_;
+    }
     PieceColor getWinner() const {                                             // chessboard.cpp:312-320, on device
         uint8_t w = 2;
         check(xq_env_get_winner(env_, 0, 1, &w));
@@ -111,6 +118,16 @@ public:
         return out;
     }
     bool isInsideBoard(int row, int col) const { return row >= 0 && row < 10 && col >= 0 && col < 9; }
+    // chessboard.h:50-56 — the per-piece validators as upstream writes them (geometry + occupancy; the piece standing on
+    // `from` is not consulted, except for the soldier's colour).  In-board queries come from a cached device-computed table,
+    // anything else is one device query (upstream reads squares outside the board as Empty).
+    bool isValidGeneralMove(int fr, int fc, int tr, int tc) const { return rule(1, fr, fc, tr, tc); }
+    bool isValidAdvisorMove(int fr, int fc, int tr, int tc) const { return rule(2, fr, fc, tr, tc); }
+    bool isValidElephantMove(int fr, int fc, int tr, int tc) const { return rule(3, fr, fc, tr, tc); }
+    bool isValidHorseMove(int fr, int fc, int tr, int tc) const { return rule(4, fr, fc, tr, tc); }
+    bool isValidChariotMove(int fr, int fc, int tr, int tc) const { return rule(5, fr, fc, tr, tc); }
+    bool isValidCannonMove(int fr, int fc, int tr, int tc) const { return rule(6, fr, fc, tr, tc); }
+    bool isValidSoldierMove(int fr, int fc, int tr, int tc) const { return rule(7, fr, fc, tr, tc); }
 
     // ---- beyond the reference surface (used by ChessAI) ----
     std::vector<Action> allValidActions(PieceColor player) const {             // chessai.cpp:347-368, on device
@@ -133,7 +150,21 @@ public:
 private:
     void refresh() {
         check(xq_env_get_state(env_, 0, 1, sq_, meta_));
-        matrix_ok_ = false;
+        matrix_ok_ = false; rules_ok_ = false; over_ok_ = false;
+    }
+    void assign(const ChessBoard& o) {
+        check(xq_env_set_state(env_, 0, 1, o.sq_, o.meta_));
+        refresh();
+        last_ = o.last_;
+    }
+    bool rule(int type, int fr, int fc, int tr, int tc) const {
+        if (isInsideBoard(fr, fc) && isInsideBoard(tr, tc) && !(type >= 5 && type <= 6 && fr == tr && fc == tc)) {
+            if (!rules_ok_) { rules_.resize(7 * 8100); check(xq_env_rule_matrix(env_, 0, rules_.data())); rules_ok_ = true; }
+            return rules_[(size_t)(type - 1) * 8100 + (fr * 9 + fc) * 90 + tr * 9 + tc] != 0;
+        }
+        int ok = 0;
+        check(xq_env_rule_query(env_, 0, type, fr, fc, tr, tc, &ok));
+        return ok != 0;
     }
     void ensureMatrix() const {
         if (!matrix_ok_) { check(xq_env_valid_matrix(env_, 0, valid_)); matrix_ok_ = true; }
@@ -149,6 +180,9 @@ private:
     int32_t meta_[4];
     mutable uint8_t valid_[8100];
     mutable bool matrix_ok_ = false;
+    mutable std::vector<uint8_t> rules_;
+    mutable bool rules_ok_ = false;
+    mutable bool over_ = false, over_ok_ = false;
     xq_step_result last_{};
 };
 
@@ -456,6 +490,7 @@ private:
         cfg.seed = (uint64_t)std::time(nullptr); cfg.first_game_id = 0;
         xq_trainer* t = nullptr;
         check(xq_trainer_create(&cfg, nullptr, &t));
+        struct Guard { xq_trainer* t; ~Guard() { xq_trainer_destroy(t); } } guard{t};   // released on every path, also when check() throws
         xq_dqn* td = nullptr; xq_env* te = nullptr;
         check(xq_trainer_dqn(t, &td)); check(xq_trainer_env(t, &te));
         std::vector<double> w, b;
@@ -478,7 +513,6 @@ private:
         check(xq_dqn_get_params(td, XQ_NET_ONLINE, w.data(), b.data()));
         dqn->setParameters(w, b);
         dqn->updateTargetNetwork();
-        xq_trainer_destroy(t);
     }
 
     ChessBoard* board;

@@ -82,6 +82,14 @@ int xq_env_get_winner(xq_env* env, int first, int n, uint8_t* winners_host);
 /* ChessBoard::isValidMove for all 90x90 (from,to) pairs of game g (chessboard.cpp:66-93,328-440): valid8100[f*90+t]. */
 int xq_env_valid_matrix(xq_env* env, int game, uint8_t* valid8100_host);
 
+/* The seven public per-piece validators isValid{General,Advisor,Elephant,Horse,Chariot,Cannon,Soldier}Move
+ * (chessboard.h:50-56, chessboard.cpp:328-440) of game g, evaluated on device as upstream writes them (geometry + occupancy
+ * only; the piece on `from` is not consulted except for the soldier's colour): rules[(type-1)*8100 + f*90 + t] for all in-board
+ * (from, to) pairs, type = PieceType 1..7.  xq_env_rule_query answers one call with arbitrary coordinates (upstream reads
+ * squares outside the board as Empty); from == to on a chariot/cannon overflows a loop upstream => XQ_ERR_UNDEFINED_UPSTREAM. */
+int xq_env_rule_matrix(xq_env* env, int game, uint8_t* rules7x8100_host);
+int xq_env_rule_query(xq_env* env, int game, int piece_type, int from_row, int from_col, int to_row, int to_col, int* ok);
+
 /* Per-game result of one ply.  Mirrors what chessai.cpp:113-119,146-162 derives after movePiece(). */
 typedef struct {
     int32_t action;      /* action code played, -1 if the side to move had no action (chessai.cpp:100-103) */
@@ -99,7 +107,9 @@ typedef struct {
 
 /* ChessBoard::movePiece with caller-chosen actions (chessboard.cpp:38-64) + evaluateBoard + checkGameOver, per game.
  * actions: [n_games] action codes (any int; out-of-board / invalid => rejected, no state change).
- * auto_reset != 0: a game whose checkGameOver() became true is reset (the `for episode` loop of chessai.cpp:89-90). */
+ * auto_reset != 0: a game whose checkGameOver() became true BY THIS MOVE is reset (the `for episode` loop of chessai.cpp:89-90).
+ * A rejected move changes nothing — no counters, no episode record, no reset — also on an already finished board
+ * (its result still reports terminated/winner: that is how the facade's checkGameOver() probes). */
 int xq_env_step(xq_env* env, const int32_t* actions_host, int auto_reset, xq_step_result* results_host);
 
 /* One self-play ply for every game, fully on device: legal moves (LDS) -> epsilon-greedy DQN::selectAction

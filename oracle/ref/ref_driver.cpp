@@ -165,6 +165,97 @@ int cmdValidMat(uint64_t seed, int npos, const char* path) {
     return 0;
 }
 
+// tracebig: random play; one Record per position in which either side has MORE THAN 64 moves (the second half of the
+// 128-entry move list), with one attempted move each.  Records do not chain.
+int cmdTraceBig(uint64_t seed, int nrec, const char* path) {
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { std::perror(path); return 1; }
+    SplitMix64 rng(seed);
+    ChessBoard b;
+    int written = 0;
+    long plies = 0;
+    while (written < nrec) {
+        b.reset();
+        while (!b.checkGameOver() && written < nrec) {
+            Record r;
+            snapshot(b, r);
+            PieceColor player = b.getCurrentPlayer();
+            const uint16_t* list = (player == PieceColor::Red) ? r.red : r.black;
+            int n = (player == PieceColor::Red) ? r.nRed : r.nBlack;
+            if (n == 0) break;
+            int c = list[rng.below((uint32_t)(n > 128 ? 128 : n))];
+            int fr = (c / 90) / 9, fc = (c / 90) % 9, tr = (c % 90) / 9, tc = (c % 90) % 9;
+            r.fr = (int8_t)fr; r.fc = (int8_t)fc; r.tr = (int8_t)tr; r.tc = (int8_t)tc;
+            r.valid = b.isValidMove(fr, fc, tr, tc);
+            r.captured = pieceCode(b.movePiece(fr, fc, tr, tc));
+            ++plies;
+            if (r.nRed > 64 || r.nBlack > 64) { std::fwrite(&r, sizeof r, 1, f); ++written; }
+        }
+    }
+    std::fclose(f);
+    std::fprintf(stderr, "tracebig: %d records out of %ld plies\n", written, plies);
+    return 0;
+}
+
+// rulemat: for sampled random-play positions dump the board, the seven PUBLIC per-piece validators
+// (chessboard.h:50-56) over all in-board (from, to) pairs — 7 x 8100 bytes, type-major — and 64 queries with
+// coordinates in [-2, 11] (squares outside the board read as Empty upstream): 5 x int8 (type, fr, fc, tr, tc) + result.
+// from == to is skipped for chariot / cannon: the path loop `i != end` overflows there.
+int cmdRuleMat(uint64_t seed, int npos, const char* path) {
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { std::perror(path); return 1; }
+    SplitMix64 rng(seed);
+    ChessBoard b;
+    int written = 0;
+    auto rule = [&](int type, int fr, int fc, int tr, int tc) -> bool {
+        switch (type) {
+            case 1: return b.isValidGeneralMove(fr, fc, tr, tc);
+            case 2: return b.isValidAdvisorMove(fr, fc, tr, tc);
+            case 3: return b.isValidElephantMove(fr, fc, tr, tc);
+            case 4: return b.isValidHorseMove(fr, fc, tr, tc);
+            case 5: return b.isValidChariotMove(fr, fc, tr, tc);
+            case 6: return b.isValidCannonMove(fr, fc, tr, tc);
+            default: return b.isValidSoldierMove(fr, fc, tr, tc);
+        }
+    };
+    while (written < npos) {
+        b.reset();
+        while (!b.checkGameOver() && written < npos) {
+            uint16_t list[128];
+            int n = allActions(b, b.getCurrentPlayer(), list);
+            if (n == 0) break;
+            if (rng.below(16) == 0) {
+                uint8_t board[90];
+                static uint8_t mat[7 * 8100];
+                for (int s = 0; s < 90; ++s) board[s] = pieceCode(b.getPieceAt(s / 9, s % 9));
+                for (int type = 1; type <= 7; ++type)
+                    for (int fsq = 0; fsq < 90; ++fsq)
+                        for (int tsq = 0; tsq < 90; ++tsq)
+                            mat[(type - 1) * 8100 + fsq * 90 + tsq] =
+                                (fsq == tsq && (type == 5 || type == 6)) ? 0 : rule(type, fsq / 9, fsq % 9, tsq / 9, tsq % 9);
+                std::fwrite(board, 1, 90, f);
+                std::fwrite(mat, 1, sizeof mat, f);
+                for (int q = 0; q < 64; ++q) {
+                    int8_t t[6];
+                    do {
+                        t[0] = (int8_t)(1 + rng.below(7));
+                        t[1] = (int8_t)((int)rng.below(14) - 2); t[2] = (int8_t)((int)rng.below(13) - 2);
+                        if (rng.below(2)) { t[3] = (int8_t)(t[1] + (int)rng.below(5) - 2); t[4] = (int8_t)(t[2] + (int)rng.below(5) - 2); }
+                        else { t[3] = (int8_t)((int)rng.below(14) - 2); t[4] = (int8_t)((int)rng.below(13) - 2); }
+                    } while ((t[0] == 5 || t[0] == 6) && t[1] == t[3] && t[2] == t[4]);
+                    t[5] = rule(t[0], t[1], t[2], t[3], t[4]);
+                    std::fwrite(t, 1, 6, f);
+                }
+                ++written;
+            }
+            int c = list[rng.below((uint32_t)(n > 128 ? 128 : n))];
+            b.movePiece((c / 90) / 9, (c / 90) % 9, (c % 90) / 9, (c % 90) % 9);
+        }
+    }
+    std::fclose(f);
+    return 0;
+}
+
 // bench: env-only random-policy stepping (move-gen for the side to move + movePiece + game-over test),
 // the reference-CPU leg of BASELINE.md §3 C2.  Prints "steps seconds".
 int cmdBench(uint64_t seed, double seconds) {
@@ -196,9 +287,13 @@ int main(int argc, char** argv) {
         return cmdTrace(std::strtoull(argv[2], nullptr, 0), std::atoi(argv[3]), argv[4]);
     if (argc >= 5 && !std::strcmp(argv[1], "validmat"))
         return cmdValidMat(std::strtoull(argv[2], nullptr, 0), std::atoi(argv[3]), argv[4]);
+    if (argc >= 5 && !std::strcmp(argv[1], "tracebig"))
+        return cmdTraceBig(std::strtoull(argv[2], nullptr, 0), std::atoi(argv[3]), argv[4]);
+    if (argc >= 5 && !std::strcmp(argv[1], "rulemat"))
+        return cmdRuleMat(std::strtoull(argv[2], nullptr, 0), std::atoi(argv[3]), argv[4]);
     if (argc >= 4 && !std::strcmp(argv[1], "bench"))
         return cmdBench(std::strtoull(argv[2], nullptr, 0), std::atof(argv[3]));
     if (argc >= 2 && !std::strcmp(argv[1], "recsize")) { std::printf("%zu\n", sizeof(Record)); return 0; }
-    std::fprintf(stderr, "usage: xqref trace SEED NGAMES OUT | validmat SEED NPOS OUT | bench SEED SECONDS | recsize\n");
+    std::fprintf(stderr, "usage: xqref trace SEED NGAMES OUT | tracebig SEED NREC OUT | validmat SEED NPOS OUT | rulemat SEED NPOS OUT | bench SEED SECONDS | recsize\n");
     return 2;
 }

@@ -7,6 +7,7 @@
 #include "xq_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -115,6 +116,21 @@ int xqo_is_valid_move(const xqo_board* b, int fr, int fc, int tr, int tc) {     
         case T_HORSE:    return valid_horse(b, fr, fc, tr, tc);
         case T_CHARIOT:  return valid_chariot(b, fr, fc, tr, tc);
         case T_CANNON:   return valid_cannon(b, fr, fc, tr, tc);
+        case T_SOLDIER:  return valid_soldier(b, fr, fc, tr, tc);
+        default: return 0;
+    }
+}
+
+/* the seven PUBLIC validators (chessboard.h:50-56) by PieceType 1..7, for any coordinates; -1 where upstream's path loop
+ * overflows (from == to on a chariot / cannon, chessboard.cpp:390/:410) */
+int xqo_piece_rule(const xqo_board* b, int type, int fr, int fc, int tr, int tc) {
+    switch (type) {
+        case T_GENERAL:  return valid_general(fr, fc, tr, tc);
+        case T_ADVISOR:  return valid_advisor(fr, fc, tr, tc);
+        case T_ELEPHANT: return valid_elephant(b, fr, fc, tr, tc);
+        case T_HORSE:    return valid_horse(b, fr, fc, tr, tc);
+        case T_CHARIOT:  return (fr == tr && fc == tc) ? -1 : valid_chariot(b, fr, fc, tr, tc);
+        case T_CANNON:   return (fr == tr && fc == tc) ? -1 : valid_cannon(b, fr, fc, tr, tc);
         case T_SOLDIER:  return valid_soldier(b, fr, fc, tr, tc);
         default: return 0;
     }
@@ -562,6 +578,97 @@ int xqo_train_episode(const int* L, int ns, double* w, double* b, double lr, dou
     }
     free(state); free(next); free(q); free(tq);
     return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * ChessAI::startSelfPlay (chessai.cpp:191-266), getAIMove (:29-83), onGameCompleted (:370-393)
+ * ---------------------------------------------------------------------------------------------- */
+static int select_with_rand(const int* L, int ns, const double* w, const double* b, const double* state, double* q,
+                            const uint16_t* codes, int n, xqo_rand_fn rnd, void* ctx, int rand_max, double eps) {
+    /* DQN::selectAction, dqn.cpp:24-56: one rand() always, a second one only on the explore branch */
+    const int r1 = rnd(ctx);
+    if ((double)r1 / (double)rand_max < eps) return rnd(ctx) % n;
+    xqo_nn_forward(L, ns, w, b, state, q);
+    return xqo_select_action(q, L[ns - 1], codes, n, rand_max, 0, rand_max, -1.0);
+}
+
+int xqo_selfplay_game(const int* L, int ns, double* w, double* b, double lr, double gamma, double eps,
+                      xqo_rand_fn rnd, void* ctx, int rand_max, int mode, xqo_board* board_out, xqo_episode_stats* st) {
+    const int nout = L[ns - 1];
+    xqo_board board;
+    xqo_reset(&board);                                                       /* :193 */
+    double* state = (double*)malloc(sizeof(double) * 1260);
+    double* next = (double*)malloc(sizeof(double) * 1260);
+    double* q = (double*)malloc(sizeof(double) * (size_t)nout);
+    double* tq = (double*)malloc(sizeof(double) * (size_t)nout);
+    xqo_state_repr(&board, state);                                           /* :194 */
+    int steps = 0, syncs = 0, rc = 0;
+    uint16_t codes[XQO_MAX_MOVES];
+    while (!xqo_check_game_over(&board)) {                                   /* :196 — no local cap */
+        const int currentPlayer = board.currentPlayer;                       /* :197 */
+        int n = xqo_all_valid_actions(&board, currentPlayer, codes);         /* :200 */
+        if (n == 0) break;                                                   /* :202-205 */
+        if (n > XQO_MAX_MOVES) n = XQO_MAX_MOVES;
+        const int idx = select_with_rand(L, ns, w, b, state, q, codes, n, rnd, ctx, rand_max, eps);   /* :208 */
+        const int from = codes[idx] / 90, to = codes[idx] % 90;
+        xqo_move_piece(&board, from / 9, from % 9, to / 9, to % 9);          /* :216 */
+        const double reward = xqo_evaluate_board(&board, currentPlayer, board.moveCount);   /* :220 */
+        xqo_state_repr(&board, next);                                        /* :223 */
+        const int done = xqo_check_game_over(&board);                        /* :226 */
+        xqo_td_target(L, ns, w, b, state, next, to, reward, done, gamma, tq);/* :229-235 */
+        rc |= xqo_nn_backprop(L, ns, w, b, state, tq, lr, mode);             /* :238 */
+        memcpy(state, next, sizeof(double) * 1260);                          /* :241 */
+        if (board.moveCount % 100 == 0) ++syncs;                             /* :244-246 (stale copy upstream: no effect) */
+        ++steps;
+    }
+    if (st) {
+        st->steps = steps; st->winner = xqo_get_winner(&board);              /* :250 */
+        st->redScore = board.redScore; st->blackScore = board.blackScore;    /* :251 */
+        st->moveCount = board.moveCount; st->target_syncs = syncs;
+    }
+    if (board_out) *board_out = board;
+    free(state); free(next); free(q); free(tq);
+    return rc;
+}
+
+void xqo_get_ai_move(const xqo_board* board, int color, const int* L, int ns, const double* w, const double* b,
+                     xqo_rand_fn rnd, void* ctx, int rand_max, int mv[4]) {
+    double* state = (double*)malloc(sizeof(double) * 1260);
+    double* q = (double*)malloc(sizeof(double) * (size_t)L[ns - 1]);
+    uint16_t codes[XQO_MAX_MOVES];
+    int moves[32];
+    xqo_state_repr(board, state);                                            /* :31 */
+    mv[0] = mv[1] = mv[2] = mv[3] = -1;
+    for (int attempt = 0; attempt < 10; ++attempt) {                         /* :32-34 */
+        int n = xqo_all_valid_actions(board, color, codes);                  /* :36 */
+        if (n == 0) continue;                                                /* :38-40 */
+        if (n > XQO_MAX_MOVES) n = XQO_MAX_MOVES;
+        const int idx = select_with_rand(L, ns, w, b, state, q, codes, n, rnd, ctx, rand_max, 0.1);   /* :43 */
+        const int from = codes[idx] / 90, to = codes[idx] % 90;
+        const int fr = from / 9, fc = from % 9, tr = to / 9, tc = to % 9;
+        const int m = xqo_get_valid_moves(board, fr, fc, moves);             /* :50 */
+        const int pc = board->sq[from];
+        const int pcolor = pc == 0 ? XQO_NONE : (pc > 7 ? XQO_BLACK : XQO_RED);
+        if (pcolor == color && m > 0) {                                      /* :53 */
+            for (int k = 0; k < m; ++k)
+                if (moves[k] == to) { mv[0] = fr; mv[1] = fc; mv[2] = tr; mv[3] = tc; free(state); free(q); return; }   /* :55-64 */
+        }
+    }
+    const int n = xqo_all_valid_actions(board, color, codes);                /* :69 */
+    if (n > 0) {                                                             /* :70-73 */
+        const int c = codes[rnd(ctx) % (n > XQO_MAX_MOVES ? XQO_MAX_MOVES : n)];   /* :75-76 (QRandomGenerator upstream) */
+        mv[0] = (c / 90) / 9; mv[1] = (c / 90) % 9; mv[2] = (c % 90) / 9; mv[3] = (c % 90) % 9;
+    }
+    free(state); free(q);
+}
+
+int xqo_game_log_line(int gameNumber, int redScore, int blackScore, int numGames, char* out, size_t cap) {
+    const char* result = redScore > blackScore ? "Red wins!" : blackScore > redScore ? "Black wins!" : "It's a draw!";   /* :376 */
+    int n = snprintf(out, cap, "Game %d completed. Red Score: %d, Black Score: %d. %s\n", gameNumber, redScore, blackScore,
+                     result);                                                /* :379-380 */
+    if (gameNumber == numGames && n >= 0 && (size_t)n < cap)                 /* :383-385 */
+        n += snprintf(out + n, cap - (size_t)n, "AI self-play session completed. Total games: %d\n\n", numGames);
+    return n;
 }
 
 /* ------------------------------------------------------------------------------------------------

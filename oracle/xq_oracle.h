@@ -38,6 +38,7 @@ typedef struct {
 /* ---- rules engine: chessboard.cpp ---- */
 void xqo_reset(xqo_board* b);                                              /* :8-29, :95-102 */
 int  xqo_is_valid_move(const xqo_board* b, int fr, int fc, int tr, int tc); /* :66-93, :328-440 */
+int  xqo_piece_rule(const xqo_board* b, int type, int fr, int fc, int tr, int tc);  /* :328-440, the public isValid<Piece>Move; -1 = overflow upstream */
 int  xqo_get_valid_moves(const xqo_board* b, int row, int col, int* out_sq);/* :112-283, ordered; returns n */
 int  xqo_move_piece(xqo_board* b, int fr, int fc, int tr, int tc);          /* :38-64; returns captured code (0: none/invalid) */
 int  xqo_check_game_over(const xqo_board* b);                               /* :286-309 */
@@ -81,6 +82,20 @@ typedef struct {
 int  xqo_train_episode(const int* sizes, int nsizes, double* w, double* b, double lr, double gamma, double eps,
                        uint64_t* rng_state, int mode, xqo_episode_stats* st);
 int  xqo_rand(uint64_t* rng_state);  /* 31-bit LCG standing in for the time-seeded C rand() */
+
+/* ---- the other ChessAI entry points of SURVEY §8(f), with the C library rand() injected as a callback ---- */
+typedef int (*xqo_rand_fn)(void* ctx);
+/* ChessAI::startSelfPlay, one iteration of its `for i` loop (chessai.cpp:192-252): like train() but driven by
+ * board->getCurrentPlayer(), NO local 200-ply cap and done = checkGameOver() (:227).  board_out = final position. */
+int  xqo_selfplay_game(const int* sizes, int nsizes, double* w, double* b, double lr, double gamma, double eps,
+                       xqo_rand_fn rnd, void* ctx, int rand_max, int mode, xqo_board* board_out, xqo_episode_stats* st);
+/* ChessAI::getAIMove(color) (chessai.cpp:29-83): 10 re-validated selectAction attempts at epsilon 0.1, then a random valid
+ * action (upstream draws it from QRandomGenerator::global(); here from the injected rand, `% n`), all -1 when there is none.
+ * mv = {fromRow, fromCol, toRow, toCol}. */
+void xqo_get_ai_move(const xqo_board* board, int color, const int* sizes, int nsizes, const double* w, const double* b,
+                     xqo_rand_fn rnd, void* ctx, int rand_max, int mv[4]);
+/* ChessAI::onGameCompleted (chessai.cpp:370-393): the text appended to game_log.txt for one finished game.  Returns its length. */
+int  xqo_game_log_line(int gameNumber, int redScore, int blackScore, int numGames, char* out, size_t cap);
 
 /* ---- counter-based RNG used by the build's batched self-play (build-defined; Philox4x32-10) ---- */
 void xqo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

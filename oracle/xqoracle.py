@@ -64,6 +64,7 @@ def lib():
     L.xqo_reset.argtypes = [pB]
     L.xqo_is_valid_move.argtypes = [pB, C.c_int, C.c_int, C.c_int, C.c_int]
     L.xqo_get_valid_moves.argtypes = [pB, C.c_int, C.c_int, pi]
+    L.xqo_piece_rule.argtypes = [pB, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.xqo_move_piece.argtypes = [pB, C.c_int, C.c_int, C.c_int, C.c_int]
     L.xqo_check_game_over.argtypes = [pB]
     L.xqo_get_winner.argtypes = [pB]

@@ -3,7 +3,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <iterator>
 #include <random>
+#include <string>
 
 #include "../../include/xq/xq.hpp"
 #include "../../oracle/xq_oracle.h"
@@ -156,6 +159,124 @@ int main() {
         CHECK(completed == 41);
         ai.saveModel("/tmp/xq_facade_model.bin");
         ai.loadModel("/tmp/xq_facade_model.bin");
+    }
+    // ---- getAIMove, the game_log.txt line, startSelfPlay — against the oracle's restatements ----
+    {
+        auto crand = [](void*) -> int { return std::rand(); };
+        const int L[3] = {1260, 128, 8100};
+        std::remove("game_log.txt");
+        xq::ChessBoard board;
+        xq::ChessAI ai(&board);
+        ai.setDQN(std::make_unique<xq::DQN>(std::vector<int>{1260, 128, 8100}, 0.001, 0.99, 99));
+        std::vector<double> w, bb;
+        ai.network()->getParameters(w, bb);
+        // (f2) getAIMove under srand(k), both colours, start position and a mid-game position (incl. explore draws)
+        xqo_board o; xqo_reset(&o);
+        std::mt19937 rng(5);
+        for (int k = 0; k < 24; ++k) {
+            if (k >= 4) {            // walk both boards a few random plies further
+                uint16_t codes[XQO_MAX_MOVES];
+                const int n = xqo_all_valid_actions(&o, o.currentPlayer, codes);
+                if (n == 0 || xqo_check_game_over(&o)) break;
+                const int c = codes[rng() % n];
+                xqo_move_piece(&o, (c / 90) / 9, (c / 90) % 9, (c % 90) / 9, (c % 90) % 9);
+                board.movePiece((c / 90) / 9, (c / 90) % 9, (c % 90) / 9, (c % 90) % 9);
+            }
+            for (int color = 0; color < 2; ++color) {
+                int want[4];
+                std::srand(1000 + k);
+                xqo_get_ai_move(&o, color, L, 3, w.data(), bb.data(), crand, nullptr, RAND_MAX, want);
+                std::srand(1000 + k);
+                const auto mv = ai.getAIMove(color ? xq::PieceColor::Black : xq::PieceColor::Red);
+                CHECK(mv.first.first == want[0] && mv.first.second == want[1] && mv.second.first == want[2] && mv.second.second == want[3]);
+            }
+        }
+        {   // a colour with no piece at all: ten empty attempts, then ((-1,-1),(-1,-1)) (chessai.cpp:38-40,70-73)
+            uint8_t sq[90] = {0};
+            sq[4] = 1;                                   // a lone red general
+            board.setState(sq, 0, xq::PieceColor::Black, 0, 0);
+            const auto mv = ai.getAIMove(xq::PieceColor::Black);
+            CHECK(mv.first.first == -1 && mv.first.second == -1 && mv.second.first == -1 && mv.second.second == -1);
+            xqo_board e; memset(&e, 0, sizeof e); e.sq[4] = 1; e.currentPlayer = 1;
+            int want[4];
+            xqo_get_ai_move(&e, 1, L, 3, w.data(), bb.data(), crand, nullptr, RAND_MAX, want);
+            CHECK(want[0] == -1 && want[3] == -1);
+            CHECK(board.checkGameOver());                // black general missing
+            const auto red = ai.getAIMove(xq::PieceColor::Red);
+            CHECK(board.isValidMove(red.first.first, red.first.second, red.second.first, red.second.second));
+        }
+        // (f4) startSelfPlay(2): same rand() stream on both sides; no local ply cap, done = checkGameOver()
+        std::vector<std::pair<int, std::pair<int, int>>> seen;
+        ai.gameCompleted = [&](int g, int r, int b) { seen.push_back({g, {r, b}}); ai.onGameCompleted(g, r, b); };
+        int finished = 0;
+        ai.selfPlayFinished = [&]() { ++finished; };
+        ai.numGames = 2;
+        std::srand(31337);
+        ai.startSelfPlay(2);
+        std::srand(31337);
+        xqo_episode_stats st[2];
+        xqo_board fin;
+        std::string want_log;
+        for (int g = 0; g < 2; ++g) {
+            xqo_selfplay_game(L, 3, w.data(), bb.data(), 0.001, 0.99, 0.1, crand, nullptr, RAND_MAX, 0, &fin, &st[g]);
+            char line[256];
+            xqo_game_log_line(g + 1, st[g].redScore, st[g].blackScore, 2, line, sizeof line);
+            want_log += line;
+        }
+        CHECK(finished == 1 && seen.size() == 2);
+        for (int g = 0; g < 2 && g < (int)seen.size(); ++g)
+            CHECK(seen[g].first == g + 1 && seen[g].second.first == st[g].redScore && seen[g].second.second == st[g].blackScore);
+        CHECK(std::memcmp(board.squares(), fin.sq, 90) == 0 && board.getMoveCount() == fin.moveCount);
+        CHECK(board.checkGameOver() && (int)board.getWinner() == st[1].winner);
+        std::vector<double> w2, b2;
+        ai.network()->getParameters(w2, b2);
+        double err = 0; for (size_t i = 0; i < w.size(); ++i) err = std::fmax(err, std::fabs(w2[i] - w[i]));
+        CHECK(err < 1e-4);
+        // (f3) the literal game_log.txt text (chessai.cpp:379-385), incl. the session trailer after the last game
+        std::ifstream lf("game_log.txt");
+        const std::string got((std::istreambuf_iterator<char>(lf)), std::istreambuf_iterator<char>());
+        CHECK(got == want_log);
+        if (got != want_log) std::printf("log got:\n%s\nwant:\n%s\n", got.c_str(), want_log.c_str());
+        char line[256];
+        xqo_game_log_line(7, 30, 30, 9, line, sizeof line);
+        CHECK(std::string(line) == "Game 7 completed. Red Score: 30, Black Score: 30. It's a draw!\n");
+        xqo_game_log_line(9, 10, 45, 9, line, sizeof line);
+        CHECK(std::string(line) == "Game 9 completed. Red Score: 10, Black Score: 45. Black wins!\nAI self-play session completed. Total games: 9\n\n");
+    }
+    // ---- ChessBoard is a value type (chessboard.h:33-88) + the seven public validators (chessboard.h:50-56) ----
+    {
+        xq::ChessBoard a;
+        a.movePiece(2, 1, 9, 1);                         // cannon takes the horse
+        xq::ChessBoard b(a);                             // copy = an independent game in the same state
+        CHECK(std::memcmp(a.squares(), b.squares(), 90) == 0 && b.getMoveCount() == 1 && b.getRedScore() == a.getRedScore());
+        CHECK(b.getCurrentPlayer() == xq::PieceColor::Black);
+        b.movePiece(9, 0, 9, 1);                         // chariot retakes on the copy only
+        CHECK(a.getMoveCount() == 1 && b.getMoveCount() == 2 && a.getPieceAt(9, 1).type == xq::PieceType::Cannon);
+        xq::ChessBoard c;
+        c = b;
+        CHECK(std::memcmp(c.squares(), b.squares(), 90) == 0 && c.getBlackScore() == b.getBlackScore() && c.getMoveCount() == 2);
+        // validators: geometry + occupancy as upstream writes them, for whatever stands on `from`
+        CHECK(a.isValidGeneralMove(0, 4, 1, 4) && !a.isValidGeneralMove(0, 4, 0, 2) && !a.isValidGeneralMove(3, 4, 4, 4));
+        CHECK(a.isValidAdvisorMove(0, 3, 1, 4) && !a.isValidAdvisorMove(0, 3, 1, 2));
+        CHECK(a.isValidAdvisorMove(-1, 2, 0, 3));        // `from` outside the board: only `to` is tested (chessboard.cpp:346-353)
+        CHECK(a.isValidElephantMove(0, 2, 2, 4) && !a.isValidElephantMove(3, 2, 5, 4));
+        CHECK(a.isValidHorseMove(0, 1, 2, 2) && !a.isValidHorseMove(0, 1, 1, 3));   // (1,3): leg (0,2) is occupied
+        CHECK(a.isValidChariotMove(0, 0, 2, 0) && !a.isValidChariotMove(0, 0, 4, 0) && !a.isValidChariotMove(0, 0, 1, 1));
+        CHECK(a.isValidCannonMove(2, 7, 9, 7) && !a.isValidCannonMove(2, 7, 7, 7) && a.isValidCannonMove(2, 7, 6, 7));
+        CHECK(a.isValidSoldierMove(3, 0, 4, 0) && !a.isValidSoldierMove(3, 0, 3, 1) && a.isValidSoldierMove(6, 0, 5, 0));
+        CHECK(a.isValidSoldierMove(4, 4, 3, 4));         // empty `from` takes the Black branch (chessboard.cpp:432-439)
+        bool threw = false;
+        try { a.isValidChariotMove(0, 0, 0, 0); } catch (const std::runtime_error&) { threw = true; }   // loop overflow upstream
+        CHECK(threw);
+        // repeated probes of a finished game fabricate nothing
+        uint8_t sq[90] = {0};
+        sq[4] = 1;
+        a.setState(sq, 17, xq::PieceColor::Red, 0, 0);
+        for (int i = 0; i < 5; ++i) CHECK(a.checkGameOver());
+        xq_episode_record rec[8]; int n = -1; uint64_t total = 99;
+        CHECK(xq_env_drain_episodes(a.handle(), rec, 8, &n, &total) == XQ_OK && n == 0 && total == 0);
+        uint64_t cnt[6];
+        CHECK(xq_env_counters(a.handle(), cnt) == XQ_OK && cnt[1] == 0 && cnt[2] == 0 && cnt[3] == 0);
     }
     // ---- ReplayBuffer / VecEnv ----
     {

@@ -76,6 +76,74 @@ def test_valid_matrix_matches_reference(xq, golden_dir):
     env.close()
 
 
+def test_positions_with_more_than_64_moves(xq, golden_dir):
+    """The `lane + 64 < n_moves` half of move generation, compaction and select on real-reference positions with 65..77 moves."""
+    t = np.load(os.path.join(golden_dir, "ref_bigmoves.npz"))
+    n = len(t["moveCount"])
+    env = xq.VecEnv(n)
+    env.set_state(t["board"], _meta(t))
+    for colour, key in ((0, "red"), (1, "black")):
+        codes, counts = env.legal_moves(colour)
+        assert np.array_equal(counts, np.diff(t[key + "_off"]))
+        for i in range(n):
+            assert np.array_equal(codes[i, :counts[i]], _ragged(t, key, i)), (key, i)
+    # greedy select over the long lists: Q rows that put the maximum on a move in the second half of the list (index >= 64)
+    codes, counts = env.legal_moves(-1)
+    q = np.full((n, 90), -0.5, dtype=np.float32)
+    want = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        k = int(counts[i]) - 1 - (i % 5) if counts[i] > 64 else int(counts[i]) - 1
+        to = int(codes[i, k]) % 90
+        q[i, to] = 0.25 + 0.001 * i
+        want[i] = next(int(c) for c in codes[i, :counts[i]] if int(c) % 90 == to)     # first move onto that square wins
+    res = env.selfplay_step(q, 0.0)
+    assert np.array_equal(res["action"], want) and np.array_equal(res["n_moves"], counts)
+    mv = t["move"].astype(np.int64)
+    env.set_state(t["board"], _meta(t))
+    res = env.step(((mv[:, 0] * 9 + mv[:, 1]) * 90 + mv[:, 2] * 9 + mv[:, 3]).astype(np.int32), auto_reset=False)
+    assert np.array_equal(res["valid"], t["valid"]) and np.array_equal(res["captured"], t["captured"])
+    env.close()
+
+
+def test_public_piece_validators_match_reference(xq, golden_dir):
+    """xq_env_rule_matrix / xq_env_rule_query == the real reference's isValid{General..Soldier}Move (chessboard.h:50-56)."""
+    g = np.load(os.path.join(golden_dir, "ref_rulemat.npz"))
+    n = len(g["board"])
+    env = xq.VecEnv(n)
+    env.set_state(g["board"])
+    for i in range(n):
+        want = np.unpackbits(g["rule_bits"][i])[:7 * 8100].reshape(7, 8100)
+        assert np.array_equal(env.rule_matrix(i), want), i
+        for q, res in zip(g["query"][i][:16], g["query_result"][i][:16]):
+            assert env.rule_query(i, *(int(x) for x in q)) == bool(res), (i, q)
+    with pytest.raises(xq._capi.XqError) as e:
+        env.rule_query(0, 5, 3, 3, 3, 3)                 # from == to on a chariot: loop overflow upstream
+    assert e.value.code == 5
+    env.close()
+
+
+def test_probing_a_finished_game_fabricates_nothing(xq):
+    """A rejected move on an already finished board reports terminated/winner but adds no episode, no win, no reset."""
+    env = xq.VecEnv(2)
+    boards = np.zeros((2, 90), dtype=np.uint8)
+    boards[:, 4] = 1                                       # lone red general: checkGameOver() is true
+    env.set_state(boards, np.array([[30, 1, 5, 7], [30, 1, 5, 7]], dtype=np.int32))
+    for _ in range(4):
+        res = env.step(np.array([-1, 8100], dtype=np.int32), auto_reset=True)
+        assert (res["terminated"] == 1).all() and (res["winner"] == 0).all() and (res["valid"] == 0).all()
+    b2, m2 = env.get_state()
+    assert np.array_equal(b2, boards) and (m2 == [30, 1, 5, 7]).all()
+    c = env.counters()
+    assert c["episodes"] == 0 and c["red_wins"] == 0 and len(env.drain_episodes()[0]) == 0
+    res = env.step(np.array([4 * 90 + 13, -1], dtype=np.int32), auto_reset=True)    # a VALID move on a finished board still plays
+    assert res["valid"][0] == 1 and res["terminated"][0] == 1
+    c = env.counters()
+    assert c["episodes"] == 1 and c["red_wins"] == 1 and len(env.drain_episodes()[0]) == 1
+    b3, m3 = env.get_state()
+    assert np.array_equal(b3[0], xq.START_BOARD) and not m3[0].any() and np.array_equal(b3[1], boards[1])
+    env.close()
+
+
 def test_step_matches_reference_trace(xq, trace):
     """movePiece with the reference's recorded attempts (valid, invalid, out-of-turn, out-of-board, after game over)."""
     n = len(trace["moveCount"])

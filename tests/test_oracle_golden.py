@@ -96,6 +96,41 @@ def test_is_valid_move_matrix_matches_reference(golden_dir):
             assert len(set(codes.tolist())) == cnt
 
 
+def test_positions_with_more_than_64_moves_match_reference(golden_dir):
+    """ref_bigmoves.npz: 160 real-reference positions in which a side has 65..77 moves (second half of the 128-entry lists)."""
+    t = np.load(os.path.join(golden_dir, "ref_bigmoves.npz"))
+    L = xo.lib()
+    n = len(t["moveCount"])
+    counts = np.maximum(np.diff(t["red_off"]), np.diff(t["black_off"]))
+    assert n >= 100 and counts.min() > 64 and counts.max() >= 75
+    for i in range(n):
+        b = _board(t, i)
+        for colour, key in ((0, "red"), (1, "black")):
+            want = t[key][t[key + "_off"][i]:t[key + "_off"][i + 1]]
+            got, cnt = xo.all_valid_actions(b, colour)
+            assert cnt == len(want) and np.array_equal(got, want), (i, key)
+        fr, fc, tr, tc = (int(x) for x in t["move"][i])
+        assert L.xqo_is_valid_move(C.byref(b), fr, fc, tr, tc) == t["valid"][i]
+        assert L.xqo_move_piece(C.byref(b), fr, fc, tr, tc) == t["captured"][i]
+
+
+def test_public_piece_validators_match_reference(golden_dir):
+    """ref_rulemat.npz: isValid{General..Soldier}Move (chessboard.h:50-56) of the real reference on 24 positions — all
+    in-board (from, to) pairs per piece type plus 64 queries each with coordinates outside the board."""
+    g = np.load(os.path.join(golden_dir, "ref_rulemat.npz"))
+    L = xo.lib()
+    for i in range(len(g["board"])):
+        b = xo.board_from(g["board"][i])
+        want = np.unpackbits(g["rule_bits"][i])[:7 * 8100].reshape(7, 8100)
+        for k in range(0, 7 * 8100, 7):                  # every 7th entry of the table: 8100 checks per position
+            t, ft = divmod(k, 8100)
+            f, to = divmod(ft, 90)
+            r = L.xqo_piece_rule(C.byref(b), t + 1, f // 9, f % 9, to // 9, to % 9)
+            assert max(r, 0) == want[t, ft], (i, t, f, to)
+        for q, res in zip(g["query"][i], g["query_result"][i]):
+            assert L.xqo_piece_rule(C.byref(b), *(int(x) for x in q)) == res, (i, q)
+
+
 def test_start_position_known_answers():
     b = xo.new_board()
     red, n = xo.all_valid_actions(b, 0)

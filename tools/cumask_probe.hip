@@ -1,7 +1,7 @@
 // tools/cumask_probe.hip — does spatial partitioning with hipExtStreamCreateWithCUMask pay?  Runs the dominant persistent
 // GEMM on a stream confined to `g` CUs while a chain of small 64-tile GEMMs (proxy for the gradient chain) runs on the rest.
 // Diagnostic only.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/cumask_probe.hip -o cumask_probe
-#include "../cn_chess_ai_amd/csrc/xq_gemm.cuh"
+#include "../cn_chess_ai_amd/csrc/xq_gemm.hip.h"
 #include <cstdio>
 #include <vector>
 using namespace xq;

@@ -1,6 +1,6 @@
-// tools/gemm_bench.hip — micro-benchmark of xq_gemm.cuh on the dominant product (8100 x B x 256, column-max epilogue).
+// tools/gemm_bench.hip — micro-benchmark of xq_gemm.hip.h on the dominant product (8100 x B x 256, column-max epilogue).
 // Diagnostic only (not part of the library).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.hip -o gemm_bench
-#include "../cn_chess_ai_amd/csrc/xq_gemm.cuh"
+#include "../cn_chess_ai_amd/csrc/xq_gemm.hip.h"
 #include <cstdio>
 #include <vector>
 using namespace xq;
