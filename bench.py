@@ -36,13 +36,13 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 ENV_BYTES_PER_GAME = 2 * (48 + 16) + 360 + 105   # board+meta r/w, Q row, transition record
 
 
-def cpu_train_loop(seconds):
+def cpu_train_loop(seconds, net=(1260, 128, 8100)):
     """(plies, episodes, elapsed) of the CPU port of ChessAI::train run for ~`seconds` on the calling core."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import xqoracle as xo
     L = xo.lib()
-    sizes = xo.sizes_arr([1260, 128, 8100])
-    w, b = xo.init_weights([1260, 128, 8100], 1)
+    sizes = xo.sizes_arr(list(net))
+    w, b = xo.init_weights(list(net), 1)
     rng = C.c_uint64(12345 + os.getpid())
     st = xo.EpisodeStats()
     steps, episodes = 0, 0
@@ -75,6 +75,12 @@ def cpu_baseline(seconds=15.0):
     out = {"value": steps / el, "unit": "env steps/s (= DQN updates/s, batch 1)", "cores": 1, "kind": "port",
            "sample": f"{episodes} episodes / {steps} plies of the ChessAI::train restatement, net 1260-128-8100 fp64, "
                      f"{el:.1f} s on one host core"}
+    try:     # the same loop on the bench's OWN topology (the reference default is 1260-128-8100), bounded to ~6 s
+        s2, e2, el2 = cpu_train_loop(6.0, LAYERS)
+        out["bench_net"] = {"value": s2 / el2, "unit": "env steps/s (= DQN updates/s, batch 1)", "cores": 1,
+                            "sample": f"{e2} episodes / {s2} plies, net {'-'.join(map(str, LAYERS))} fp64, {el2:.1f} s on one host core"}
+    except Exception as e:
+        out["bench_net_error"] = str(e)[:120]
     try:
         out["all_cores"] = cpu_all_cores()
     except Exception as e:
@@ -147,6 +153,12 @@ def main():
                     help="diagnostic: time only the fused self-play kernel with the uniform-random policy (no Q-network)")
     ap.add_argument("--independent", action="store_true",
                     help="BASELINE configs[2]: N > 1 ranks train independent replicas on their own game shards, no gradient all-reduce")
+    ap.add_argument("--prefill-plies", type=int, default=300,
+                    help="uniform-random plies played in every game before anything is timed (spreads the games over all phases)")
+    ap.add_argument("--no-fill", action="store_true", help="diagnostic: do not fill the replay ring before timing")
+    ap.add_argument("--td-net", choices=("online", "target"), default="online",
+                    help="net that gives max Q(s'): online = ChessAI::train (chessai.cpp:126, headline), target = DQN::train (dqn.cpp:166)")
+    ap.add_argument("--target-sync-interval", type=int, default=10, help="updates between updateTargetNetwork() calls")
     ap.add_argument("--no-overlap", action="store_true",
                     help="queue collect and learn on one stream (collect -> learn -> apply) instead of running collect beside learn_grads")
     args = ap.parse_args()
@@ -185,8 +197,9 @@ def main():
         return env_only(args, xq, tstream)
     first, _ = xd.shard_games(rank, n_games)
     cfg = xq.TrainerConfig(n_games=n_games, layer_sizes=LAYERS, learning_rate=0.001, gamma=0.99, epsilon=0.1,
-                           replay_capacity=max(REPLAY, n_games), minibatch=minibatch, td_net=_capi.TD_TARGET_NET,
-                           backprop_mode=_capi.BACKPROP_REFERENCE, target_sync_interval=100, mean_gradient=1,
+                           replay_capacity=max(REPLAY, n_games), minibatch=minibatch,
+                           td_net=_capi.TD_ONLINE_NET if args.td_net == "online" else _capi.TD_TARGET_NET,
+                           backprop_mode=_capi.BACKPROP_REFERENCE, target_sync_interval=args.target_sync_interval, mean_gradient=1,
                            seed=0x5EED, first_game_id=first, overlap_collect=0 if args.no_overlap else 1)
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
     grads = None
@@ -207,22 +220,46 @@ def main():
             xd.allreduce_gradients(grads, world)
         t.learn_apply(1 if args.independent else world)
 
+    # ---- steady state before anything is timed: games spread over all phases, replay ring filled to capacity ----
+    cap = max(REPLAY, n_games)
+    t.random_plies(args.prefill_plies)
+    fill_collects = 0 if args.no_fill else (cap + n_games - 1) // n_games
+    for _ in range(fill_collects):
+        t.collect()                          # epsilon-greedy plies on the initial net, transitions into the ring
     for _ in range(args.warmup):
         one_step()
+    torch.cuda.synchronize()
+    c0 = t.counters()
+
+    def timed(steps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        return xd.max_over_ranks(el, device="cuda" if world > 1 else "cpu"), enq
+
     t.dqn.kernel_stats(enable=2 if args.profile_all else 3)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    host_enqueue = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = xd.max_over_ranks(elapsed, device="cuda" if world > 1 else "cpu")
+    elapsed, host_enqueue = timed(args.steps)
     stats = {s["name"]: s for s in t.dqn.kernel_stats(enable=0)}
+    c1 = t.counters()
+    # the other TD rule on the same trainer, same steady state, timed the same way (reported beside the headline)
+    other = "target" if args.td_net == "online" else "online"
+    t.set_td_net(_capi.TD_TARGET_NET if other == "target" else _capi.TD_ONLINE_NET)
+    one_step()
+    el_other, _ = timed(args.steps)
+    t.set_td_net(_capi.TD_ONLINE_NET if args.td_net == "online" else _capi.TD_TARGET_NET)
+    # workload statistics of the state the numbers were taken in (host reads, outside every timed region)
+    import numpy as np
+    _, meta = t.env.get_state()
+    _, legal_counts = t.env.legal_moves(-1)
+    rp_size, rp_cap, rp_total = t.replay.stats()
     iso = {}
     if not args.no_overlap and world == 1:
         # the same two kernels with nothing beside them (device-wide sync between collect and learn), outside the timed region:
@@ -254,10 +291,22 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "variant_td_" + other: {"value": world * n_games * args.steps / el_other, "unit": "env steps/s",
+                                    "updates_per_s": args.steps / el_other, "ms_per_step": 1e3 * el_other / args.steps},
             "config": {"workload": "BASELINE configs[1]: 8192 self-play games per GPU, DQN 1260-256-256-8100 fp32, "
                                    "replay 1M transitions, minibatch 8192, one update per ply",
                        "games_per_gpu": n_games, "layer_sizes": list(LAYERS), "replay_capacity": max(REPLAY, n_games),
-                       "minibatch": minibatch, "epsilon": 0.1, "td_net": "target", "backprop": "reference-compatible",
+                       "minibatch": minibatch, "epsilon": 0.1, "backprop": "reference-compatible",
+                       "td_net": args.td_net + (" (max Q(s') from the online net, chessai.cpp:126)" if args.td_net == "online"
+                                                else " (max Q(s') from the target net, dqn.cpp:166)"),
+                       "target_sync_interval": args.target_sync_interval,
+                       "target_syncs_in_timed_region": (c1["updates"] // max(args.target_sync_interval, 1)
+                                                        - c0["updates"] // max(args.target_sync_interval, 1)) if args.target_sync_interval else 0,
+                       "steady_state": {"prefill_random_plies": args.prefill_plies, "fill_collects": fill_collects,
+                                        "replay_fill": rp_size / rp_cap, "replay_total_pushed": rp_total,
+                                        "mean_ply": float(np.mean(meta[:, 0])), "max_ply": int(np.max(meta[:, 0])),
+                                        "mean_legal_moves": float(np.mean(legal_counts)), "max_legal_moves": int(np.max(legal_counts)),
+                                        "episodes_finished_in_timed_region": c1["episodes"] - c0["episodes"]},
                        "schedule": "collect -> learn -> apply on one stream" if args.no_overlap else
                                    "collect(t) on its own stream beside learn_grads(t), both on theta_t; minibatch from the ring minus "
                                    "the slots collect(t) writes; apply joins both",

@@ -125,6 +125,8 @@ PROTOTYPES = {
     "xq_trainer_env": [_vp, _pvp],
     "xq_trainer_dqn": [_vp, _pvp],
     "xq_trainer_replay": [_vp, _pvp],
+    "xq_trainer_random_plies": [_vp, _i],
+    "xq_trainer_set_td_net": [_vp, _i],
     "xq_trainer_collect": [_vp],
     "xq_trainer_learn_grads": [_vp],
     "xq_trainer_learn_apply": [_vp, _i],

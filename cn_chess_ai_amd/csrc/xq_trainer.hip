@@ -139,6 +139,21 @@ int xq_trainer_collect(xq_trainer* t) {
     return collect_impl(t);
 }
 
+int xq_trainer_set_td_net(xq_trainer* t, int td_net) {
+    if (!t || (td_net != XQ_TD_ONLINE_NET && td_net != XQ_TD_TARGET_NET)) return fail(XQ_ERR_INVALID_ARGUMENT, "bad td_net");
+    if (t->grads_queued) return fail(XQ_ERR_RUNTIME, "xq_trainer_set_td_net: call between iterations (after learn_apply)");
+    t->cfg.td_net = td_net;
+    return XQ_OK;
+}
+
+int xq_trainer_random_plies(xq_trainer* t, int n_plies) {
+    if (!t || n_plies < 0) return fail(XQ_ERR_INVALID_ARGUMENT, "bad argument");
+    if (t->inflight > 0 || t->grads_queued) return fail(XQ_ERR_RUNTIME, "xq_trainer_random_plies: call between iterations (after learn_apply)");
+    for (int i = 0; i < n_plies; ++i) XQ_TRY(env_selfplay_launch(t->env, nullptr, 0, 0u, nullptr, nullptr, t->stream));
+    if (t->cstream) XQ_HIP(hipEventRecord(t->ev_params, t->stream));     // the next collect (own stream) starts behind these plies
+    return XQ_OK;
+}
+
 int xq_trainer_learn_grads(xq_trainer* t) {
     if (!t) return fail(XQ_ERR_INVALID_ARGUMENT, "null trainer");
     int batch = 0;

@@ -231,6 +231,13 @@ class Trainer:
         except Exception:
             pass
 
+    def random_plies(self, n):
+        """n uniform-random plies in every game, outside the replay ring and the step counters (desynchronises the games)."""
+        call("xq_trainer_random_plies", self._h, int(n))
+
+    def set_td_net(self, td_net):
+        call("xq_trainer_set_td_net", self._h, int(td_net))
+
     def collect(self):
         call("xq_trainer_collect", self._h)
 

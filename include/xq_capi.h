@@ -266,6 +266,13 @@ int xq_trainer_destroy(xq_trainer* t);
 int xq_trainer_env(xq_trainer* t, xq_env** env);
 int xq_trainer_dqn(xq_trainer* t, xq_dqn** dqn);
 int xq_trainer_replay(xq_trainer* t, xq_replay** replay);
+/* n_plies uniform-random plies in every game (no Q-network, nothing written to the replay ring, not counted as env steps):
+ * desynchronises the games so that a measurement or a training run starts from a spread of game phases rather than from
+ * n_games copies of the opening.  Call between iterations. */
+int xq_trainer_random_plies(xq_trainer* t, int n_plies);
+/* Which net gives max Q(s') from the next learn step on: XQ_TD_ONLINE_NET (ChessAI::train, chessai.cpp:126) or XQ_TD_TARGET_NET
+ * (DQN::train, dqn.cpp:166).  Call between iterations. */
+int xq_trainer_set_td_net(xq_trainer* t, int td_net);
 int xq_trainer_collect(xq_trainer* t);                       /* one ply in every game */
 int xq_trainer_learn_grads(xq_trainer* t);                   /* sample + gradients into the grad buffer */
 int xq_trainer_learn_apply(xq_trainer* t, int world_size);   /* SGD apply (+ target sync bookkeeping) */
