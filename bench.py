@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--td-net", choices=("online", "target"), default="online",
                     help="net that gives max Q(s'): online = ChessAI::train (chessai.cpp:126, headline), target = DQN::train (dqn.cpp:166)")
     ap.add_argument("--target-sync-interval", type=int, default=10, help="updates between updateTargetNetwork() calls")
+    ap.add_argument("--torch-allreduce", action="store_true",
+                    help="diagnostic, N > 1: all-reduce through torch.distributed after learn_grads instead of the bucketed RCCL path of the C ABI")
     ap.add_argument("--no-overlap", action="store_true",
                     help="queue collect and learn on one stream (collect -> learn -> apply) instead of running collect beside learn_grads")
     args = ap.parse_args()
@@ -202,12 +204,17 @@ def main():
                            backprop_mode=_capi.BACKPROP_REFERENCE, target_sync_interval=args.target_sync_interval, mean_gradient=1,
                            seed=0x5EED, first_game_id=first, overlap_collect=0 if args.no_overlap else 1)
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
-    grads = None
+    grads, comm = None, None
     if world == 1 or args.independent:
         t.dqn.set_fused_apply(True)          # nothing reads the gradient buffer between td_grads and apply_grads
-    if world > 1:
+    elif args.torch_allreduce or backend != "nccl":   # diagnostic / one-GPU gloo rehearsal: the exchange through torch.distributed
         ptr, n = t.dqn.grad_buffer()
         grads = xd.wrap_device_floats(ptr, n)
+    else:
+        # the exchange step lives behind the C ABI: learn_grads all-reduces the gradient buffer over RCCL itself, in two
+        # buckets released by their producers (xq_dqn_set_comm); torch.distributed only carries the 128-byte id and barriers
+        comm = xd.Comm()
+        t.set_comm(comm)
 
     def one_step():
         if args.no_overlap:
@@ -312,7 +319,9 @@ def main():
                                    "the slots collect(t) writes; apply joins both",
                        "parallelism": ("1 GPU" if world == 1 else
                                        f"{world} independent shards, no all-reduce (BASELINE configs[2])" if args.independent else
-                                       f"dp{world} (games sharded, gradient all-reduce per update)")},
+                                       f"dp{world} (games sharded; per update one RCCL sum all-reduce of the 1.65 MB gradient buffer "
+                                       f"behind the C ABI, two buckets released by their producers)" if comm is not None else
+                                       f"dp{world} (games sharded, gradient all-reduce per update through torch.distributed)")},
         }
         g = stats.get("gemm_qmax_rowmax")
         if g and g["launches"]:
@@ -352,6 +361,8 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "env steps/s", "cores": 0, "kind": "port", "sample": "failed: " + str(e)[:160]}
         print(json.dumps(line), flush=True)
     t.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -120,6 +120,16 @@ PROTOTYPES = {
     "xq_dqn_kernel_stats": [_vp, _i, C.POINTER(KernelStat), _i, _pi],
     "xq_dqn_set_fused_apply": [_vp, _i],
     "xq_dqn_kernel_timeline": [_vp, C.POINTER(KernelSpan), _i, _pi],
+    "xq_comm_unique_id": [_pu8],
+    "xq_comm_create": [_i, _i, _pu8, _pvp],
+    "xq_comm_create_from_file": [_i, _i, C.c_char_p, _d, _pvp],
+    "xq_comm_destroy": [_vp],
+    "xq_comm_info": [_vp, _pi, _pi, _pu64, _pu64],
+    "xq_comm_allreduce": [_vp, _vp, C.c_size_t, _vp],
+    "xq_comm_sum_u64": [_vp, _pu64],
+    "xq_dqn_set_comm": [_vp, _vp],
+    "xq_allreduce_grads": [_vp, _vp],
+    "xq_trainer_set_comm": [_vp, _vp],
     "xq_trainer_create": [C.POINTER(TrainerConfig), _vp, _pvp],
     "xq_trainer_destroy": [_vp],
     "xq_trainer_env": [_vp, _pvp],

@@ -63,6 +63,8 @@ struct xq_dqn {
     float* grads_full = nullptr;
     float* slabs = nullptr;  size_t slabs_cap = 0;
     float* slabs_l0 = nullptr;  size_t slabs_l0_cap = 0;     // layer-0 gradient partials
+    xq_comm* comm = nullptr;                    // xq_dqn_set_comm: bucketed RCCL all-reduce of the gradient buffer inside td_grads
+    hipEvent_t ev_l0 = nullptr;                 // handle stream: the layer-0 gradient segment is final
     bool fused_apply = false;                   // xq_dqn_set_fused_apply: apply_grads may sum the layer-0 partials itself
     int l0_pending = 0;                         // > 0: that many layer-0 slabs wait in slabs_l0, not yet reduced into grads_td
     struct PendingSlab { const float* src = nullptr; int nslabs = 0; long long stride = 0; };
@@ -76,6 +78,8 @@ struct xq_dqn {
     int32_t* ha = nullptr; float* hr = nullptr; uint8_t* hd = nullptr;
     xq::Profiler prof;
 
+    // partial-sum slabs may stay unreduced until the SGD kernel only when nothing (an all-reduce) reads the buffer in between
+    bool fused() const { return fused_apply && comm == nullptr; }
     float* w0t(int net) const { return params[net]; }
     float* wrest(int net) const { return params[net] + (size_t)L[0] * L[1]; }     // layers 1.. in reference flat order
     float* wl(int net, int l) const { return l == 0 ? w0t(net) : wrest(net) + (wo[l] - wo[1]); }
@@ -88,6 +92,7 @@ namespace xq {
 
 Profiler* dqn_profiler(xq_dqn* d) { return &d->prof; }
 int dqn_fused_apply(const xq_dqn* d) { return d->fused_apply ? 1 : 0; }
+xq_comm* dqn_comm(const xq_dqn* d) { return d->comm; }
 hipStream_t dqn_stream(xq_dqn* d) { return d->stream; }
 hipEvent_t dqn_qmax_event(xq_dqn* d) { return d->ev_qmax; }
 
@@ -868,7 +873,7 @@ static int l0_gradient(xq_dqn* d, int n, float* dst) {
         XQ_HIP(hipGetLastError());
     }
     d->l0_pending = 0;
-    if (nchunks > 1 && d->fused_apply) {
+    if (nchunks > 1 && d->fused()) {
         d->l0_pending = nchunks;                     // summed inside the SGD kernel: one kernel fewer on the critical chain
     } else if (nchunks > 1) {
         ProfScope ps(d, "reduce_slabs", (double)nchunks * len, 4.0 * (nchunks + 1) * len);
@@ -952,6 +957,7 @@ static int dqn_init(xq_dqn* d, const int* layer_sizes, int n_sizes, double learn
     XQ_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
     XQ_HIP(hipEventCreateWithFlags(&d->ev_delta, hipEventDisableTiming));
     XQ_HIP(hipEventCreateWithFlags(&d->ev_qmax, hipEventDisableTiming));
+    XQ_HIP(hipEventCreateWithFlags(&d->ev_l0, hipEventDisableTiming));
     // + 128 rows of the widest layer: the persistent column-max GEMM reads whole 128-row tiles of W_out (rows beyond the
     // last output are masked in its epilogue, but must be readable)
     int widest = 0;
@@ -988,6 +994,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     if (d->ev_join) hipEventDestroy(d->ev_join);
     if (d->ev_delta) hipEventDestroy(d->ev_delta);
     if (d->ev_qmax) hipEventDestroy(d->ev_qmax);
+    if (d->ev_l0) hipEventDestroy(d->ev_l0);
     if (d->own_stream) hipStreamDestroy(d->stream);
     delete d;
     return XQ_OK;
@@ -1154,7 +1161,7 @@ int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boar
 static int side_gradients(xq_dqn* d, int n, float* const* outs, float* G) {
     const int nl = d->nl, Hl = d->hlast();
     BiasJobs bj;
-    const bool fused = d->fused_apply;
+    const bool fused = d->fused();
     const int chunk = 1024;
     const int nchunks = (n + chunk - 1) / chunk;
     const long long len_out = 96LL * Hl + 96;
@@ -1287,13 +1294,41 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     if (nl >= 3) XQ_TRY(hidden_deltas(d, n, d->deltas[nl - 2], d->L[nl - 1], d->L[nl - 1], mode, nl - 3));
     XQ_HIP(hipEventRecord(d->ev_delta, d->stream));
     XQ_TRY(l0_gradient(d, n, G + d->g_w0));
+    if (d->comm) XQ_HIP(hipEventRecord(d->ev_l0, d->stream));
     d->cur = d->side;
     const int rc = side_gradients(d, n, outs, G);
     d->cur = d->stream;
     if (rc != XQ_OK) return rc;
     XQ_HIP(hipEventRecord(d->ev_join, d->side));
+    if (d->comm) {
+        // two buckets on the communicator's stream, each released by its producer: everything behind the layer-0 segment
+        // (hidden + output-layer weights, all biases) as soon as the side stream is done, the layer-0 segment last
+        hipStream_t cs = comm_stream(d->comm);
+        const size_t n0 = (size_t)d->L[0] * d->L[1];
+        XQ_HIP(hipStreamWaitEvent(cs, d->ev_join, 0));
+        XQ_TRY(comm_allreduce_on(d->comm, G + n0, d->n_grads_td - n0, cs));
+        XQ_HIP(hipStreamWaitEvent(cs, d->ev_l0, 0));
+        XQ_TRY(comm_allreduce_on(d->comm, G, n0, cs));
+        XQ_HIP(hipEventRecord(comm_done_event(d->comm), cs));
+        XQ_HIP(hipStreamWaitEvent(d->stream, comm_done_event(d->comm), 0));
+    }
     XQ_HIP(hipStreamWaitEvent(d->stream, d->ev_join, 0));
     return XQ_OK;
+}
+
+int xq_dqn_set_comm(xq_dqn* d, xq_comm* comm) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    if (d->l0_pending > 0 || d->pend_wout.nslabs > 0)
+        return fail(XQ_ERR_RUNTIME, "xq_dqn_set_comm: a TD step is waiting for its apply_grads");
+    d->comm = comm;
+    return XQ_OK;
+}
+
+int xq_allreduce_grads(xq_dqn* d, xq_comm* comm) {
+    if (!d || !comm) return fail(XQ_ERR_INVALID_ARGUMENT, "null handle");
+    if (d->l0_pending > 0 || d->pend_wout.nslabs > 0)
+        return fail(XQ_ERR_RUNTIME, "xq_allreduce_grads: gradient slabs are still unreduced (xq_dqn_set_fused_apply is on)");
+    return comm_allreduce_on(comm, d->grads_td, d->n_grads_td, d->stream);      // in order on the handle's stream
 }
 
 int xq_dqn_apply_grads(xq_dqn* d, double lr, double grad_scale) {

@@ -112,8 +112,15 @@ struct Profiler {
     ~Profiler() { collect(); for (auto e : pool) (void)hipEventDestroy(e); }
 };
 
+// communicator internals (xq_comm.hip)
+int comm_allreduce_on(xq_comm* c, float* buf, size_t n_floats, hipStream_t stream);   // in-place sum over all ranks
+hipStream_t comm_stream(xq_comm* c);
+hipEvent_t comm_done_event(xq_comm* c);
+int comm_world(const xq_comm* c);
+
 // dqn-side entry points used by the trainer (defined in xq_dqn.hip)
 Profiler* dqn_profiler(xq_dqn* d);
+xq_comm* dqn_comm(const xq_dqn* d);         // communicator attached with xq_dqn_set_comm, or nullptr
 int dqn_fused_apply(const xq_dqn* d);      // current xq_dqn_set_fused_apply setting
 int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride, hipStream_t on = nullptr);
 hipStream_t dqn_stream(xq_dqn* d);

@@ -139,6 +139,12 @@ int xq_trainer_collect(xq_trainer* t) {
     return collect_impl(t);
 }
 
+int xq_trainer_set_comm(xq_trainer* t, xq_comm* comm) {
+    if (!t) return fail(XQ_ERR_INVALID_ARGUMENT, "null trainer");
+    if (t->grads_queued) return fail(XQ_ERR_RUNTIME, "xq_trainer_set_comm: call between iterations (after learn_apply)");
+    return xq_dqn_set_comm(t->dqn, comm);
+}
+
 int xq_trainer_set_td_net(xq_trainer* t, int td_net) {
     if (!t || (td_net != XQ_TD_ONLINE_NET && td_net != XQ_TD_TARGET_NET)) return fail(XQ_ERR_INVALID_ARGUMENT, "bad td_net");
     if (t->grads_queued) return fail(XQ_ERR_RUNTIME, "xq_trainer_set_td_net: call between iterations (after learn_apply)");
@@ -215,6 +221,7 @@ int xq_trainer_step(xq_trainer* t, int n_iterations) {
     const int plies = t->cfg.collects_per_update > 1 ? t->cfg.collects_per_update : 1;
     if (plies > 1 && t->cfg.replay_capacity == 0)
         return fail(XQ_ERR_INVALID_ARGUMENT, "collects_per_update > 1 needs a replay ring (on-policy keeps one ply)");
+    const int world = dqn_comm(t->dqn) ? comm_world(dqn_comm(t->dqn)) : 1;     // data-parallel when a communicator is attached
     const int fused_before = dqn_fused_apply(t->dqn);   // restored on every exit path: the caller's choice survives step()
     XQ_TRY(xq_dqn_set_fused_apply(t->dqn, 1));      // single-GPU loop: nothing reads the gradient buffer between grads and apply
     int rc = XQ_OK;
@@ -226,7 +233,7 @@ int xq_trainer_step(xq_trainer* t, int n_iterations) {
             for (int c = 0; c < plies && rc == XQ_OK; ++c) rc = xq_trainer_collect(t);
             if (rc == XQ_OK) rc = xq_trainer_learn_grads(t);
         }
-        if (rc == XQ_OK) rc = xq_trainer_learn_apply(t, 1);
+        if (rc == XQ_OK) rc = xq_trainer_learn_apply(t, world);
     }
     const int rc_off = xq_dqn_set_fused_apply(t->dqn, fused_before);     // also after a failed iteration
     return rc != XQ_OK ? rc : rc_off;

@@ -54,6 +54,52 @@ def allreduce_gradients(flat, world_size=None):
     return flat
 
 
+class Comm:
+    """xq_comm: the RCCL communicator behind the C ABI (include/xq_capi.h).  The 128-byte id is drawn on rank 0 and shipped
+    through torch.distributed's control plane (any backend) — the gradient traffic itself never goes through torch."""
+
+    def __init__(self, rank=None, world=None, id_bytes=None, path=None, timeout_s=120.0):
+        import ctypes as C
+        import numpy as np
+        from . import _capi
+        r, _, w = env_rank()
+        self.rank = r if rank is None else int(rank)
+        self.world = w if world is None else int(world)
+        h = C.c_void_p()
+        if path is not None:
+            _capi.call("xq_comm_create_from_file", self.rank, self.world, str(path).encode(), float(timeout_s), C.byref(h))
+        else:
+            if id_bytes is None:
+                buf = np.zeros(128, dtype=np.uint8)
+                if self.rank == 0:
+                    _capi.call("xq_comm_unique_id", buf.ctypes.data_as(C.POINTER(C.c_uint8)))
+                if self.world > 1:
+                    box = [buf.tobytes()]
+                    dist.broadcast_object_list(box, src=0)
+                    buf = np.frombuffer(box[0], dtype=np.uint8).copy()
+                id_bytes = buf.tobytes()
+            arr = np.frombuffer(id_bytes, dtype=np.uint8).copy()
+            _capi.call("xq_comm_create", self.rank, self.world, arr.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(h))
+        self._h = h
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        import ctypes as C
+        from . import _capi
+        r, w, n, f = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_uint64()
+        _capi.call("xq_comm_info", self._h, C.byref(r), C.byref(w), C.byref(n), C.byref(f))
+        return dict(rank=r.value, world=w.value, collectives=n.value, floats=f.value)
+
+    def close(self):
+        from . import _capi
+        if self._h is not None:
+            _capi.call("xq_comm_destroy", self._h)
+        self._h = None
+
+
 def max_over_ranks(value, device="cpu"):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)

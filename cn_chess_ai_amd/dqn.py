@@ -165,6 +165,14 @@ class DQN:
                      bytes=arr[i].bytes) for i in range(n.value)]
 
 
+def _set_comm(self, comm):
+    """Attach an xq_comm (dist.Comm) or None: td_grads then all-reduces the gradient buffer itself, in buckets."""
+    call("xq_dqn_set_comm", self._h, comm.handle if comm is not None else None)
+
+
+DQN.set_comm = _set_comm
+
+
 def _set_fused_apply(self, on=True):
     """apply_grads sums the layer-0 gradient partials itself (single GPU: nothing reads the gradient buffer in between)."""
     call("xq_dqn_set_fused_apply", self._h, 1 if on else 0)
@@ -234,6 +242,9 @@ class Trainer:
     def random_plies(self, n):
         """n uniform-random plies in every game, outside the replay ring and the step counters (desynchronises the games)."""
         call("xq_trainer_random_plies", self._h, int(n))
+
+    def set_comm(self, comm):
+        call("xq_trainer_set_comm", self._h, comm.handle if comm is not None else None)
 
     def set_td_net(self, td_net):
         call("xq_trainer_set_td_net", self._h, int(td_net))

@@ -324,6 +324,32 @@ private:
     int n_;
 };
 
+// ---- Comm: the RCCL communicator of the data-parallel loop (build-defined) ------------------------------------
+// One process per GPU; rank r plays games [r*n, (r+1)*n) and every update sums the gradient buffer over all ranks.
+class Comm {
+public:
+    // rendezvous through a file every rank can see (rank 0 writes the 128-byte id, the others poll)
+    Comm(int rank, int world, const std::string& rendezvousFile, double timeoutSeconds = 120.0) : rank_(rank), world_(world) {
+        check(xq_comm_create_from_file(rank, world, rendezvousFile.c_str(), timeoutSeconds, &h_));
+    }
+    // id drawn by uniqueId() on rank 0 and shipped by the caller's launcher
+    Comm(int rank, int world, const std::vector<uint8_t>& id) : rank_(rank), world_(world) {
+        if (id.size() != XQ_COMM_ID_BYTES) throw std::invalid_argument("communicator id must be 128 bytes");
+        check(xq_comm_create(rank, world, id.data(), &h_));
+    }
+    static std::vector<uint8_t> uniqueId() { std::vector<uint8_t> id(XQ_COMM_ID_BYTES); check(xq_comm_unique_id(id.data())); return id; }
+    ~Comm() { xq_comm_destroy(h_); }
+    Comm(const Comm&) = delete;
+    Comm& operator=(const Comm&) = delete;
+    int rank() const { return rank_; }
+    int world() const { return world_; }
+    uint64_t collectivesIssued() const { uint64_t n = 0; check(xq_comm_info(h_, nullptr, nullptr, &n, nullptr)); return n; }
+    xq_comm* handle() const { return h_; }
+private:
+    xq_comm* h_ = nullptr;
+    int rank_, world_;
+};
+
 // ---- ChessAI, chessai.h:17-56 ---------------------------------------------------------------------------------------
 class ChessAI {
 public:
@@ -461,6 +487,10 @@ public:
 
     // ---- beyond the reference surface ----
     void setParallelGames(int n) { parallelGames_ = n; }
+    // data-parallel train(): this process is rank comm->rank() of comm->world(); its batched games take the id range
+    // [rank * parallelGames, (rank + 1) * parallelGames) and every update all-reduces the gradients over RCCL (nullptr = off)
+    void setCommunicator(Comm* comm) { comm_ = comm; }
+    void setBatchSeed(uint64_t seed) { batchSeed_ = seed; }                  // 0 (default): time-seeded like upstream
     void setDQN(std::unique_ptr<DQN> d) { dqn = std::move(d); }
     DQN* network() { return dqn.get(); }
     std::vector<double> getStateRepresentation() {                           // chessai.cpp:268-289 (encoding only)
@@ -487,7 +517,8 @@ private:
         cfg.td_net = XQ_TD_ONLINE_NET;           // chessai.cpp:126 uses the online net
         cfg.backprop_mode = XQ_BACKPROP_REFERENCE;
         cfg.target_sync_interval = 100; cfg.mean_gradient = 1;
-        cfg.seed = (uint64_t)std::time(nullptr); cfg.first_game_id = 0;
+        cfg.seed = batchSeed_ ? batchSeed_ : (uint64_t)std::time(nullptr);   // replicas must share it: it seeds the initial weights
+        cfg.first_game_id = comm_ ? (uint32_t)(comm_->rank() * cfg.n_games) : 0u;
         xq_trainer* t = nullptr;
         check(xq_trainer_create(&cfg, nullptr, &t));
         struct Guard { xq_trainer* t; ~Guard() { xq_trainer_destroy(t); } } guard{t};   // released on every path, also when check() throws
@@ -497,9 +528,14 @@ private:
         dqn->getParameters(w, b);                // continue from this agent's weights
         check(xq_dqn_set_params(td, XQ_NET_ONLINE, w.data(), b.data()));
         check(xq_dqn_update_target(td));
+        if (comm_) check(xq_trainer_set_comm(t, comm_->handle()));
         std::vector<xq_episode_record> rec(4096);
+        // Every rank must run the same number of iterations (each carries a collective): the loop ends when the episodes
+        // finished on ALL ranks together reach numEpisodes per rank; a rank reports at most its own numEpisodes.
+        const uint64_t quota = (uint64_t)numEpisodes * (uint64_t)(comm_ ? comm_->world() : 1);
         int finished = 0;
-        while (finished < numEpisodes) {
+        uint64_t localDone = 0;
+        for (;;) {
             check(xq_trainer_step(t, 8));
             int n = 0; uint64_t total = 0;
             do {
@@ -509,6 +545,10 @@ private:
                     if (gameCompleted) gameCompleted(episodes_, rec[i].red_score, rec[i].black_score);
                 }
             } while (n == (int)rec.size());
+            localDone = total;
+            uint64_t global = localDone;
+            if (comm_) check(xq_comm_sum_u64(comm_->handle(), &global));
+            if (comm_ ? global >= quota : finished >= numEpisodes) break;
         }
         check(xq_dqn_get_params(td, XQ_NET_ONLINE, w.data(), b.data()));
         dqn->setParameters(w, b);
@@ -523,6 +563,8 @@ private:
     int moveCount_ = 0;
     int episodes_ = 0;
     int parallelGames_ = 8192;
+    Comm* comm_ = nullptr;
+    uint64_t batchSeed_ = 0;
 };
 
 }  // namespace xq

@@ -234,6 +234,34 @@ typedef struct { char name[48]; float start_ms; float end_ms; } xq_kernel_span;
 int xq_dqn_kernel_timeline(xq_dqn* d, xq_kernel_span* spans, int max_spans, int* n_spans);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * xq_comm — the one exchange step of the data-parallel loop (no upstream analogue: the reference is
+ * single-GPU): games are sharded over ranks by contiguous game-id ranges, one process per GPU, and each update sums
+ * the compact TD gradient buffer over all ranks with an RCCL all-reduce over xGMI; every replica then applies the same SGD
+ * step (xq_trainer_learn_apply scales by 1/(minibatch*world)).  RCCL is loaded on first use.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct xq_comm xq_comm;
+enum { XQ_COMM_ID_BYTES = 128 };
+/* rank 0 draws the communicator id (ncclGetUniqueId) and ships the 128 bytes to the other ranks out of band. */
+int xq_comm_unique_id(uint8_t* id128);
+/* ncclCommInitRank on the calling process's current device (xq_set_device).  Collective: every rank calls it. */
+int xq_comm_create(int rank, int world, const uint8_t* id128, xq_comm** out);
+/* Same, with the id exchanged through a file every rank can see (rank 0 writes, the others poll up to timeout_s). */
+int xq_comm_create_from_file(int rank, int world, const char* path, double timeout_s, xq_comm** out);
+int xq_comm_destroy(xq_comm* c);
+int xq_comm_info(const xq_comm* c, int* rank, int* world, uint64_t* collectives_issued, uint64_t* floats_reduced);
+/* Sum of one host counter over all ranks (blocking; control decisions every rank must take alike, e.g. "enough episodes"). */
+int xq_comm_sum_u64(xq_comm* c, uint64_t* inout_host);
+/* In-place sum of n_floats fp32 over all ranks on hip_stream (NULL = the communicator's own stream). */
+int xq_comm_allreduce(xq_comm* c, float* buf_dev, size_t n_floats, void* hip_stream);
+/* Attach (or detach with NULL) a communicator: every xq_dqn_td_grads* then all-reduces the gradient buffer itself, in two
+ * buckets on the communicator's stream — [hidden + output-layer weights, biases] as soon as the side stream has produced
+ * them, the layer-0 segment (the largest and last) behind the layer-0 kernel — and returns with the handle's stream
+ * ordered behind both.  xq_dqn_apply_grads therefore sees the global sum.  world = 1 is bit-identical to no communicator. */
+int xq_dqn_set_comm(xq_dqn* d, xq_comm* comm);
+/* One all-reduce of the whole gradient buffer on the handle's stream, for callers that do not attach a communicator. */
+int xq_allreduce_grads(xq_dqn* d, xq_comm* comm);
+
+/* ------------------------------------------------------------------------------------------------------------
  * xq_trainer — the ChessAI::train() loop (chessai.cpp:85-170) for n_games boards at once, on device.
  *   collect : Q(s)[0..89] for every game -> xq_env_selfplay_step -> transitions into the replay ring
  *   learn   : sample minibatch -> xq_dqn_td_grads  [caller may all-reduce xq_dqn_grad_buffer] -> apply
@@ -266,6 +294,8 @@ int xq_trainer_destroy(xq_trainer* t);
 int xq_trainer_env(xq_trainer* t, xq_env** env);
 int xq_trainer_dqn(xq_trainer* t, xq_dqn** dqn);
 int xq_trainer_replay(xq_trainer* t, xq_replay** replay);
+/* xq_dqn_set_comm on the trainer's network: learn_grads then carries the bucketed all-reduce, learn_apply(world) the mean. */
+int xq_trainer_set_comm(xq_trainer* t, xq_comm* comm);
 /* n_plies uniform-random plies in every game (no Q-network, nothing written to the replay ring, not counted as env steps):
  * desynchronises the games so that a measurement or a training run starts from a spread of game phases rather than from
  * n_games copies of the opening.  Call between iterations. */
@@ -276,7 +306,7 @@ int xq_trainer_set_td_net(xq_trainer* t, int td_net);
 int xq_trainer_collect(xq_trainer* t);                       /* one ply in every game */
 int xq_trainer_learn_grads(xq_trainer* t);                   /* sample + gradients into the grad buffer */
 int xq_trainer_learn_apply(xq_trainer* t, int world_size);   /* SGD apply (+ target sync bookkeeping) */
-int xq_trainer_step(xq_trainer* t, int n_iterations);        /* (collect x collects_per_update) + learn_grads + learn_apply, n times (single GPU) */
+int xq_trainer_step(xq_trainer* t, int n_iterations);        /* (collect x collects_per_update) + learn_grads + learn_apply(world of the attached communicator, else 1), n times */
 int xq_trainer_counters(xq_trainer* t, uint64_t* env_steps, uint64_t* updates, uint64_t* episodes);
 
 #ifdef __cplusplus

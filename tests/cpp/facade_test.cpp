@@ -278,6 +278,29 @@ int main() {
         uint64_t cnt[6];
         CHECK(xq_env_counters(a.handle(), cnt) == XQ_OK && cnt[1] == 0 && cnt[2] == 0 && cnt[3] == 0);
     }
+    // ---- data-parallel train() from C++: RCCL behind the C ABI, one-rank communicator through the file rendezvous ----
+    {
+        std::remove("xq_comm_id");
+        xq::Comm comm(0, 1, "xq_comm_id");
+        CHECK(comm.rank() == 0 && comm.world() == 1 && comm.collectivesIssued() == 0);
+        const std::vector<int> sizes{1260, 32, 8100};
+        std::vector<double> w[2], bb[2];
+        for (int pass = 0; pass < 2; ++pass) {         // pass 0: no communicator, pass 1: all-reduce over the one-rank communicator
+            xq::ChessBoard board;
+            xq::ChessAI ai(&board);
+            ai.setDQN(std::make_unique<xq::DQN>(sizes, 0.001, 0.99, 7));
+            ai.setParallelGames(32);
+            ai.setBatchSeed(4711);
+            int completed = 0;
+            ai.gameCompleted = [&](int, int, int) { ++completed; };
+            if (pass == 1) ai.setCommunicator(&comm);
+            ai.train(32);
+            CHECK(completed == 32);
+            ai.network()->getParameters(w[pass], bb[pass]);
+        }
+        CHECK(comm.collectivesIssued() > 0 && comm.collectivesIssued() % 2 == 0);     // two buckets per update
+        CHECK(w[0] == w[1] && bb[0] == bb[1]);          // sum over one rank = identity: bit-identical training
+    }
     // ---- ReplayBuffer / VecEnv ----
     {
         xq::ReplayBuffer rb(8, 3);

@@ -64,8 +64,9 @@ def test_struct_layouts_match_header(capi):
 def test_no_device_fails_loudly(capi):
     import cn_chess_ai_amd as xq
     assert capi.device_count() == 0
+    from cn_chess_ai_amd import dist as xd
     for make in (lambda: xq.VecEnv(4), lambda: xq.DQN([1260, 128, 8100]), lambda: xq.ReplayBuffer(16),
-                 lambda: xq.Trainer(xq.TrainerConfig(n_games=4))):
+                 lambda: xq.Trainer(xq.TrainerConfig(n_games=4)), lambda: xd.Comm(rank=0, world=1, id_bytes=bytes(128))):
         with pytest.raises(xq.XqError) as e:
             make()
         assert e.value.code == 3 and "no CPU fallback" in str(e.value)
