@@ -143,12 +143,17 @@ def overlap_window(size, total, cap, m):
     return (w + m) % cap, cap - m
 
 
-@pytest.mark.parametrize("n,cap,minibatch,plies,iters", [(64, 256, 48, 1, 9), (32, 200, 64, 2, 8), (2048, 1 << 15, 2048, 1, 6)])
-def test_overlapped_trainer_equals_its_sequential_definition(xq, n, cap, minibatch, plies, iters):
+CFG4_NET = (1260, 512, 512, 512, 8100)          # BASELINE configs[3]: (512,512,512) hidden layers, 4 plies per update
+
+
+@pytest.mark.parametrize("n,cap,minibatch,plies,iters,sizes", [
+    (64, 256, 48, 1, 9, CFG2_NET), (32, 200, 64, 2, 8, CFG2_NET), (2048, 1 << 15, 2048, 1, 6, CFG2_NET),
+    (256, 4096, 512, 4, 5, CFG4_NET)])           # configs[3] topology and cadence at a size the composition finishes quickly
+def test_overlapped_trainer_equals_its_sequential_definition(xq, n, cap, minibatch, plies, iters, sizes):
     """Iteration t: minibatch drawn from the ring minus the slots collect(t) writes, gradients with theta_t; collect(t) acts with
     theta_t; then apply.  First iteration (nothing older in the ring): collect, then learn on what was just played."""
     import torch
-    seed, first, sizes = 99, 7, CFG2_NET
+    seed, first = 99, 7
     cfg = xq.TrainerConfig(n_games=n, layer_sizes=sizes, learning_rate=0.01, gamma=0.99, epsilon=0.2, replay_capacity=cap,
                            minibatch=minibatch, td_net=1, backprop_mode=0, target_sync_interval=3, mean_gradient=1, seed=seed,
                            first_game_id=first, collects_per_update=plies, overlap_collect=1)
@@ -194,6 +199,38 @@ def test_overlapped_trainer_equals_its_sequential_definition(xq, n, cap, minibat
     assert np.array_equal(w, tw) and np.array_equal(b, tb)
     assert np.abs(w - w0).max() > 0
     t.close(); env.close(); d.close(); rp.close()
+
+
+def test_baseline_config4_full_size(xq):
+    """BASELINE configs[3] per GPU at FULL size: 8192 games, (512,512,512), 4 plies per update, collect overlapped with the TD
+    step, minibatch 8192 from a 256 k ring.  Size-independent properties: counters, finite parameters and loss, every
+    sampled transition well-formed, and a bit-identical rerun (no race between the three streams, no float atomics)."""
+    def run():
+        cfg = xq.TrainerConfig(n_games=8192, layer_sizes=CFG4_NET, replay_capacity=1 << 18, minibatch=8192, collects_per_update=4,
+                               target_sync_interval=2, td_net=0, overlap_collect=1, seed=0x5EED, first_game_id=8192)
+        t = xq.Trainer(cfg)
+        w0, _ = t.dqn.get_params()
+        t.random_plies(40)
+        t.step(5)
+        c = t.counters()
+        w, b = t.dqn.get_params()
+        wt, _ = t.dqn.get_params(net=1)
+        boards, meta = t.env.get_state()
+        loss = t.dqn.last_loss()
+        size, cap, tot = t.replay.stats()
+        acts = [t.replay.get(s)[1] for s in range(0, size, 4099)]
+        t.close()
+        return c, w, b, wt, boards, meta, loss, (size, cap, tot), (acts, w0)
+    c, w, b, wt, boards, meta, loss, rp, (acts, w0) = run()
+    assert c["env_steps"] == 8192 * 4 * 5 and c["updates"] == 5
+    assert rp == (8192 * 20, 1 << 18, 8192 * 20)
+    assert np.isfinite(w).all() and np.isfinite(b).all() and np.isfinite(loss) and loss > 0
+    assert not np.array_equal(wt, w0) and not np.array_equal(wt, w)      # target = the weights after update 4 (sync every 2)
+    assert all(-1 <= a < 90 for a in acts)
+    assert meta[:, 0].max() <= 200 and (boards <= 14).all()
+    c2, w2, b2, wt2, boards2, meta2, loss2, rp2, _ = run()
+    assert c2 == c and np.array_equal(w, w2) and np.array_equal(b, b2) and np.array_equal(wt, wt2)
+    assert np.array_equal(boards, boards2) and np.array_equal(meta, meta2) and loss == loss2
 
 
 def test_overlap_needs_a_replay_ring(xq):
