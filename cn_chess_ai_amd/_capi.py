@@ -15,7 +15,8 @@ BOARD_WORDS = 12
 MAX_LAYERS = 8
 NET_ONLINE, NET_TARGET = 0, 1
 BACKPROP_REFERENCE, BACKPROP_TEXTBOOK = 0, 1
-TD_ONLINE_NET, TD_TARGET_NET = 0, 1
+TD_ONLINE_NET, TD_TARGET_NET, TD_DOUBLE = 0, 1, 2
+PRECISION_F32, PRECISION_BF16 = 0, 1
 
 STATUS_NAMES = {1: "XQ_ERR_INVALID_ARGUMENT", 2: "XQ_ERR_RUNTIME", 3: "XQ_ERR_NO_DEVICE", 4: "XQ_ERR_IO",
                 5: "XQ_ERR_UNDEFINED_UPSTREAM"}
@@ -53,7 +54,9 @@ class TrainerConfig(C.Structure):
                 ("learning_rate", C.c_double), ("gamma", C.c_double), ("epsilon", C.c_double),
                 ("replay_capacity", C.c_int), ("minibatch", C.c_int), ("td_net", C.c_int), ("backprop_mode", C.c_int),
                 ("target_sync_interval", C.c_int), ("mean_gradient", C.c_int), ("seed", C.c_uint64),
-                ("first_game_id", C.c_uint32), ("collects_per_update", C.c_int), ("overlap_collect", C.c_int)]
+                ("first_game_id", C.c_uint32), ("collects_per_update", C.c_int), ("overlap_collect", C.c_int),
+                ("prioritized", C.c_int), ("per_alpha", C.c_double), ("per_beta", C.c_double), ("per_eps", C.c_double),
+                ("precision", C.c_int)]
 
 
 assert C.sizeof(StepResult) == 24 and C.sizeof(EpisodeRecord) == 16
@@ -100,8 +103,15 @@ PROTOTYPES = {
     "xq_replay_sample": [_vp, _i, _pi],
     "xq_replay_sample_window": [_vp, _i, _i, _i, _pi],
     "xq_replay_get": [_vp, _i, _pu8, _pi, _pf, _pu8, _pu8],
+    "xq_replay_enable_per": [_vp, _d, _d, _d],
+    "xq_replay_per_rebuild": [_vp, _i, _i],
+    "xq_replay_sample_prioritized": [_vp, _i, _pi, _pf],
+    "xq_replay_set_priorities": [_vp, _i, _i, _pf],
+    "xq_replay_get_priorities": [_vp, _i, _i, _pf],
+    "xq_replay_per_stats": [_vp, _pf, _pf, _pi],
     "xq_dqn_create": [_pi, _i, _d, _d, _u64, _vp, _pvp],
     "xq_dqn_destroy": [_vp],
+    "xq_dqn_set_precision": [_vp, _i],
     "xq_dqn_num_params": [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "xq_dqn_set_params": [_vp, _i, _pd, _pd],
     "xq_dqn_get_params": [_vp, _i, _pd, _pd],

@@ -38,6 +38,18 @@ struct xq_dqn {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_delta = nullptr;
     hipEvent_t ev_qmax = nullptr;               // recorded behind the column-max GEMM of the last TD step (trainer: collect starts here)
     float* params[2] = {nullptr, nullptr};
+    // bf16 Q-net (xq_dqn_set_precision): bf16 shadow of the WEIGHTS of both nets, same element order as params[] (biases stay fp32);
+    // forward kernels read the shadow, the backward pass and the SGD step work on the fp32 master copy and refresh the shadow
+    int precision = XQ_PRECISION_F32;
+    uint16_t* params_bf[2] = {nullptr, nullptr};
+    uint16_t* acts_bf[XQ_MAX_LAYERS] = {nullptr};      // bf16 bits of acts[] (acts[] then holds the same, rounded, values in fp32)
+    uint16_t* tacts_bf[2] = {nullptr, nullptr};
+    uint16_t* t2acts_bf[2] = {nullptr, nullptr};
+    uint16_t* sel_acts_bf[XQ_MAX_LAYERS] = {nullptr};
+    int cap_bf = 0, sel_cap_bf = 0;
+    float* t2acts[2] = {nullptr, nullptr};             // third forward chain of a Double-DQN step (s' on the target net)
+    int cap_t2 = 0;
+    int* partial_idx = nullptr;  int cap_idx = 0;      // row index of each column-max partial (Double DQN)
     // workspaces sized for `cap` samples
     int cap = 0;
     float* acts[XQ_MAX_LAYERS] = {nullptr};     // online hidden activations a_{l+1} = tanh(z_l), l = 0..nl-2
@@ -80,6 +92,8 @@ struct xq_dqn {
 
     // partial-sum slabs may stay unreduced until the SGD kernel only when nothing (an all-reduce) reads the buffer in between
     bool fused() const { return fused_apply && comm == nullptr; }
+    bool bf16() const { return precision == XQ_PRECISION_BF16; }
+    uint16_t* wl_bf(int net, int l) const { return params_bf[net] + (l == 0 ? 0 : (size_t)L[0] * L[1] + (wo[l] - wo[1])); }
     float* w0t(int net) const { return params[net]; }
     float* wrest(int net) const { return params[net] + (size_t)L[0] * L[1]; }     // layers 1.. in reference flat order
     float* wl(int net, int l) const { return l == 0 ? w0t(net) : wrest(net) + (wo[l] - wo[1]); }
@@ -121,18 +135,24 @@ __device__ __forceinline__ int slot_of(const SlotSrc& s, int b) {
     }
     return s.slots ? s.slots[b] : b;
 }
-// the two forward chains of a TD step (s on the online net, s' on the TD net) share one launch per layer
+// the forward chains of a TD step (s on the online net, s' on the TD net, and for Double DQN s' on the target net as well)
+// share one launch per layer
+enum { kMaxChains = 3 };
 struct L0Jobs {
-    const uint32_t* boards[2];
-    const float* W0T[2];
-    const float* b0[2];
-    float* out[2];
-    uint32_t* gathered[2];
+    const uint32_t* boards[kMaxChains];
+    const float* W0T[kMaxChains];
+    const uint16_t* W0T_bf[kMaxChains];      // bf16 Q-net: shadow of W0^T (same [1260][H] order)
+    const float* b0[kMaxChains];
+    float* out[kMaxChains];                  // fp32 activations (may be nullptr in bf16 mode when nothing reads them)
+    uint16_t* out_bf[kMaxChains];            // bf16 Q-net: bf16 bits of the activations
+    uint32_t* gathered[kMaxChains];
     int njobs;
 };
 
 // Layer 0 from packed boards: a_1 = tanh(b_0 + sum over occupied squares of W0^T[sq*14 + piece-1][:]).
 // One wave per sample; ascending square order = the reference's i-ascending accumulation with the zeros skipped.
+// BF16: rows come from the bf16 shadow (half the L2 traffic of this gather), the sum runs in fp32, the result is rounded to bf16.
+template <bool BF16>
 __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, int n, int H) {
     __shared__ int rows[4][96];
     const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
@@ -140,8 +160,10 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
     if (b >= n) return;
     const int job = (int)blockIdx.y;
     const float* __restrict__ W0T = J.W0T[job];
+    const uint16_t* __restrict__ W0B = J.W0T_bf[job];
     const float* __restrict__ b0 = J.b0[job];
     float* __restrict__ out = J.out[job];
+    uint16_t* __restrict__ out_bf = J.out_bf[job];
     uint32_t* __restrict__ gathered = J.gathered[job];
     const int srow = slot_of(src, b);
     const uint32_t* bw = J.boards[job] + (long long)srow * kBoardWords;
@@ -159,32 +181,46 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float* o = out + (long long)b * H;
+    auto load4 = [&](int row, int col) -> float4 {
+        if (BF16) {
+            const uint2 x = *reinterpret_cast<const uint2*>(W0B + (long long)row * H + col);
+            return make_float4(__builtin_bit_cast(float, x.x << 16), __builtin_bit_cast(float, x.x & 0xFFFF0000u),
+                               __builtin_bit_cast(float, x.y << 16), __builtin_bit_cast(float, x.y & 0xFFFF0000u));
+        }
+        return *reinterpret_cast<const float4*>(W0T + (long long)row * H + col);
+    };
     if ((H & 3) == 0) {
         for (int col = lane * 4; col < H; col += 256) {
             float4 acc = *reinterpret_cast<const float4*>(b0 + col);
             int i = 0;
             for (; i + 4 <= cnt; i += 4) {
-                const float4 w0 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i] * H + col);
-                const float4 w1 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i + 1] * H + col);
-                const float4 w2 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i + 2] * H + col);
-                const float4 w3 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i + 3] * H + col);
+                const float4 w0 = load4(rows[wid][i], col), w1 = load4(rows[wid][i + 1], col);
+                const float4 w2 = load4(rows[wid][i + 2], col), w3 = load4(rows[wid][i + 3], col);
                 acc.x = ((acc.x + w0.x) + w1.x) + w2.x + w3.x;
                 acc.y = ((acc.y + w0.y) + w1.y) + w2.y + w3.y;
                 acc.z = ((acc.z + w0.z) + w1.z) + w2.z + w3.z;
                 acc.w = ((acc.w + w0.w) + w1.w) + w2.w + w3.w;
             }
             for (; i < cnt; ++i) {
-                const float4 w = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i] * H + col);
+                const float4 w = load4(rows[wid][i], col);
                 acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
             }
-            *reinterpret_cast<float4*>(o + col) = make_float4(tanhf(acc.x), tanhf(acc.y), tanhf(acc.z), tanhf(acc.w));
+            float4 t = make_float4(tanhf(acc.x), tanhf(acc.y), tanhf(acc.z), tanhf(acc.w));
+            if (BF16) {
+                const uint16_t q0 = bf16_bits(t.x), q1 = bf16_bits(t.y), q2 = bf16_bits(t.z), q3 = bf16_bits(t.w);
+                *reinterpret_cast<uint2*>(out_bf + (long long)b * H + col) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
+                t = make_float4(bf16_to_float(q0), bf16_to_float(q1), bf16_to_float(q2), bf16_to_float(q3));
+            }
+            if (out) *reinterpret_cast<float4*>(out + (long long)b * H + col) = t;
         }
     } else {
         for (int col = lane; col < H; col += 64) {
             float acc = b0[col];
-            for (int i = 0; i < cnt; ++i) acc += W0T[(long long)rows[wid][i] * H + col];
-            o[col] = tanhf(acc);
+            for (int i = 0; i < cnt; ++i)
+                acc += BF16 ? bf16_to_float(W0B[(long long)rows[wid][i] * H + col]) : W0T[(long long)rows[wid][i] * H + col];
+            float t = tanhf(acc);
+            if (BF16) { const uint16_t q = bf16_bits(t); out_bf[(long long)b * H + col] = q; t = bf16_to_float(q); }
+            if (out) out[(long long)b * H + col] = t;
         }
     }
 }
@@ -304,6 +340,18 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
     }
 }
 
+// What the generalised TD step (BASELINE configs[4], build-defined) adds to td_delta_kernel; all optional.
+struct TdExtra {
+    const int* partial_idx;        // Double DQN: row index of each column-max partial (first maximum)
+    const float* wout_t; const uint16_t* wout_t_bf; const float* bout_t;   // target net's output layer (fp32 master / bf16 shadow)
+    const float* alast_t; const uint16_t* alast_t_bf;                      // a_last(s') of the target net (fp32 / bf16 bits)
+    const uint16_t* wout_bf;       // bf16 Q-net: shadow of the online output layer for Q(s,a)
+    const float* is_w; const float* is_wmax;     // prioritized replay: raw importance weights [n] and their batch maximum
+    float* prio; unsigned* pmax_live;            // prioritized replay: priority table (by ring slot) and the running maximum (float bits)
+    float per_eps, per_alpha;
+    int double_dqn, nout;
+};
+
 // TD target, output delta and the TOP hidden delta for one sample per wave (chessai.cpp:122-128 +
 // outputLayerDeltaKernel dqn.cu:288-295 + hiddenLayerDeltaKernel dqn.cu:297-308 for the last hidden layer).
 // The output delta of a TD step has ONE non-zero entry per sample (column action.to), so the last hidden layer's delta
@@ -311,6 +359,8 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
 // View[a][i] = view[a*view_ld + i] is the as-written (reference mode: a < view_kmax = width of the last hidden layer,
 // stride = width of the layer below) or the textbook (row a of W_out) operand.  Also emits, per sample, the scalar
 // delta and the action (gathered through `slots`) for the segmented output-layer gradient.
+// Double DQN: the partials carry (max z_online(s'), its row a*); y = r + gamma * tanh(W_out_target[a*] . a_last_target(s') + b).
+// Prioritized replay: delta is scaled by w_b / max w, and (|Q(s,a) - y| + eps)^alpha goes back into the priority table.
 __global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
                                                        const int32_t* __restrict__ action_to, const float* __restrict__ reward,
                                                        const uint8_t* __restrict__ done, const float* __restrict__ a_last, int H,
@@ -318,7 +368,8 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
                                                        const float* __restrict__ partial, int n_partial, float gamma,
                                                        const float* __restrict__ view, long long view_ld, int view_kmax,
                                                        float* __restrict__ dtop, float* __restrict__ dsc, int32_t* __restrict__ act,
-                                                       float* __restrict__ qsa, float* __restrict__ yv, float* __restrict__ lossv) {
+                                                       float* __restrict__ qsa, float* __restrict__ yv, float* __restrict__ lossv,
+                                                       TdExtra X) {
     const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int b = (int)blockIdx.x * 4 + wid;
     if (b >= n) return;
@@ -329,19 +380,45 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
     const float* ar = a_last + (long long)b * H;
     if (live) {
         float z = 0.f;
-        const float* wr = w_out + (long long)a * H;
-        for (int i = lane; i < H; i += 64) z += wr[i] * ar[i];
+        if (X.wout_bf) { const uint16_t* wr = X.wout_bf + (long long)a * H; for (int i = lane; i < H; i += 64) z += bf16_to_float(wr[i]) * ar[i]; }
+        else { const float* wr = w_out + (long long)a * H; for (int i = lane; i < H; i += 64) z += wr[i] * ar[i]; }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
         z += b_out[a];
         float zm = -__builtin_inff();
-        for (int t = lane; t < n_partial; t += 64) zm = fmaxf(zm, partial[(long long)t * n + b]);
+        int zi = 0x7fffffff;
+        for (int t = lane; t < n_partial; t += 64) {
+            const float v = partial[(long long)t * n + b];
+            if (X.double_dqn) {
+                const int vi = X.partial_idx[(long long)t * n + b];
+                if (v > zm || (v == zm && vi < zi)) { zm = v; zi = vi; }
+            } else zm = fmaxf(zm, v);
+        }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) zm = fmaxf(zm, __shfl_xor(zm, off, 64));
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(zm, off, 64);
+            if (X.double_dqn) {
+                const int oi = __shfl_xor(zi, off, 64);
+                if (ov > zm || (ov == zm && oi < zi)) { zm = ov; zi = oi; }
+            } else zm = fmaxf(zm, ov);
+        }
+        if (X.double_dqn) {          // value of the online net's greedy action on the TARGET net
+            const int astar = (zi >= 0 && zi < X.nout) ? zi : 0;
+            float zt = 0.f;
+            for (int i = lane; i < H; i += 64) {
+                const float wv = X.wout_t_bf ? bf16_to_float(X.wout_t_bf[(long long)astar * H + i]) : X.wout_t[(long long)astar * H + i];
+                const float av = X.alast_t_bf ? bf16_to_float(X.alast_t_bf[(long long)b * H + i]) : X.alast_t[(long long)b * H + i];
+                zt += wv * av;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) zt += __shfl_xor(zt, off, 64);
+            zm = zt + X.bout_t[astar];
+        }
         q = tanhf(z);
         const float r = reward[s];
         y = done[s] ? r : r + gamma * tanhf(zm);       // max_k tanh(z_k) = tanh(max_k z_k)
         delta = (q - y) * (1.f - q * q);               // (a - target) * (1 - tanh(z)^2)
+        if (X.is_w) delta *= X.is_w[b] / X.is_wmax[0];
     }
     float* drow = dtop + (long long)b * H;
     if (live && a < view_kmax) {
@@ -358,6 +435,11 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
         act[b] = live ? a : -1;
         qsa[b] = q; yv[b] = y;
         lossv[b] = live ? 0.5f * (q - y) * (q - y) : 0.f;
+        if (X.prio && live) {
+            const float p = powf(fabsf(q - y) + X.per_eps, X.per_alpha);
+            X.prio[s] = p;
+            atomicMax(X.pmax_live, __float_as_uint(p));          // positive floats order like their bit patterns
+        }
     }
 }
 
@@ -536,8 +618,14 @@ struct SegTable {
     long long len[16];
     int nslabs[16];            // > 0: src holds that many partial-sum slabs `stride` apart; they are summed here, in the order
     long long stride[16];      //      of reduce_slabs_kernel (bit-identical to reducing first), instead of by a kernel of their own
+    uint16_t* dst_bf[16];      // bf16 Q-net: shadow of dst, refreshed with the rounded new value (nullptr: none)
     int nseg;
 };
+// bf16 shadow of a weight range (set_params / load_model / set_precision)
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = bf16_bits(src[i]);
+}
 // SGD: dst -= alpha * src per segment (updateWeightsBiasesKernel dqn.cu:310-319, batched form)
 __global__ void sgd_segments_kernel(SegTable t, float alpha) {
     const int sgm = (int)blockIdx.y;
@@ -546,9 +634,13 @@ __global__ void sgd_segments_kernel(SegTable t, float alpha) {
     const float* s = t.src[sgm];
     const int nslabs = t.nslabs[sgm];
     const long long len = t.len[sgm], st = t.stride[sgm];
+    uint16_t* db = t.dst_bf[sgm];
     if (nslabs <= 0) {
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
-            d[i] -= alpha * s[i];
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
+            const float v = d[i] - alpha * s[i];
+            d[i] = v;
+            if (db) db[i] = bf16_bits(v);
+        }
         return;
     }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
@@ -561,7 +653,9 @@ __global__ void sgd_segments_kernel(SegTable t, float alpha) {
             s3 += s[(long long)(z + 3) * st + i];
         }
         for (; z < nslabs; ++z) s0 += s[(long long)z * st + i];
-        d[i] -= alpha * ((s0 + s1) + (s2 + s3));
+        const float v = d[i] - alpha * ((s0 + s1) + (s2 + s3));
+        d[i] = v;
+        if (db) db[i] = bf16_bits(v);
     }
 }
 
@@ -571,7 +665,7 @@ __global__ void sgd_segments_kernel(SegTable t, float alpha) {
 static inline int vec_ok(const void* p, long long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }
 
 // tile choice: 128x128 when that grid already fills the chip twice over, else 64x64 (4x the blocks)
-template <int AL, int BL, int EPI>
+template <int AL, int BL, int EPI, int DT = DT_F32>
 static int launch_gemm(xq_dqn* d, GemmArgs g, int splits, const char* name, int* used_splits = nullptr, bool force_small = false,
                        bool force_big = false) {
     if (used_splits) *used_splits = 0;
@@ -582,22 +676,27 @@ static int launch_gemm(xq_dqn* d, GemmArgs g, int splits, const char* name, int*
     g.k_chunk = round_up((g.K + splits - 1) / splits, GBK);
     splits = (g.K + g.k_chunk - 1) / g.k_chunk;
     if (splits < 1) splits = 1;
-    const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.grouped ? 2 : splits);
+    const int groups = g.grouped > 1 ? g.grouped : 1;
+    const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.grouped ? groups : splits);
     const bool big = force_big || (!force_small && !d->small_tiles && t128 >= 512);
-    ProfScope ps(d, name, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    const double kk = DT == DT_BF16 ? 2.0 * g.K : (double)g.K;       // bf16: K counts pairs
+    ProfScope ps(d, name, 2.0 * g.M * g.N * kk, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
     if (g.grouped) {
         if (splits != 1) return fail(XQ_ERR_INVALID_ARGUMENT, "grouped GEMM cannot be split-K");
-        g.b_vec = g.b_vec && vec_ok(g.B2, g.ldb);
-        g.a_vec = g.a_vec && vec_ok(g.A2, g.lda);
-        ps.flops *= 2; ps.bytes *= 2;
+        if (groups > 3) return fail(XQ_ERR_INVALID_ARGUMENT, "at most 3 grouped products");
+        for (int k = 0; k + 1 < groups; ++k) {
+            g.b_vec = g.b_vec && vec_ok(g.Bx[k], g.ldb);
+            g.a_vec = g.a_vec && vec_ok(g.Ax[k], g.lda);
+        }
+        ps.flops *= groups; ps.bytes *= groups;
     }
-    const int gz = g.grouped ? 2 : splits;
+    const int gz = g.grouped ? groups : splits;
     if (big) {
         dim3 grid((g.M + 127) / 128, (g.N + 127) / 128, gz);
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI, 2, 2>), grid, dim3(256), 0, d->cur, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI, 2, 2, DT>), grid, dim3(256), 0, d->cur, g);
     } else {
         dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, gz);
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI, 1, 1>), grid, dim3(256), 0, d->cur, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, EPI, 1, 1, DT>), grid, dim3(256), 0, d->cur, g);
     }
     XQ_HIP(hipGetLastError());
     if (used_splits) *used_splits = splits;
@@ -652,46 +751,121 @@ static int ensure_capacity(xq_dqn* d, int n) {
     return XQ_OK;
 }
 
-static SlotSrc explicit_slots(const int32_t* slots) {
-    SlotSrc s; memset(&s, 0, sizeof s); s.slots = slots; return s;
-}
-
-// a_1 .. a_{nl-1} for n packed boards; outs[l] receives a_{l+1}.  With a second job (boards2/net2/outs2) both chains run
-// in the same launches: one gather grid with blockIdx.y = job, grouped GEMMs with blockIdx.z = job.
-static int chain_boards(xq_dqn* d, int net, const uint32_t* boards, SlotSrc src, int n, float* const* outs,
-                        uint32_t* gathered = nullptr, int net2 = -1, const uint32_t* boards2 = nullptr,
-                        float* const* outs2 = nullptr) {
-    if (d->L[0] != kStateSize) return fail(XQ_ERR_INVALID_ARGUMENT, "board input needs layer_sizes[0] == 1260 (got %d)", d->L[0]);
-    const int jobs = net2 >= 0 ? 2 : 1;
-    {
-        const int H = d->L[1];
-        L0Jobs J; memset(&J, 0, sizeof J);
-        J.njobs = jobs;
-        J.boards[0] = boards; J.W0T[0] = d->w0t(net); J.b0[0] = d->bl(net, 0); J.out[0] = outs[0]; J.gathered[0] = gathered;
-        if (jobs == 2) { J.boards[1] = boards2; J.W0T[1] = d->w0t(net2); J.b0[1] = d->bl(net2, 0); J.out[1] = outs2[0]; J.gathered[1] = nullptr; }
-        ProfScope ps(d, "l0_forward_gather", 2.0 * jobs * n * 32 * H, (double)jobs * n * (48 + 32.0 * H * 4 + H * 4));
-        hipLaunchKernelGGL(l0_forward_kernel, dim3((n + 3) / 4, jobs), dim3(256), 0, d->cur, J, src, n, H);
-        XQ_HIP(hipGetLastError());
-    }
-    for (int l = 1; l + 1 < d->nl; ++l) {
-        GemmArgs g; memset(&g, 0, sizeof g);
-        g.M = n; g.N = d->L[l + 1]; g.K = d->L[l];
-        g.A = outs[l - 1]; g.lda = d->L[l];
-        g.B = d->wl(net, l); g.ldb = d->L[l];
-        g.C = outs[l]; g.ldc = d->L[l + 1];
-        g.bias = d->bl(net, l);
-        if (jobs == 2) {
-            g.grouped = 1;
-            g.A2 = outs2[l - 1]; g.B2 = d->wl(net2, l); g.C2 = outs2[l]; g.bias2 = d->bl(net2, l);
+// the extra buffers of the build-defined modes, allocated on first use: bf16 bits of every activation buffer (bf16 Q-net), the
+// third forward chain and the arg-max partials (Double DQN)
+static int ensure_ext_capacity(xq_dqn* d, int n, bool want_double) {
+    int maxh = 0;
+    for (int l = 0; l + 1 < d->nl; ++l) maxh = std::max(maxh, d->L[l + 1]);
+    const size_t rows = (size_t)round_up(n, 128);
+    if (d->bf16() && n > d->cap_bf) {
+        XQ_HIP(hipDeviceSynchronize());
+        for (int l = 0; l + 1 < d->nl; ++l) {
+            if (d->acts_bf[l]) XQ_HIP(hipFree(d->acts_bf[l]));
+            XQ_HIP(hipMalloc(&d->acts_bf[l], rows * d->L[l + 1] * sizeof(uint16_t)));
         }
-        XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH>(d, g, 1, "gemm_hidden_fwd")));
+        for (int i = 0; i < 2; ++i) {
+            if (d->tacts_bf[i]) XQ_HIP(hipFree(d->tacts_bf[i]));
+            if (d->t2acts_bf[i]) XQ_HIP(hipFree(d->t2acts_bf[i]));
+            XQ_HIP(hipMalloc(&d->tacts_bf[i], rows * (size_t)maxh * sizeof(uint16_t)));
+            XQ_HIP(hipMalloc(&d->t2acts_bf[i], rows * (size_t)maxh * sizeof(uint16_t)));
+            XQ_HIP(hipMemsetAsync(d->tacts_bf[i], 0, rows * (size_t)maxh * sizeof(uint16_t), d->stream));
+            XQ_HIP(hipMemsetAsync(d->t2acts_bf[i], 0, rows * (size_t)maxh * sizeof(uint16_t), d->stream));
+        }
+        d->cap_bf = n;
+    }
+    if (want_double && n > d->cap_t2) {
+        XQ_HIP(hipDeviceSynchronize());
+        for (int i = 0; i < 2; ++i) {
+            if (d->t2acts[i]) XQ_HIP(hipFree(d->t2acts[i]));
+            XQ_HIP(hipMalloc(&d->t2acts[i], rows * (size_t)maxh * sizeof(float)));
+            XQ_HIP(hipMemsetAsync(d->t2acts[i], 0, rows * (size_t)maxh * sizeof(float), d->stream));
+        }
+        d->cap_t2 = n;
+    }
+    if (want_double && n > d->cap_idx) {
+        XQ_HIP(hipDeviceSynchronize());
+        if (d->partial_idx) XQ_HIP(hipFree(d->partial_idx));
+        const int ntn = (d->nout() + 63) / 64;
+        XQ_HIP(hipMalloc(&d->partial_idx, (size_t)n * (size_t)ntn * 2 * sizeof(int)));
+        d->cap_idx = n;
     }
     return XQ_OK;
 }
 
-// Q head on the first n_out outputs: q[m][0..n_out) = tanh(W_out[0:n_out] a_last + b_out)
-static int q_head(xq_dqn* d, int net, const float* a_last, int n, int n_out, float* q, int ldq, const char* name) {
+static SlotSrc explicit_slots(const int32_t* slots) {
+    SlotSrc s; memset(&s, 0, sizeof s); s.slots = slots; return s;
+}
+
+// One forward chain of a launch group: a_1 .. a_{nl-1} of `net` for n packed boards; outs[l] receives a_{l+1} in fp32 (may be
+// nullptr per chain in bf16 mode when only the next layer reads it), outs_bf[l] its bf16 bits (bf16 Q-net only).
+struct ChainJob {
+    int net;
+    const uint32_t* boards;
+    float* const* outs;
+    uint16_t* const* outs_bf;
+    uint32_t* gathered;
+};
+// Up to three chains run in the same launches: one gather grid with blockIdx.y = chain, grouped GEMMs with blockIdx.z = chain.
+static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src, int n) {
+    if (d->L[0] != kStateSize) return fail(XQ_ERR_INVALID_ARGUMENT, "board input needs layer_sizes[0] == 1260 (got %d)", d->L[0]);
+    if (njobs < 1 || njobs > kMaxChains) return fail(XQ_ERR_INVALID_ARGUMENT, "1..3 forward chains per launch group");
+    const bool bf = d->bf16();
+    {
+        const int H = d->L[1];
+        L0Jobs J; memset(&J, 0, sizeof J);
+        J.njobs = njobs;
+        for (int k = 0; k < njobs; ++k) {
+            J.boards[k] = jobs[k].boards; J.W0T[k] = d->w0t(jobs[k].net); J.b0[k] = d->bl(jobs[k].net, 0);
+            J.out[k] = jobs[k].outs ? jobs[k].outs[0] : nullptr; J.gathered[k] = jobs[k].gathered;
+            if (bf) { J.W0T_bf[k] = d->wl_bf(jobs[k].net, 0); J.out_bf[k] = jobs[k].outs_bf[0]; }
+        }
+        ProfScope ps(d, "l0_forward_gather", 2.0 * njobs * n * 32 * H, (double)njobs * n * (48 + 32.0 * H * (bf ? 2 : 4) + H * 4));
+        if (bf) hipLaunchKernelGGL(l0_forward_kernel<true>, dim3((n + 3) / 4, njobs), dim3(256), 0, d->cur, J, src, n, H);
+        else hipLaunchKernelGGL(l0_forward_kernel<false>, dim3((n + 3) / 4, njobs), dim3(256), 0, d->cur, J, src, n, H);
+        XQ_HIP(hipGetLastError());
+    }
+    for (int l = 1; l + 1 < d->nl; ++l) {
+        GemmArgs g; memset(&g, 0, sizeof g);
+        g.M = n; g.N = d->L[l + 1];
+        g.grouped = njobs > 1 ? njobs : 0;
+        if (bf) {
+            if (d->L[l] & 1) return fail(XQ_ERR_INVALID_ARGUMENT, "bf16 Q-net needs even layer widths (layer %d has %d)", l, d->L[l]);
+            g.K = d->L[l] / 2; g.lda = g.ldb = d->L[l] / 2;
+            g.ldc = d->L[l + 1]; g.ldcb = d->L[l + 1];
+            for (int k = 0; k < njobs; ++k) {
+                const float* A = reinterpret_cast<const float*>(jobs[k].outs_bf[l - 1]);
+                const float* B = reinterpret_cast<const float*>(d->wl_bf(jobs[k].net, l));
+                float* C = jobs[k].outs ? jobs[k].outs[l] : nullptr;
+                if (k == 0) { g.A = A; g.B = B; g.C = C; g.bias = d->bl(jobs[k].net, l); g.Cb = jobs[k].outs_bf[l]; }
+                else { g.Ax[k - 1] = A; g.Bx[k - 1] = B; g.Cx[k - 1] = C; g.biasx[k - 1] = d->bl(jobs[k].net, l); g.Cbx[k - 1] = jobs[k].outs_bf[l]; }
+            }
+            XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH, DT_BF16>(d, g, 1, "gemm_hidden_fwd")));
+        } else {
+            g.K = d->L[l]; g.lda = g.ldb = d->L[l]; g.ldc = d->L[l + 1];
+            for (int k = 0; k < njobs; ++k) {
+                if (k == 0) { g.A = jobs[k].outs[l - 1]; g.B = d->wl(jobs[k].net, l); g.C = jobs[k].outs[l]; g.bias = d->bl(jobs[k].net, l); }
+                else { g.Ax[k - 1] = jobs[k].outs[l - 1]; g.Bx[k - 1] = d->wl(jobs[k].net, l); g.Cx[k - 1] = jobs[k].outs[l]; g.biasx[k - 1] = d->bl(jobs[k].net, l); }
+            }
+            XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH>(d, g, 1, "gemm_hidden_fwd")));
+        }
+    }
+    return XQ_OK;
+}
+
+// Q head on the first n_out outputs: q[m][0..n_out) = tanh(W_out[0:n_out] a_last + b_out); a_last_bf != nullptr: bf16 operands
+// (weights from the shadow), fp32 result (the output layer is never rounded)
+static int q_head(xq_dqn* d, int net, const float* a_last, int n, int n_out, float* q, int ldq, const char* name,
+                  const uint16_t* a_last_bf = nullptr) {
     GemmArgs g; memset(&g, 0, sizeof g);
+    if (a_last_bf) {
+        g.M = n; g.N = n_out; g.K = d->hlast() / 2;
+        g.A = reinterpret_cast<const float*>(a_last_bf); g.lda = d->hlast() / 2;
+        g.B = reinterpret_cast<const float*>(d->wl_bf(net, d->nl - 1)); g.ldb = d->hlast() / 2;
+        g.C = q; g.ldc = ldq;
+        g.bias = d->bl(net, d->nl - 1);
+        XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH, DT_BF16>(d, g, 1, name)));
+        return XQ_OK;
+    }
     g.M = n; g.N = n_out; g.K = d->hlast();
     g.A = a_last; g.lda = d->hlast();
     g.B = d->wl(net, d->nl - 1); g.ldb = d->hlast();
@@ -713,26 +887,41 @@ static int ensure_select_capacity(xq_dqn* d, int n) {
     d->sel_cap = n;
     return XQ_OK;
 }
+static int ensure_select_capacity_bf(xq_dqn* d, int n) {
+    if (!d->bf16() || n <= d->sel_cap_bf) return XQ_OK;
+    XQ_HIP(hipDeviceSynchronize());
+    for (int l = 0; l + 1 < d->nl; ++l) {
+        if (d->sel_acts_bf[l]) XQ_HIP(hipFree(d->sel_acts_bf[l]));
+        XQ_HIP(hipMalloc(&d->sel_acts_bf[l], (size_t)round_up(n, 128) * d->L[l + 1] * sizeof(uint16_t)));
+    }
+    d->sel_cap_bf = n;
+    return XQ_OK;
+}
 
 // Q(s)[0..95] of n packed boards on the online net.  `on` != nullptr queues the chain on that stream with its own
 // workspace and 64x64 tiles, so it can run concurrently with a TD step queued on the handle's stream.
 int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride, hipStream_t on) {
     if (d->nout() < 96) return fail(XQ_ERR_INVALID_ARGUMENT, "self-play select needs >= 96 outputs");
     float* outs[XQ_MAX_LAYERS];
+    uint16_t* outs_bf[XQ_MAX_LAYERS] = {nullptr};
     float* q = nullptr;
+    const bool bf = d->bf16();
     if (on) {
         XQ_TRY(ensure_select_capacity(d, n));
-        for (int l = 0; l + 1 < d->nl; ++l) outs[l] = d->sel_acts[l];
+        XQ_TRY(ensure_select_capacity_bf(d, n));
+        for (int l = 0; l + 1 < d->nl; ++l) { outs[l] = bf ? nullptr : d->sel_acts[l]; outs_bf[l] = d->sel_acts_bf[l]; }
         q = d->sel_q90;
         d->cur = on;
         d->small_tiles = true;
     } else {
         XQ_TRY(ensure_capacity(d, n));
-        for (int l = 0; l + 1 < d->nl; ++l) outs[l] = d->acts[l];
+        XQ_TRY(ensure_ext_capacity(d, n, false));
+        for (int l = 0; l + 1 < d->nl; ++l) { outs[l] = bf ? nullptr : d->acts[l]; outs_bf[l] = d->acts_bf[l]; }
         q = d->q90;
     }
-    int rc = chain_boards(d, XQ_NET_ONLINE, boards_dev, explicit_slots(nullptr), n, outs);
-    if (rc == XQ_OK) rc = q_head(d, XQ_NET_ONLINE, outs[d->nl - 2], n, 96, q, 96, "gemm_q90_select");
+    ChainJob job{XQ_NET_ONLINE, boards_dev, outs, outs_bf, nullptr};
+    int rc = chain_boards(d, &job, 1, explicit_slots(nullptr), n);
+    if (rc == XQ_OK) rc = q_head(d, XQ_NET_ONLINE, outs[d->nl - 2], n, 96, q, 96, "gemm_q90_select", bf ? outs_bf[d->nl - 2] : nullptr);
     d->cur = d->stream;
     d->small_tiles = false;
     XQ_TRY(rc);
@@ -915,6 +1104,7 @@ extern "C" {
 
 static int dqn_init(xq_dqn* d, const int* layer_sizes, int n_sizes, double learning_rate, double gamma, uint64_t seed,
                     void* hip_stream);
+static int refresh_shadow(xq_dqn* d, int net);
 
 int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, double gamma, uint64_t seed, void* hip_stream,
                   xq_dqn** out) {
@@ -989,6 +1179,9 @@ int xq_dqn_destroy(xq_dqn* d) {
     hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
     d->prof.collect();
     hipFree(d->slabs_l0);
+    for (int i = 0; i < 2; ++i) { hipFree(d->params_bf[i]); hipFree(d->tacts_bf[i]); hipFree(d->t2acts_bf[i]); hipFree(d->t2acts[i]); }
+    for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts_bf[l]); hipFree(d->sel_acts_bf[l]); }
+    hipFree(d->partial_idx);
     if (d->side) { hipStreamSynchronize(d->side); hipStreamDestroy(d->side); }
     if (d->ev_fork) hipEventDestroy(d->ev_fork);
     if (d->ev_join) hipEventDestroy(d->ev_join);
@@ -1017,7 +1210,7 @@ int xq_dqn_set_params(xq_dqn* d, int net, const double* w, const double* b) {
     for (size_t i = 0; i < d->nb; ++i) p[d->nw + i] = (float)b[i];
     XQ_HIP(hipStreamSynchronize(d->stream));
     XQ_HIP(hipMemcpy(d->params[net], p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
-    return XQ_OK;
+    return refresh_shadow(d, net);
 }
 
 int xq_dqn_get_params(xq_dqn* d, int net, double* w, double* b) {
@@ -1039,7 +1232,38 @@ int xq_dqn_update_target(xq_dqn* d) {
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
     ProfScope ps(d, "target_sync_copy", 0, 8.0 * (d->nw + d->nb));
     XQ_HIP(hipMemcpyAsync(d->params[1], d->params[0], (d->nw + d->nb) * sizeof(float), hipMemcpyDeviceToDevice, d->stream));
+    if (d->bf16())
+        XQ_HIP(hipMemcpyAsync(d->params_bf[1], d->params_bf[0], d->nw * sizeof(uint16_t), hipMemcpyDeviceToDevice, d->stream));
     return XQ_OK;
+}
+
+static int refresh_shadow(xq_dqn* d, int net) {
+    if (!d->bf16()) return XQ_OK;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(1024), dim3(256), 0, d->stream, d->params[net], d->params_bf[net], (long long)d->nw);
+    XQ_HIP(hipGetLastError());
+    return XQ_OK;
+}
+
+int xq_dqn_set_precision(xq_dqn* d, int precision) {
+    if (!d || (precision != XQ_PRECISION_F32 && precision != XQ_PRECISION_BF16)) return fail(XQ_ERR_INVALID_ARGUMENT, "bad precision");
+    if (d->l0_pending > 0 || d->pend_wout.nslabs > 0)
+        return fail(XQ_ERR_RUNTIME, "xq_dqn_set_precision: a TD step is waiting for its apply_grads");
+    if (precision == XQ_PRECISION_BF16) {
+        for (int l = 1; l <= d->nl - 1; ++l)
+            if (d->L[l] & 1) return fail(XQ_ERR_INVALID_ARGUMENT, "bf16 Q-net needs even hidden widths (layer %d has %d)", l, d->L[l]);
+        if (!d->params_bf[0]) {
+            int widest = 0;
+            for (int i = 0; i < d->ns; ++i) widest = std::max(widest, d->L[i]);
+            const size_t pad = (size_t)128 * widest;         // whole-tile reads of the persistent GEMM, like params[]
+            for (int i = 0; i < 2; ++i) {
+                XQ_HIP(hipMalloc(&d->params_bf[i], (d->nw + pad) * sizeof(uint16_t)));
+                XQ_HIP(hipMemsetAsync(d->params_bf[i], 0, (d->nw + pad) * sizeof(uint16_t), d->stream));
+            }
+        }
+    }
+    d->precision = precision;
+    XQ_TRY(refresh_shadow(d, 0));
+    return refresh_shadow(d, 1);
 }
 
 // dense-state chain: a_1 via GEMM against W0^T; outs as in chain_boards
@@ -1093,10 +1317,14 @@ int xq_dqn_forward_boards_dev(xq_dqn* d, int net, const uint32_t* boards_dev, in
     if (!d || !boards_dev || !q_dev || n <= 0 || net < 0 || net > 1 || n_out <= 0 || n_out > d->nout() || ldq < n_out)
         return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_forward_boards_dev: bad argument");
     XQ_TRY(ensure_capacity(d, n));
+    XQ_TRY(ensure_ext_capacity(d, n, false));
     float* outs[XQ_MAX_LAYERS];
-    for (int l = 0; l + 1 < d->nl; ++l) outs[l] = d->acts[l];
-    XQ_TRY(chain_boards(d, net, boards_dev, explicit_slots(nullptr), n, outs));
-    return q_head(d, net, outs[d->nl - 2], n, n_out, q_dev, ldq, n_out <= 96 ? "gemm_q90_select" : "gemm_q_full");
+    uint16_t* outs_bf[XQ_MAX_LAYERS] = {nullptr};
+    for (int l = 0; l + 1 < d->nl; ++l) { outs[l] = d->acts[l]; outs_bf[l] = d->acts_bf[l]; }
+    ChainJob job{net, boards_dev, outs, outs_bf, nullptr};
+    XQ_TRY(chain_boards(d, &job, 1, explicit_slots(nullptr), n));
+    return q_head(d, net, outs[d->nl - 2], n, n_out, q_dev, ldq, n_out <= 96 ? "gemm_q90_select" : "gemm_q_full",
+                  d->bf16() ? outs_bf[d->nl - 2] : nullptr);
 }
 
 int xq_dqn_backpropagate(xq_dqn* d, const double* states, const double* targets, int n, double lr, double grad_scale, int mode) {
@@ -1149,12 +1377,18 @@ int xq_dqn_backpropagate(xq_dqn* d, const double* states, const double* targets,
     return XQ_OK;
 }
 
+// prioritized replay hooks of one TD step (device pointers owned by the replay ring; nullptr = uniform replay)
+struct PerOpts {
+    const float* is_w; const float* is_wmax;
+    float* prio; unsigned* pmax_live;
+    float eps, alpha;
+};
 static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boards, const int32_t* action_to,
-                         const float* reward, const uint8_t* done, SlotSrc slots, int n, int td_net, int mode);
+                         const float* reward, const uint8_t* done, SlotSrc slots, int n, int td_net, int mode, const PerOpts* per);
 
 int xq_dqn_td_grads(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boards, const int32_t* action_to,
                     const float* reward, const uint8_t* done, const int32_t* slots, int n, int td_net, int mode) {
-    return td_grads_impl(d, boards, next_boards, action_to, reward, done, explicit_slots(slots), n, td_net, mode);
+    return td_grads_impl(d, boards, next_boards, action_to, reward, done, explicit_slots(slots), n, td_net, mode, nullptr);
 }
 
 // gradients that run on the side stream (d->cur == d->side), see td_grads_impl
@@ -1220,39 +1454,59 @@ static int side_gradients(xq_dqn* d, int n, float* const* outs, float* G) {
 }
 
 static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boards, const int32_t* action_to,
-                         const float* reward, const uint8_t* done, SlotSrc slots, int n, int td_net, int mode) {
+                         const float* reward, const uint8_t* done, SlotSrc slots, int n, int td_net, int mode, const PerOpts* per) {
     if (!d || !boards || !next_boards || !action_to || !reward || !done || n <= 0)
         return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_td_grads: bad argument");
-    if (td_net != XQ_TD_ONLINE_NET && td_net != XQ_TD_TARGET_NET) return fail(XQ_ERR_INVALID_ARGUMENT, "bad td_net");
+    if (td_net != XQ_TD_ONLINE_NET && td_net != XQ_TD_TARGET_NET && td_net != XQ_TD_DOUBLE) return fail(XQ_ERR_INVALID_ARGUMENT, "bad td_net");
     if (mode != XQ_BACKPROP_REFERENCE && mode != XQ_BACKPROP_TEXTBOOK) return fail(XQ_ERR_INVALID_ARGUMENT, "bad backprop mode");
     if (d->nout() < 96) return fail(XQ_ERR_INVALID_ARGUMENT, "TD path needs >= 96 outputs (action.to indexes outputs 0..89)");
     if (mode == XQ_BACKPROP_REFERENCE) XQ_TRY(check_reference_topology(d));
+    const bool dbl = td_net == XQ_TD_DOUBLE, bf = d->bf16();
     XQ_TRY(ensure_capacity(d, n));
+    XQ_TRY(ensure_ext_capacity(d, n, dbl));
     const int nl = d->nl, Hl = d->hlast(), NO = d->nout();
-    // 1. both forward chains in the same launches (one gather grid, grouped hidden GEMMs): s on the online net with the
-    //    activations kept for the backward pass, s' on the TD net
-    float* outs[XQ_MAX_LAYERS];
-    float* touts[XQ_MAX_LAYERS];
-    for (int l = 0; l + 1 < nl; ++l) { outs[l] = d->acts[l]; touts[l] = d->tacts[l & 1]; }
-    XQ_TRY(chain_boards(d, XQ_NET_ONLINE, boards, slots, n, outs, d->gboards, td_net, next_boards, touts));
+    if (bf && (Hl & 1)) return fail(XQ_ERR_INVALID_ARGUMENT, "bf16 Q-net needs even layer widths");
+    // 1. the forward chains in the same launches (one gather grid, grouped hidden GEMMs): s on the online net with the
+    //    activations kept for the backward pass, s' on the net that selects (online, or target for XQ_TD_TARGET_NET) and,
+    //    for Double DQN, s' on the target net that evaluates
+    const int sel_net = td_net == XQ_TD_TARGET_NET ? XQ_NET_TARGET : XQ_NET_ONLINE;
+    float* outs[XQ_MAX_LAYERS]; uint16_t* outs_bf[XQ_MAX_LAYERS];
+    float* touts[XQ_MAX_LAYERS]; uint16_t* touts_bf[XQ_MAX_LAYERS];
+    float* t2outs[XQ_MAX_LAYERS]; uint16_t* t2outs_bf[XQ_MAX_LAYERS];
+    for (int l = 0; l + 1 < nl; ++l) {
+        outs[l] = d->acts[l]; outs_bf[l] = d->acts_bf[l];
+        touts[l] = bf ? nullptr : d->tacts[l & 1]; touts_bf[l] = d->tacts_bf[l & 1];
+        t2outs[l] = bf ? nullptr : d->t2acts[l & 1]; t2outs_bf[l] = d->t2acts_bf[l & 1];
+    }
+    ChainJob jobs[3] = {{XQ_NET_ONLINE, boards, outs, outs_bf, d->gboards}, {sel_net, next_boards, touts, touts_bf, nullptr},
+                        {XQ_NET_TARGET, next_boards, t2outs, t2outs_bf, nullptr}};
+    XQ_TRY(chain_boards(d, jobs, dbl ? 3 : 2, slots, n));
     // launched transposed (rows = output neurons, columns = samples): the max over the 8100 outputs then runs over
     // accumulator registers inside one lane instead of across the 32 lanes of a row
     const bool big_tiles = (long long)((NO + 127) / 128) * ((n + 127) / 128) >= 512;
     const int n_partial = 2 * (big_tiles ? (NO + 127) / 128 : (NO + 63) / 64);
     {
         GemmArgs g; memset(&g, 0, sizeof g);
-        g.M = NO; g.N = n; g.K = Hl;
-        g.A = d->wl(td_net, nl - 1); g.lda = Hl;
-        g.B = touts[nl - 2]; g.ldb = Hl;
-        g.bias = d->bl(td_net, nl - 1);
+        g.M = NO; g.N = n;
+        if (bf) {
+            g.K = Hl / 2; g.lda = g.ldb = Hl / 2;
+            g.A = reinterpret_cast<const float*>(d->wl_bf(sel_net, nl - 1));
+            g.B = reinterpret_cast<const float*>(touts_bf[nl - 2]);
+        } else {
+            g.K = Hl; g.lda = g.ldb = Hl;
+            g.A = d->wl(sel_net, nl - 1);
+            g.B = touts[nl - 2];
+        }
+        g.bias = d->bl(sel_net, nl - 1);
         g.partial = d->partial;
+        g.partial_idx = dbl ? d->partial_idx : nullptr;
         // the persistent kernel keeps the whole bias vector in LDS beside its operand tiles (2 blocks per CU must fit)
         const size_t bias_lds = (size_t)((NO + 127) / 128) * 128 * sizeof(float);
-        if (big_tiles && (Hl % GBK) == 0 && vec_ok(g.A, g.lda) && vec_ok(g.B, g.ldb) && bias_lds <= 40 * 1024) {
+        if (big_tiles && (g.K % GBK) == 0 && vec_ok(g.A, g.lda) && vec_ok(g.B, g.ldb) && bias_lds <= 40 * 1024) {
             // persistent form: 2 blocks per CU walk the tile list with the prefetch running across tile boundaries
             const int tiles_m = (NO + 127) / 128, total = tiles_m * ((n + 127) / 128);
             const int ncu = d->ncu;
-            g.a_vec = g.b_vec = 1; g.k_chunk = Hl;
+            g.a_vec = g.b_vec = 1; g.k_chunk = g.K;
             g.bias_padded = ((((uintptr_t)g.bias) % 16 == 0) && (NO % 4) == 0) ? 1 : 0;     // wide bias preload
             const int grid = std::min(total, 2 * ncu);
             // static priority for the second half of the grid (see the kernel): each half walks its own half of the tiles
@@ -1262,10 +1516,14 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
                 g.prio_tiles = (total / 2) / tiles_m * tiles_m;
                 if (g.prio_tiles <= 0 || g.prio_tiles >= total) { g.prio_split = 0; g.prio_tiles = 0; }
             }
-            ProfScope ps(d, "gemm_qmax_rowmax", 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + 2.0 * tiles_m * g.N));
-            hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2>), dim3(grid), dim3(256), bias_lds, d->cur, g,
-                               tiles_m, total);
+            ProfScope ps(d, "gemm_qmax_rowmax", 2.0 * g.M * g.N * Hl, (bf ? 2.0 : 4.0) * ((double)g.M * Hl + (double)g.N * Hl) + 8.0 * tiles_m * g.N);
+            if (bf && dbl) hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_BF16, true>), dim3(grid), dim3(256), bias_lds, d->cur, g, tiles_m, total);
+            else if (bf) hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_BF16, false>), dim3(grid), dim3(256), bias_lds, d->cur, g, tiles_m, total);
+            else if (dbl) hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_F32, true>), dim3(grid), dim3(256), bias_lds, d->cur, g, tiles_m, total);
+            else hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_F32, false>), dim3(grid), dim3(256), bias_lds, d->cur, g, tiles_m, total);
             XQ_HIP(hipGetLastError());
+        } else if (bf) {
+            XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_COLMAX, DT_BF16>(d, g, 1, "gemm_qmax_rowmax")));
         } else {
             XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_COLMAX>(d, g, 1, "gemm_qmax_rowmax")));
         }
@@ -1278,9 +1536,22 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         const long long view_ld = (mode == XQ_BACKPROP_REFERENCE) ? d->L[lt] : d->L[lt + 1];
         const int view_kmax = (mode == XQ_BACKPROP_REFERENCE) ? d->L[lt + 1] : NO;
         ProfScope ps(d, "td_target_delta", 4.0 * n * Hl, (double)n * (Hl * 16 + n_partial * 4));
+        TdExtra X; memset(&X, 0, sizeof X);
+        X.nout = NO;
+        if (dbl) {
+            X.double_dqn = 1; X.partial_idx = d->partial_idx;
+            X.bout_t = d->bl(XQ_NET_TARGET, nl - 1);
+            if (bf) { X.wout_t_bf = d->wl_bf(XQ_NET_TARGET, nl - 1); X.alast_t_bf = t2outs_bf[nl - 2]; }
+            else { X.wout_t = d->wl(XQ_NET_TARGET, nl - 1); X.alast_t = t2outs[nl - 2]; }
+        }
+        if (bf) X.wout_bf = d->wl_bf(XQ_NET_ONLINE, nl - 1);
+        if (per) {
+            X.is_w = per->is_w; X.is_wmax = per->is_wmax; X.prio = per->prio; X.pmax_live = per->pmax_live;
+            X.per_eps = per->eps; X.per_alpha = per->alpha;
+        }
         hipLaunchKernelGGL(td_delta_kernel, dim3((n + 3) / 4), dim3(256), 0, d->cur, n, slots, action_to, reward, done,
                            outs[nl - 2], Hl, d->wl(XQ_NET_ONLINE, nl - 1), d->bl(XQ_NET_ONLINE, nl - 1), d->partial, n_partial,
-                           (float)d->gamma, view, view_ld, view_kmax, d->deltas[lt], d->dsc, d->act_mb, d->qsa, d->yv, d->lossv);
+                           (float)d->gamma, view, view_ld, view_kmax, d->deltas[lt], d->dsc, d->act_mb, d->qsa, d->yv, d->lossv, X);
         XQ_HIP(hipGetLastError());
     }
     d->last_n = n;
@@ -1340,15 +1611,20 @@ int xq_dqn_apply_grads(xq_dqn* d, double lr, double grad_scale) {
         if (p.nslabs > 0) { t.src[k] = p.src; t.nslabs[k] = p.nslabs; t.stride[k] = p.stride; }
         p = xq_dqn::PendingSlab();
     };
+    const bool bf = d->bf16();
     t.dst[k] = d->w0t(0); t.src[k] = G + d->g_w0; t.len[k] = (long long)d->L[0] * d->L[1];
+    if (bf) t.dst_bf[k] = d->wl_bf(0, 0);
     if (d->l0_pending > 0) { t.src[k] = d->slabs_l0; t.nslabs[k] = d->l0_pending; t.stride[k] = t.len[k]; d->l0_pending = 0; }
     ++k;
     for (int l = 1; l + 1 < d->nl; ++l) {
         t.dst[k] = d->wl(0, l); t.src[k] = G + d->g_wh[l]; t.len[k] = (long long)d->L[l] * d->L[l + 1];
+        if (bf) t.dst_bf[k] = d->wl_bf(0, l);
         take(d->pend_hidden[l]);
         ++k;
     }
-    t.dst[k] = d->wl(0, d->nl - 1); t.src[k] = G + d->g_wout; t.len[k] = 96LL * d->hlast(); take(d->pend_wout); ++k;
+    t.dst[k] = d->wl(0, d->nl - 1); t.src[k] = G + d->g_wout; t.len[k] = 96LL * d->hlast();
+    if (bf) t.dst_bf[k] = d->wl_bf(0, d->nl - 1);
+    take(d->pend_wout); ++k;
     // hidden biases are contiguous in both layouts
     t.dst[k] = d->bl(0, 0); t.src[k] = G + d->g_bh[0]; t.len[k] = (long long)(d->bo[d->nl - 1]); ++k;
     t.dst[k] = d->bl(0, d->nl - 1); t.src[k] = G + d->g_bout; t.len[k] = 96; take(d->pend_bout); ++k;
@@ -1388,8 +1664,15 @@ int xq_dqn_td_grads_replay(xq_dqn* d, xq_replay* r, int batch, int td_net, int m
         batch = r->size;       // identity over the filled part of the ring (on-policy use)
     }
     if (batch <= 0) return fail(XQ_ERR_RUNTIME, "replay is empty");
+    PerOpts per; memset(&per, 0, sizeof per);
+    const bool prioritized = r->per.enabled && r->per.last_prioritized && !r->implicit && src.slots != nullptr;
+    if (prioritized) {        // importance weights in, TD-error priorities out (xq_replay_sample_prioritized drew the slots)
+        per.is_w = r->per.is_w; per.is_wmax = reinterpret_cast<const float*>(r->per.scalars + 2);
+        per.prio = r->dev.prio; per.pmax_live = r->per.scalars + 0;
+        per.eps = r->per.eps; per.alpha = r->per.alpha;
+    }
     return td_grads_impl(d, r->dev.boards, r->dev.next_boards, r->dev.action_to, r->dev.reward, r->dev.done, src, batch, td_net,
-                         mode);
+                         mode, prioritized ? &per : nullptr);
 }
 
 int xq_dqn_td_update_host(xq_dqn* d, int n, const uint8_t* boards90, const uint8_t* next_boards90, const int32_t* action_to,

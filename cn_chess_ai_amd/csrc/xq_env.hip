@@ -194,6 +194,8 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
             P.rp.action_to[slot] = have_action ? to : -1;
             P.rp.reward[slot] = (float)reward;
             P.rp.done[slot] = done ? 1 : 0;
+            // prioritized replay: a new transition enters with the largest priority assigned so far (an empty one never gets sampled)
+            if (P.rp.prio != nullptr) P.rp.prio[slot] = have_action ? __uint_as_float(*P.rp.pmax_snap) : 0.f;
         }
     }
 

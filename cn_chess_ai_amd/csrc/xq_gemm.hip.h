@@ -1,4 +1,7 @@
-// xq_gemm.hip.h — fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled for gfx950.
+// xq_gemm.hip.h — GEMM on the CDNA4 matrix cores, LDS-tiled for gfx950: fp32 (v_mfma_f32_32x32x2_f32, exact fp32) and,
+// for the bf16 Q-net of BASELINE configs[4], bf16 with fp32 accumulation (v_mfma_f32_32x32x16_bf16) through the SAME
+// staging code: a k-contiguous bf16 operand [rows][K] is addressed as a float matrix [rows][K/2], so one staged 32-float
+// k-tile carries 64 bf16 of K and one 16-byte fragment read is exactly the 8 bf16 (k = 8h..8h+7) one lane feeds the MFMA.
 //
 // One template serves every dense contraction of the Q-network (reference dqn.cu kernels forwardKernel :184/:275,
 // hiddenLayerDeltaKernel :297, updateWeightsBiasesKernel :310 — there one thread per output neuron with a serial
@@ -24,6 +27,13 @@
 namespace xq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { DT_F32 = 0, DT_BF16 = 1 };     // operand element type (accumulation is fp32 either way)
+__device__ __forceinline__ float bf16_round(float v) { return (float)(__bf16)v; }                       // RNE, v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+__device__ __forceinline__ float bf16_to_float(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 
 enum { L_KCONTIG = 0, L_MCONTIG = 1 };
 // EPI_COLMAX: per column n, max over the rows m of (acc + bias[m]) — the GEMM is launched "transposed" (rows = output
@@ -46,9 +56,13 @@ struct GemmArgs {
     int k_chunk;                  // split-K: k range of blockIdx.z is [z*k_chunk, min(K,(z+1)*k_chunk))
     long long slab_stride;        // split-K: C of split z = C + z*slab_stride
     int a_vec, b_vec;             // 16-byte vector loads allowed (base and ld aligned)
-    // grouped launch (two independent products of the same shape in one grid, blockIdx.z = 0/1; no split-K then):
+    // grouped launch (`grouped` = 2 or 3 independent products of the same shape in one grid, blockIdx.z = group; no split-K then):
     int grouped;
-    const float* A2; const float* B2; float* C2; const float* bias2;
+    const float* Ax[2]; const float* Bx[2]; float* Cx[2]; const float* biasx[2];     // groups 1 and 2
+    // DT_BF16: A, B point at bf16 data, K / lda / ldb / k_chunk count PAIRS of bf16 (float units).  EPI_BIAS_TANH then rounds
+    // its result to bf16 and writes it to Cb (bf16 bits, row stride ldcb) — and, when C != nullptr, the rounded value to C too.
+    uint16_t* Cb; long long ldcb; uint16_t* Cbx[2];
+    int* partial_idx;             // EPI_COLMAX: != nullptr => also the row index of each partial maximum (first maximum wins)
     int bias_padded;              // EPI_COLMAX: bias[] is 16-byte aligned and readable up to the last tile's edge
     int prio_split;               // persistent kernel: blocks >= prio_split run at s_setprio 1 (0 = off) ...
     int prio_tiles;               // ... and own tiles [0, prio_tiles); the other blocks own [prio_tiles, total)
@@ -166,7 +180,30 @@ __device__ __forceinline__ void frag_read(const float* __restrict__ Xs, int wbas
 
 // MFMAs of one staged k-tile (32 deep = 4 chunks of 8).  Fragments of chunk c+1 are read from LDS while the MFMAs of
 // chunk c issue (two named register sets, static indexing).
-template <int ASL, int BL, int BM, int BN, int TM, int TN>
+template <int TM, int TN, int DT>
+__device__ __forceinline__ void chunk_mma(const float (&fa)[TM][4], const float (&fb)[TN][4], f32x16 (&acc)[TM][TN]) {
+    if (DT == DT_BF16) {           // the 4 floats of a fragment ARE 8 consecutive bf16 of k: one 32x32x16 MFMA per tile pair
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f32x4 a = {fa[i][0], fa[i][1], fa[i][2], fa[i][3]};
+                const f32x4 b = {fb[j][0], fb[j][1], fb[j][2], fb[j][3]};
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                                    acc[i][j], 0, 0, 0);
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <int ASL, int BL, int BM, int BN, int TM, int TN, int DT = DT_F32>
 __device__ __forceinline__ void tile_mma(const float* __restrict__ As, const float* __restrict__ Bs, int wm, int wn, int r, int h,
                                          f32x16 (&acc)[TM][TN]) {
     float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
@@ -177,29 +214,17 @@ __device__ __forceinline__ void tile_mma(const float* __restrict__ As, const flo
         frag_read<ASL, BM, TM>(As, wm * 32 * TM, c + 1, r, h, fa1);
         frag_read<BL, BN, TN>(Bs, wn * 32 * TN, c + 1, r, h, fb1);
         __builtin_amdgcn_sched_barrier(0);                        // keep the DS reads ahead of the whole MFMA block
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][t], fb0[j][t], acc[i][j], 0, 0, 0);
+        chunk_mma<TM, TN, DT>(fa0, fb0, acc);
         if (c + 2 < GBK / 8) {
             frag_read<ASL, BM, TM>(As, wm * 32 * TM, c + 2, r, h, fa0);
             frag_read<BL, BN, TN>(Bs, wn * 32 * TN, c + 2, r, h, fb0);
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i][t], fb1[j][t], acc[i][j], 0, 0, 0);
+        chunk_mma<TM, TN, DT>(fa1, fb1, acc);
     }
 }
 
-template <int AL, int BL, int TM, int TN, bool FAST>
+template <int AL, int BL, int TM, int TN, bool FAST, int DT = DT_F32>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* __restrict__ As, float* __restrict__ Bs, int m0, int n0,
                                               int kbeg, int kend, f32x16 (&acc)[TM][TN]) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -221,21 +246,25 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* __restri
             stage_load<AL, BM, FAST>(g, g.A, g.lda, g.a_vec, m0, g.M, k0 + GBK, kend, va);
             stage_load<BL, BN, FAST>(g, g.B, g.ldb, g.b_vec, n0, g.N, k0 + GBK, kend, vb);
         }
-        tile_mma<AL, BL, BM, BN, TM, TN>(As, Bs, wm, wn, r, h, acc);
+        tile_mma<AL, BL, BM, BN, TM, TN, DT>(As, Bs, wm, wn, r, h, acc);
     }
 }
 
 // column-max epilogue: partial[(tile_m*2 + wm)][n] = max over the wave's rows of (acc + bias[m]); runs over the
-// accumulator registers of one lane, then one exchange between the two half-waves
+// accumulator registers of one lane, then one exchange between the two half-waves.  With g.partial_idx the row index of
+// the maximum travels along: rows are visited in ascending order per lane with a strict >, the half-wave exchange and the
+// later reduction over the partials break ties towards the lower row => the FIRST maximum, like dqn.cpp:48.
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_colmax(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int m0, int n0, int tile_m) {
     const int lane = (int)threadIdx.x & 63, wid = (int)threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
     const float NEG = -__builtin_inff();
+    const bool want_idx = g.partial_idx != nullptr;
     float cm[TN];
+    int ci[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) cm[j] = NEG;
+    for (int j = 0; j < TN; ++j) { cm[j] = NEG; ci[j] = 0x7fffffff; }
     // The 16 rows a lane holds of one 32x32 tile are four runs of 4 consecutive rows (reg 4g..4g+3 -> row 8g + 4h + 0..3):
     // their biases come as four 16-byte loads per tile, issued together (a branch per row compiles to 32 serialised
     // load + wait pairs; one wide batch keeps the register footprint of the epilogue small).  Rows >= M are masked by
@@ -256,24 +285,39 @@ __device__ __forceinline__ void epilogue_colmax(const GemmArgs& g, const f32x16 
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const bool ok = mb + (q & 3) + 8 * (q >> 2) < g.M;
+            const int row = mb + (q & 3) + 8 * (q >> 2);
+            const bool ok = row < g.M;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) cm[j] = fmaxf(cm[j], ok ? acc[i][j][q] + bm[q] : NEG);
+            for (int j = 0; j < TN; ++j) {
+                const float v = ok ? acc[i][j][q] + bm[q] : NEG;
+                if (want_idx) { if (v > cm[j]) { cm[j] = v; ci[j] = row; } }
+                else cm[j] = fmaxf(cm[j], v);
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const float v = fmaxf(cm[j], __shfl_xor(cm[j], 32, 64));      // the other 4-row groups live in the other half-wave
+        const float ov = __shfl_xor(cm[j], 32, 64);                   // the other 4-row groups live in the other half-wave
+        const int oi = __shfl_xor(ci[j], 32, 64);
+        float v = fmaxf(cm[j], ov);
+        int idx = ci[j];
+        if (want_idx && (ov > cm[j] || (ov == cm[j] && oi < ci[j]))) idx = oi;
         const int n = n0 + wn * 32 * TN + j * 32 + r;
-        if (h == 0 && n < g.N) g.partial[((long long)tile_m * 2 + wm) * g.N + n] = v;
+        if (h == 0 && n < g.N) {
+            g.partial[((long long)tile_m * 2 + wm) * g.N + n] = v;
+            if (want_idx) g.partial_idx[((long long)tile_m * 2 + wm) * g.N + n] = idx;
+        }
     }
 }
 
-template <int AL, int BL, int EPI, int TM, int TN>
+template <int AL, int BL, int EPI, int TM, int TN, int DT = DT_F32>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_f32_kernel(const GemmArgs g_in) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     GemmArgs g = g_in;
-    if (g_in.grouped && blockIdx.z == 1) { g.A = g_in.A2; g.B = g_in.B2; g.C = g_in.C2; g.bias = g_in.bias2; }
+    if (g_in.grouped && blockIdx.z >= 1) {
+        const int k = (int)blockIdx.z - 1;
+        g.A = g_in.Ax[k]; g.B = g_in.Bx[k]; g.C = g_in.Cx[k]; g.bias = g_in.biasx[k]; g.Cb = g_in.Cbx[k];
+    }
     __shared__ __attribute__((aligned(16))) float As[g_tile_floats(BM)];
     __shared__ __attribute__((aligned(16))) float Bs[g_tile_floats(BN)];
 
@@ -296,8 +340,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     // interior tiles (all rows/columns in range, k range a multiple of 32, 16-byte aligned operands) take the
     // branch-free loaders; the decision is block-uniform
     const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (((kend - kbeg) & (GBK - 1)) == 0) && g.a_vec && g.b_vec;
-    if (interior) gemm_mainloop<AL, BL, TM, TN, true>(g, As, Bs, m0, n0, kbeg, kend, acc);
-    else gemm_mainloop<AL, BL, TM, TN, false>(g, As, Bs, m0, n0, kbeg, kend, acc);
+    if (interior) gemm_mainloop<AL, BL, TM, TN, true, DT>(g, As, Bs, m0, n0, kbeg, kend, acc);
+    else gemm_mainloop<AL, BL, TM, TN, false, DT>(g, As, Bs, m0, n0, kbeg, kend, acc);
 
     // ---- epilogue.  32x32 accumulator map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ---------------
     if (EPI == EPI_COLMAX) {
@@ -305,6 +349,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         return;
     }
     float* Cz = g.grouped ? g.C : g.C + (long long)blockIdx.z * g.slab_stride;
+    if (DT == DT_BF16 && EPI == EPI_BIAS_TANH) {
+        // bf16 Q-net: a = bf16(tanh(acc + bias)); the bf16 bits feed the next layer's MFMA, the (optional) fp32 copy of the
+        // SAME rounded value feeds the fp32 backward pass
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * 32 * TN + j * 32 + r;
+                if (n >= g.N) continue;
+                const float bias = g.bias[n];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int m = m0 + wm * 32 * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    if (m >= g.M) continue;
+                    float v = tanhf(acc[i][j][q] + bias);
+                    if (g.Cb) {                                  // hidden layer: rounded; the Q head (no Cb) stays fp32
+                        const __bf16 rb = (__bf16)v;
+                        g.Cb[(long long)m * g.ldcb + n] = __builtin_bit_cast(uint16_t, rb);
+                        v = (float)rb;
+                    }
+                    if (Cz) Cz[(long long)m * g.ldc + n] = v;
+                }
+            }
+        return;
+    }
     if ((m0 + BM <= g.M) && (n0 + BN <= g.N)) {
         // tile fully inside the output: no per-element bounds logic, so the epilogue's loads (bias / activation for the
         // delta) are issued as one batch instead of a load + wait per row
@@ -362,7 +431,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // the current one.  Requires K % 32 == 0, 16-byte aligned operands, and both operands readable up to the next multiple of
 // 128 rows (the callers pad their allocations, finite contents); rows beyond M never win the max (their bias is -inf in
 // LDS), columns beyond N are not stored.  Dynamic LDS: tiles_m * 128 floats (the bias vector).
-template <int TM, int TN>
+// ARG: also the row index of each partial maximum (g.partial_idx; first maximum wins, see epilogue_colmax) — Double DQN.
+// DT_BF16: bf16 operands (K counts pairs), same loop; the MFMA share of a k-step drops 16x, so the kernel is then bound by
+// its LDS staging, not by the matrix pipe.
+template <int TM, int TN, int DT = DT_F32, bool ARG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_colmax_persistent_kernel(const GemmArgs g,
                                                                                                         int tiles_m, int total) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -433,7 +505,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 stage_load<L_KCONTIG, BM, true>(g, g.A, g.lda, 1, (tnext % tiles_m) * BM, g.M, 0, g.K, va);
                 stage_load<L_KCONTIG, BN, true>(g, g.B, g.ldb, 1, (tnext / tiles_m) * BN, g.N, 0, g.K, vb);
             }
-            tile_mma<L_KCONTIG, L_KCONTIG, BM, BN, TM, TN>(As, Bs, wm, wn, r, h, acc);
+            tile_mma<L_KCONTIG, L_KCONTIG, BM, BN, TM, TN, DT>(As, Bs, wm, wn, r, h, acc);
         }
         // epilogue: partial[(tile_m*2 + wm)][n] = max over the wave's rows of (acc + bias[m]).  32x32 accumulator map:
         // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) — four runs of 4 consecutive rows per tile, one ds_read_b128 each; the
@@ -442,17 +514,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float c = -__builtin_inff();
+            int ci = 0x7fffffff;
+            const int row0 = tm * BM + wm * 32 * TM + 4 * h;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const float4 x = *reinterpret_cast<const float4*>(bt + i * 32 + 8 * gq);
-                    c = fmaxf(c, acc[i][j][4 * gq] + x.x); c = fmaxf(c, acc[i][j][4 * gq + 1] + x.y);
-                    c = fmaxf(c, acc[i][j][4 * gq + 2] + x.z); c = fmaxf(c, acc[i][j][4 * gq + 3] + x.w);
+                    if (ARG) {                     // rows ascending within the lane + strict > : the lane's FIRST maximum
+                        const float v0 = acc[i][j][4 * gq] + x.x, v1 = acc[i][j][4 * gq + 1] + x.y;
+                        const float v2 = acc[i][j][4 * gq + 2] + x.z, v3 = acc[i][j][4 * gq + 3] + x.w;
+                        const int rb = row0 + i * 32 + 8 * gq;
+                        if (v0 > c) { c = v0; ci = rb; }
+                        if (v1 > c) { c = v1; ci = rb + 1; }
+                        if (v2 > c) { c = v2; ci = rb + 2; }
+                        if (v3 > c) { c = v3; ci = rb + 3; }
+                    } else {
+                        c = fmaxf(c, acc[i][j][4 * gq] + x.x); c = fmaxf(c, acc[i][j][4 * gq + 1] + x.y);
+                        c = fmaxf(c, acc[i][j][4 * gq + 2] + x.z); c = fmaxf(c, acc[i][j][4 * gq + 3] + x.w);
+                    }
                 }
-            c = fmaxf(c, __shfl_xor(c, 32, 64));
+            const float oc = __shfl_xor(c, 32, 64);
             const int n = tn * BN + wn * 32 * TN + j * 32 + r;
-            if (h == 0 && n < g.N) g.partial[((long long)tm * 2 + wm) * g.N + n] = c;
+            if (ARG) {
+                const int oi = __shfl_xor(ci, 32, 64);
+                const bool take = oc > c || (oc == c && oi < ci);
+                if (h == 0 && n < g.N) {
+                    g.partial[((long long)tm * 2 + wm) * g.N + n] = take ? oc : c;
+                    g.partial_idx[((long long)tm * 2 + wm) * g.N + n] = take ? oi : ci;
+                }
+            } else {
+                c = fmaxf(c, oc);
+                if (h == 0 && n < g.N) g.partial[((long long)tm * 2 + wm) * g.N + n] = c;
+            }
         }
         if (tnext >= tend) break;
         t = tnext; tm = t % tiles_m; tn = t / tiles_m;

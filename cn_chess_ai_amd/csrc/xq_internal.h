@@ -13,6 +13,10 @@ struct ReplayDev {
     float* reward = nullptr;          // [capacity]
     uint8_t* done = nullptr;          // [capacity]
     int capacity = 0;
+    // prioritized replay (xq_replay_enable_per; nullptr = uniform): priority of every slot = leaves of the sum tree, and the
+    // largest priority assigned so far as it stood at the last rebuild (what a new transition enters with), as float bits
+    float* prio = nullptr;            // [capacity rounded up to 32]
+    const unsigned* pmax_snap = nullptr;
 };
 
 struct xq_replay {
@@ -31,6 +35,19 @@ struct xq_replay {
     int implicit_start = 0;           // windowed sample: slot = (start + philox % size) % capacity
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // prioritized replay (build-defined, BASELINE configs[4]): radix-32 sum tree, level 0 = dev.prio
+    struct Per {
+        bool enabled = false;
+        float alpha = 0.6f, beta = 0.4f, eps = 1e-3f;
+        int nlv = 0, n[8] = {0}, p[8] = {0};
+        float* leaves = nullptr;          // level 0 as of the last rebuild (copy of dev.prio; the sampler reads this, never the live table)
+        float* upper = nullptr;           // levels 1.. concatenated (padded), root last
+        size_t off[8] = {0};              // offset of level lv inside `upper` (lv >= 1)
+        unsigned* scalars = nullptr;      // [0] max priority, live (atomicMax of float bits)  [1] its snapshot at the last rebuild
+                                          // [2] max raw importance weight of the last sample (float bits)  [3] eligible slots (p > 0)
+        float* is_w = nullptr;            // [slots_cap] raw importance weights of the last prioritized sample
+        bool last_prioritized = false;
+    } per;
 };
 
 struct xq_env {
@@ -130,6 +147,10 @@ hipEvent_t dqn_qmax_event(xq_dqn* d);      // recorded behind the column-max GEM
 // but no kernel and no slot buffer — the consumer kernels recompute them.  Used by the trainer's hot loop.
 // (start, count) restricts the draw to `count` ring slots from `start` (count < 0: the whole filled part).
 int replay_sample_implicit(xq_replay* r, int batch, int start = 0, int count = -1);
+
+// prioritized replay internals used by the trainer (xq_replay.hip)
+int replay_per_rebuild(xq_replay* r, int retire_start, int retire_count, hipStream_t on);
+int replay_per_sample(xq_replay* r, int batch, hipStream_t on);
 
 // env-side launchers used by the trainer
 int env_selfplay_launch(xq_env* env, const float* q90_dev, int q_stride, uint32_t eps_u32, xq_step_result* results_dev,

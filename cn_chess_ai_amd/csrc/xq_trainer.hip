@@ -31,6 +31,7 @@ struct xq_trainer {
     int prepaid_collects = 0;               // collects learn_grads had to run itself (empty ring), owed to the next collect() calls
     int excluded = 0;                       // ring slots the queued learn_grads left out of its minibatch (from write_pos - inflight)
     hipEvent_t ev_grads = nullptr;          // main: the queued learn_grads has finished reading the ring
+    bool per_ready = false;                 // prioritized replay: the sum tree holds the ring as of the last learn_apply
 };
 
 using namespace xq;
@@ -67,6 +68,12 @@ static int trainer_init(xq_trainer* t, const xq_trainer_config* cfg, void* hip_s
                          t->stream, &t->dqn));
     const int cap = cfg->replay_capacity > 0 ? cfg->replay_capacity : cfg->n_games;
     XQ_TRY(xq_replay_create(cap, cfg->seed + 0x1234567ull + cfg->first_game_id, t->stream, &t->replay));
+    if (cfg->precision != XQ_PRECISION_F32) XQ_TRY(xq_dqn_set_precision(t->dqn, cfg->precision));
+    if (cfg->prioritized) {
+        if (cfg->replay_capacity == 0) return fail(XQ_ERR_INVALID_ARGUMENT, "prioritized replay needs a replay ring (replay_capacity > 0)");
+        XQ_TRY(xq_replay_enable_per(t->replay, cfg->per_alpha > 0 ? cfg->per_alpha : 0.6, cfg->per_beta > 0 ? cfg->per_beta : 0.4,
+                                    cfg->per_eps > 0 ? cfg->per_eps : 1e-3));
+    }
     const double e = cfg->epsilon < 0 ? 0 : cfg->epsilon;
     const double v = e * 4294967296.0;
     t->eps_u32 = v >= 4294967295.0 ? 4294967295u : (uint32_t)v;
@@ -160,8 +167,34 @@ int xq_trainer_random_plies(xq_trainer* t, int n_plies) {
     return XQ_OK;
 }
 
+// Prioritized replay: the minibatch comes from the sum tree as of the last learn_apply — it holds every transition collected
+// before this iteration except the slots this iteration's collects overwrite (retired there), in both call orders and with or
+// without overlap_collect.  An empty tree (first iteration) is filled by playing this iteration's plies first.
+static int learn_grads_prioritized(xq_trainer* t) {
+    const int plies = t->cfg.collects_per_update > 1 ? t->cfg.collects_per_update : 1;
+    if (!t->per_ready) {
+        if (t->inflight == 0 && t->replay->size == 0) {
+            for (int c = 0; c < plies; ++c) XQ_TRY(collect_impl(t));
+            t->prepaid_collects = plies;
+        }
+        if (t->cstream) { XQ_HIP(hipStreamWaitEvent(t->stream, t->ev_collect, 0)); t->inflight = 0; }
+        if (t->replay->size == 0) return fail(XQ_ERR_RUNTIME, "replay is empty");
+        XQ_TRY(replay_per_rebuild(t->replay, 0, 0, t->stream));
+        t->per_ready = true;
+        t->excluded = 0;
+    } else {
+        t->excluded = plies * t->cfg.n_games;       // retired at the last learn_apply: the collects may run beside this step
+    }
+    XQ_TRY(replay_per_sample(t->replay, t->cfg.minibatch, t->stream));
+    XQ_TRY(xq_dqn_td_grads_replay(t->dqn, t->replay, t->cfg.minibatch, t->cfg.td_net, t->cfg.backprop_mode));
+    if (t->cstream) XQ_HIP(hipEventRecord(t->ev_grads, t->stream));
+    t->grads_queued = true;
+    return XQ_OK;
+}
+
 int xq_trainer_learn_grads(xq_trainer* t) {
     if (!t) return fail(XQ_ERR_INVALID_ARGUMENT, "null trainer");
+    if (t->cfg.prioritized) return learn_grads_prioritized(t);
     int batch = 0;
     if (t->cfg.replay_capacity > 0) {
         batch = t->cfg.minibatch;
@@ -208,6 +241,16 @@ int xq_trainer_learn_apply(xq_trainer* t, int world_size) {
     t->updates += 1;
     if (t->cfg.target_sync_interval > 0 && t->updates % (uint64_t)t->cfg.target_sync_interval == 0)
         XQ_TRY(xq_dqn_update_target(t->dqn));
+    if (t->cfg.prioritized) {
+        // the tree of the next iteration: this iteration's TD-error priorities and new transitions in, the slots the next
+        // collects will overwrite out (only once the ring is full — before that they are fresh slots with priority 0)
+        const int plies = t->cfg.collects_per_update > 1 ? t->cfg.collects_per_update : 1;
+        const int m = plies * t->cfg.n_games;
+        const xq_replay* r = t->replay;
+        const bool full = r->size + m > r->dev.capacity;
+        XQ_TRY(replay_per_rebuild(t->replay, r->write_pos, full ? std::min(m, r->dev.capacity) : 0, t->stream));
+        t->per_ready = true;
+    }
     if (t->cstream) {
         XQ_HIP(hipEventRecord(t->ev_params, t->stream));
         t->inflight = 0;

@@ -165,6 +165,14 @@ class DQN:
                      bytes=arr[i].bytes) for i in range(n.value)]
 
 
+def _set_precision(self, precision):
+    """_capi.PRECISION_F32 / PRECISION_BF16: arithmetic of the forward passes on packed boards (bf16 MFMA Q-net)."""
+    call("xq_dqn_set_precision", self._h, int(precision))
+
+
+DQN.set_precision = _set_precision
+
+
 def _set_comm(self, comm):
     """Attach an xq_comm (dist.Comm) or None: td_grads then all-reduces the gradient buffer itself, in buckets."""
     call("xq_dqn_set_comm", self._h, comm.handle if comm is not None else None)
@@ -195,7 +203,8 @@ DQN.kernel_timeline = _timeline
 def TrainerConfig(n_games=8192, layer_sizes=(1260, 256, 256, 8100), learning_rate=0.001, gamma=0.99, epsilon=0.1,
                   replay_capacity=1 << 20, minibatch=8192, td_net=_capi.TD_TARGET_NET,
                   backprop_mode=_capi.BACKPROP_REFERENCE, target_sync_interval=100, mean_gradient=1, seed=0x5EED,
-                  first_game_id=0, collects_per_update=1, overlap_collect=0):
+                  first_game_id=0, collects_per_update=1, overlap_collect=0, prioritized=0, per_alpha=0.0, per_beta=0.0,
+                  per_eps=0.0, precision=_capi.PRECISION_F32):
     c = _CConfig()
     c.n_games = n_games
     for i, s in enumerate(layer_sizes):
@@ -208,6 +217,8 @@ def TrainerConfig(n_games=8192, layer_sizes=(1260, 256, 256, 8100), learning_rat
     c.seed, c.first_game_id = seed, first_game_id
     c.collects_per_update = collects_per_update
     c.overlap_collect = overlap_collect
+    c.prioritized, c.per_alpha, c.per_beta, c.per_eps = prioritized, per_alpha, per_beta, per_eps
+    c.precision = precision
     return c
 
 

@@ -94,6 +94,35 @@ class ReplayBuffer:
         call("xq_replay_sample_window", self._h, int(batch), int(start), int(count), _ptr(slots, C.c_int32))
         return slots
 
+    # ---- prioritized replay (build-defined, BASELINE configs[4]) ----
+    def enable_per(self, alpha=0.6, beta=0.4, eps=1e-3):
+        call("xq_replay_enable_per", self._h, float(alpha), float(beta), float(eps))
+
+    def per_rebuild(self, retire_start=0, retire_count=0):
+        call("xq_replay_per_rebuild", self._h, int(retire_start), int(retire_count))
+
+    def sample_prioritized(self, batch):
+        """(slots, normalised importance weights) of a stratified proportional draw from the tree as of the last rebuild."""
+        slots = np.zeros(batch, dtype=np.int32)
+        w = np.zeros(batch, dtype=np.float32)
+        call("xq_replay_sample_prioritized", self._h, int(batch), _ptr(slots, C.c_int32), _ptr(w, C.c_float))
+        return slots, w
+
+    def set_priorities(self, prio, first=0):
+        p = np.ascontiguousarray(prio, dtype=np.float32)
+        call("xq_replay_set_priorities", self._h, int(first), len(p), _ptr(p, C.c_float))
+
+    def get_priorities(self, first=0, n=None):
+        n = self.stats()[1] - first if n is None else n
+        p = np.zeros(n, dtype=np.float32)
+        call("xq_replay_get_priorities", self._h, int(first), int(n), _ptr(p, C.c_float))
+        return p
+
+    def per_stats(self):
+        t, m, k = C.c_float(), C.c_float(), C.c_int32()
+        call("xq_replay_per_stats", self._h, C.byref(t), C.byref(m), C.byref(k))
+        return dict(total=t.value, max_priority=m.value, n_eligible=k.value)
+
     def get(self, slot):
         b, nb = np.zeros(90, np.uint8), np.zeros(90, np.uint8)
         a, r, d = C.c_int32(), C.c_float(), C.c_uint8()

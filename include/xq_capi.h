@@ -155,6 +155,23 @@ int xq_replay_sample(xq_replay* r, int batch, int32_t* slots_host /* optional */
 int xq_replay_sample_window(xq_replay* r, int batch, int start, int count, int32_t* slots_host /* optional */);
 int xq_replay_get(xq_replay* r, int slot, uint8_t* board90, int32_t* action_to, float* reward, uint8_t* done,
                   uint8_t* next_board90);
+/* Prioritized replay, proportional variant (Schaul et al., ICLR 2016) — build-defined (BASELINE configs[4]), defined by
+ * DESIGN.md §4:  p_i = (|TD error_i| + eps)^alpha, P(i) = p_i / sum p, stratified draw of one sample per segment of
+ * the total mass (Philox ctr = {k, 0, sample call #, 2}), importance weight w_i = (N * P(i))^-beta / max_batch w applied to the
+ * sample's gradient, new transitions enter with the largest priority assigned so far.  The masses live in a radix-32 sum tree in
+ * HBM whose nodes are sequential fp32 sums (fixed association: sampled slots are reproducible bit for bit).
+ *   xq_replay_enable_per      : once, before use (allocates the priority table and the tree)
+ *   xq_replay_per_rebuild     : zeroes the priorities of `retire_count` slots from `retire_start` (wrapping; slots about to be
+ *                               overwritten), rebuilds the tree from the priority table and snapshots the running maximum
+ *   xq_replay_sample_prioritized: draws `batch` slots from the tree as of the last rebuild; xq_dqn_td_grads_replay then applies the
+ *                               importance weights and writes the new priorities of the sampled slots back
+ *   set/get_priorities, per_stats: tests / interop */
+int xq_replay_enable_per(xq_replay* r, double alpha, double beta, double eps);
+int xq_replay_per_rebuild(xq_replay* r, int retire_start, int retire_count);
+int xq_replay_sample_prioritized(xq_replay* r, int batch, int32_t* slots_host /* optional */, float* weights_host /* optional, normalised */);
+int xq_replay_set_priorities(xq_replay* r, int first, int n, const float* prio_host);
+int xq_replay_get_priorities(xq_replay* r, int first, int n, float* prio_host);
+int xq_replay_per_stats(xq_replay* r, float* total, float* max_priority, int* n_eligible);
 
 /* ------------------------------------------------------------------------------------------------------------
  * xq_dqn — DQN (dqn.h:97-116) = qNetwork + targetNetwork (NeuralNetwork, dqn.h:42-95, dqn.cu), fp32 on MFMA.
@@ -165,7 +182,13 @@ enum { XQ_NET_ONLINE = 0, XQ_NET_TARGET = 1 };
 enum { XQ_BACKPROP_REFERENCE = 0,  /* bug-compatible hidden delta, dqn.cu:406-423 as written */
        XQ_BACKPROP_TEXTBOOK = 1 };
 enum { XQ_TD_ONLINE_NET = 0,       /* max Q(s') from the ONLINE net — what ChessAI::train does (chessai.cpp:126-127) */
-       XQ_TD_TARGET_NET = 1 };     /* max Q(s') from the target net — DQN::train (dqn.cpp:166-167) */
+       XQ_TD_TARGET_NET = 1,       /* max Q(s') from the target net — DQN::train (dqn.cpp:166-167) */
+       XQ_TD_DOUBLE = 2 };         /* Double DQN (build-defined, BASELINE configs[4]): a* = argmax_k Q_online(s')[k] over all outputs
+                                    * (first maximum), y = r + gamma * Q_target(s')[a*] */
+enum { XQ_PRECISION_F32 = 0,       /* fp32 MFMA everywhere (the reference computes in fp64; north_star: fp32, Q within 1e-4) */
+       XQ_PRECISION_BF16 = 1 };    /* bf16 Q-net (build-defined, BASELINE configs[4]): forward passes on bf16 MFMA — weights and hidden
+                                    * activations rounded to bf16 (RNE), fp32 accumulation, biases and outputs fp32; backward and SGD
+                                    * in fp32 on the master weights */
 
 /* DQN::DQN(layerSizes, lr, gamma) (dqn.cpp:12-20) -> NeuralNetwork ctor (dqn.cu:14-57): W ~ U(-0.05,0.05) from a
  * seeded generator, biases 0; target = copy of online.  layer_sizes[0] must be 1260 for the board-input fast path;
@@ -173,6 +196,9 @@ enum { XQ_TD_ONLINE_NET = 0,       /* max Q(s') from the ONLINE net — what Che
 int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, double gamma, uint64_t seed,
                   void* hip_stream, xq_dqn** out);
 int xq_dqn_destroy(xq_dqn* d);
+/* XQ_PRECISION_*: arithmetic of the forward passes on packed boards (action select, TD targets, Q(s,a)).  The dense-state entry
+ * points (xq_dqn_forward / xq_dqn_backpropagate: the reference's std::vector<double> API) always compute in fp32. */
+int xq_dqn_set_precision(xq_dqn* d, int precision);
 int xq_dqn_num_params(const xq_dqn* d, size_t* n_weights, size_t* n_biases);
 /* host_weights / host_biases in the REFERENCE flat layout (row-major [out][in] per layer, layers concatenated,
  * dqn.cu:112-140), fp64 like upstream.  set = copyToDevice() (dqn.cu:480-485), get = copyFromDevice() (:487-492). */
@@ -287,6 +313,11 @@ typedef struct {
     int overlap_collect;                    /* 1: collect runs on its own HIP stream beside learn_grads of the same iteration; both
                                              * read the same parameters, and the minibatch is drawn from the ring minus the slots the
                                              * collect is writing (they become eligible one iteration later).  Needs a replay ring. */
+    /* build-defined modes of BASELINE configs[4] (td_net = XQ_TD_DOUBLE selects Double DQN): */
+    int prioritized;                        /* 1: proportional prioritized replay (xq_replay_enable_per); the minibatch never contains
+                                             * the slots this iteration's collects write: they are retired from the tree at learn_apply */
+    double per_alpha, per_beta, per_eps;    /* 0 => 0.6, 0.4, 1e-3 */
+    int precision;                          /* XQ_PRECISION_* of the Q-network's forward passes */
 } xq_trainer_config;
 
 int xq_trainer_create(const xq_trainer_config* cfg, void* hip_stream, xq_trainer** out);

@@ -115,6 +115,26 @@ typedef struct {
 void xqo_selfplay_step(xqo_board* b, const float* q90, uint64_t seed, uint32_t game_id, uint32_t step_id,
                        uint32_t eps_u32, xqo_step_out* out);
 
+/* =====================================================================================================================
+ * BUILD-DEFINED extensions (oracle/xq_oracle_ext.c) for BASELINE configs[4]: Double DQN, proportional prioritized replay,
+ * bf16 Q-net.  No upstream analogue — this restatement is their definition ("parity unpinned").
+ * ===================================================================================================================== */
+float xqo_bf16_round(float x);
+int  xqo_ext_forward(const int* sizes, int nsizes, const double* w, const double* b, const double* in, int bf16,
+                     double* hidden_acts /* optional, concat a_1.. */, double* z_out /* optional, L[last] pre-activations */);
+int  xqo_ext_td_accum(const int* sizes, int nsizes, const double* w, const double* b, const double* wt, const double* bt,
+                      const double* state, const double* next_state, int action_to, double reward, int done, double gamma,
+                      int td_rule /* 0 online max, 1 target max, 2 double */, int mode, int bf16, double weight,
+                      double* gw, double* gb, double* q_sa, double* y_out, int* a_star);
+int  xqo_per_levels(int capacity, int* n, int* padded);
+size_t xqo_per_tree_floats(int capacity);
+void xqo_per_build(const float* prio, int capacity, float* tree);
+float xqo_per_total(const float* tree, int capacity);
+int  xqo_per_descend(const float* tree, int capacity, float u);
+float xqo_per_sample(const float* tree, int capacity, int batch, uint64_t seed, uint32_t call, int n_eligible, float beta,
+                     int32_t* slots, float* w_raw);
+float xqo_per_priority(float td_error, float eps, float alpha);
+
 #ifdef __cplusplus
 }
 #endif

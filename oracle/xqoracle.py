@@ -43,7 +43,7 @@ class EpisodeStats(C.Structure):
 def build(force=False):
     if force or not os.path.exists(LIB_PATH) or \
             os.path.getmtime(LIB_PATH) < max(os.path.getmtime(os.path.join(HERE, f))
-                                             for f in ("xq_oracle.c", "xq_oracle.h")):
+                                             for f in ("xq_oracle.c", "xq_oracle_ext.c", "xq_oracle.h")):
         subprocess.check_call(["make", "-s", "-C", HERE, "all"])
     return LIB_PATH
 
@@ -88,6 +88,23 @@ def lib():
     L.xqo_philox4x32.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.xqo_selfplay_step.argtypes = [pB, C.POINTER(C.c_float), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.POINTER(StepOut)]
+    # build-defined extensions (xq_oracle_ext.c)
+    pf, pi32 = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    L.xqo_bf16_round.argtypes = [C.c_float]
+    L.xqo_bf16_round.restype = C.c_float
+    L.xqo_ext_forward.argtypes = [pi, C.c_int, pd, pd, pd, C.c_int, pd, pd]
+    L.xqo_ext_td_accum.argtypes = [pi, C.c_int, pd, pd, pd, pd, pd, pd, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int,
+                                   C.c_int, C.c_int, C.c_double, pd, pd, pd, pd, pi]
+    L.xqo_per_tree_floats.argtypes = [C.c_int]
+    L.xqo_per_tree_floats.restype = C.c_size_t
+    L.xqo_per_build.argtypes = [pf, C.c_int, pf]
+    L.xqo_per_total.argtypes = [pf, C.c_int]
+    L.xqo_per_total.restype = C.c_float
+    L.xqo_per_descend.argtypes = [pf, C.c_int, C.c_float]
+    L.xqo_per_sample.argtypes = [pf, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_float, pi32, pf]
+    L.xqo_per_sample.restype = C.c_float
+    L.xqo_per_priority.argtypes = [C.c_float, C.c_float, C.c_float]
+    L.xqo_per_priority.restype = C.c_float
     _lib = L
     return L
 
@@ -192,6 +209,47 @@ def td_target(sizes, w, b, state, next_state, action_to, reward, done, gamma):
                              float(reward), int(done), float(gamma), _pd(tq))
     assert rc == 0
     return tq
+
+
+# ---------------------------------------------------------------- build-defined extensions (configs[4])
+def ext_forward(sizes, w, b, x, bf16=False):
+    """(hidden activations concat, z of the output layer) in fp64 or in the bf16 Q-net arithmetic."""
+    s = sizes_arr(sizes)
+    acts = np.zeros(int(sum(s[1:-1])), dtype=np.float64)
+    z = np.zeros(int(s[-1]), dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    assert lib().xqo_ext_forward(_pi(s), len(s), _pd(w), _pd(b), _pd(x), int(bf16), _pd(acts), _pd(z)) == 0
+    return acts, z
+
+
+def ext_td_accum(sizes, w, b, wt, bt, state, next_state, action_to, reward, done, gamma, td_rule, mode, bf16, weight, gw, gb):
+    """Accumulates the weighted TD gradient of one transition; returns (Q(s,a), y, a*)."""
+    s = sizes_arr(sizes)
+    q, y, a = C.c_double(), C.c_double(), C.c_int()
+    state = np.ascontiguousarray(state, dtype=np.float64)
+    next_state = np.ascontiguousarray(next_state, dtype=np.float64)
+    rc = lib().xqo_ext_td_accum(_pi(s), len(s), _pd(w), _pd(b), _pd(wt), _pd(bt), _pd(state), _pd(next_state), int(action_to),
+                                float(reward), int(done), float(gamma), int(td_rule), int(mode), int(bf16), float(weight),
+                                _pd(gw), _pd(gb), C.byref(q), C.byref(y), C.byref(a))
+    assert rc == 0
+    return q.value, y.value, a.value
+
+
+def per_build(prio):
+    prio = np.ascontiguousarray(prio, dtype=np.float32)
+    tree = np.zeros(lib().xqo_per_tree_floats(len(prio)), dtype=np.float32)
+    pf = C.POINTER(C.c_float)
+    lib().xqo_per_build(prio.ctypes.data_as(pf), len(prio), tree.ctypes.data_as(pf))
+    return tree
+
+
+def per_sample(tree, capacity, batch, seed, call, n_eligible, beta):
+    slots = np.zeros(batch, dtype=np.int32)
+    w = np.zeros(batch, dtype=np.float32)
+    pf = C.POINTER(C.c_float)
+    wmax = lib().xqo_per_sample(tree.ctypes.data_as(pf), int(capacity), int(batch), C.c_uint64(int(seed)), int(call),
+                                int(n_eligible), float(beta), slots.ctypes.data_as(C.POINTER(C.c_int32)), w.ctypes.data_as(pf))
+    return slots, w, float(wmax)
 
 
 def philox(ctr, key):
