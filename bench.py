@@ -31,7 +31,25 @@ N_GAMES = 8192
 LAYERS = (1260, 256, 256, 8100)
 REPLAY = 1 << 20
 MINIBATCH = 8192
+# --config K: K = 1-based index into BASELINE.json `configs` (2 = configs[1], the configuration `metric` is quoted on and the default;
+# 4 / 5 = the per-GPU share of the 8-GPU configs[3] / configs[4], printed as lines of their own, never in place of the headline)
+CONFIGS = {
+    2: dict(workload="BASELINE configs[1]: 8192 self-play games per GPU, DQN 1260-256-256-8100 fp32, replay 1M transitions, "
+                     "minibatch 8192, one update per ply",
+            games=8192, layers=(1260, 256, 256, 8100), replay=1 << 20, minibatch=8192, plies=1, td="online", dtype="f32",
+            prioritized=0, bf16=False),
+    4: dict(workload="BASELINE configs[3], per-GPU share (65536 games / 8): 8192 games, DQN 1260-512-512-512-8100 fp32, one update "
+                     "(gradient all-reduce when N > 1) per 4 env steps, replay 1M, minibatch 8192",
+            games=8192, layers=(1260, 512, 512, 512, 8100), replay=1 << 20, minibatch=8192, plies=4, td="online", dtype="f32",
+            prioritized=0, bf16=False),
+    5: dict(workload="BASELINE configs[4], per-GPU share (131072 games / 8): 16384 games, Double-DQN + proportional prioritized replay "
+                     "(alpha 0.6, beta 0.4), bf16 MFMA Q-net 1260-512-512-512-8100 (fp32 master weights and backward), replay 1M, "
+                     "minibatch 16384, one update per ply",
+            games=16384, layers=(1260, 512, 512, 512, 8100), replay=1 << 20, minibatch=16384, plies=1, td="double", dtype="bf16",
+            prioritized=1, bf16=True),
+}
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 ENV_BYTES_PER_GAME = 2 * (48 + 16) + 360 + 105   # board+meta r/w, Q row, transition record
 
@@ -153,10 +171,12 @@ def main():
                     help="diagnostic: time only the fused self-play kernel with the uniform-random policy (no Q-network)")
     ap.add_argument("--independent", action="store_true",
                     help="BASELINE configs[2]: N > 1 ranks train independent replicas on their own game shards, no gradient all-reduce")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs entry, 1-based: 2 = configs[1] (headline, default), 4 = configs[3] share, 5 = configs[4] share")
     ap.add_argument("--prefill-plies", type=int, default=300,
                     help="uniform-random plies played in every game before anything is timed (spreads the games over all phases)")
     ap.add_argument("--no-fill", action="store_true", help="diagnostic: do not fill the replay ring before timing")
-    ap.add_argument("--td-net", choices=("online", "target"), default="online",
+    ap.add_argument("--td-net", choices=("online", "target", "double"), default=None,
                     help="net that gives max Q(s'): online = ChessAI::train (chessai.cpp:126, headline), target = DQN::train (dqn.cpp:166)")
     ap.add_argument("--target-sync-interval", type=int, default=10, help="updates between updateTargetNetwork() calls")
     ap.add_argument("--torch-allreduce", action="store_true",
@@ -193,16 +213,24 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
 
-    n_games = args.games
-    minibatch = args.minibatch or (MINIBATCH if n_games == N_GAMES else n_games)
+    global LAYERS, REPLAY
+    CFG = CONFIGS[args.config]
+    LAYERS, REPLAY = CFG["layers"], CFG["replay"]
+    n_games = args.games if args.games != N_GAMES or args.config == 2 else CFG["games"]
+    minibatch = args.minibatch or (CFG["minibatch"] if n_games == CFG["games"] else n_games)
+    if args.td_net is None:
+        args.td_net = CFG["td"]
+    td_code = {"online": _capi.TD_ONLINE_NET, "target": _capi.TD_TARGET_NET, "double": _capi.TD_DOUBLE}
     if args.env_only:
         return env_only(args, xq, tstream)
     first, _ = xd.shard_games(rank, n_games)
     cfg = xq.TrainerConfig(n_games=n_games, layer_sizes=LAYERS, learning_rate=0.001, gamma=0.99, epsilon=0.1,
-                           replay_capacity=max(REPLAY, n_games), minibatch=minibatch,
-                           td_net=_capi.TD_ONLINE_NET if args.td_net == "online" else _capi.TD_TARGET_NET,
+                           replay_capacity=max(REPLAY, n_games), minibatch=minibatch, td_net=td_code[args.td_net],
                            backprop_mode=_capi.BACKPROP_REFERENCE, target_sync_interval=args.target_sync_interval, mean_gradient=1,
-                           seed=0x5EED, first_game_id=first, overlap_collect=0 if args.no_overlap else 1)
+                           seed=0x5EED, first_game_id=first, overlap_collect=0 if args.no_overlap else 1,
+                           collects_per_update=CFG["plies"], prioritized=CFG["prioritized"],
+                           precision=_capi.PRECISION_BF16 if CFG["bf16"] else _capi.PRECISION_F32)
+    plies = CFG["plies"]
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
     grads, comm = None, None
     if world == 1 or args.independent:
@@ -218,11 +246,13 @@ def main():
 
     def one_step():
         if args.no_overlap:
-            t.collect()
+            for _ in range(plies):
+                t.collect()
             t.learn_grads()
         else:                   # collect is queued behind the column-max GEMM of learn_grads and runs beside the gradient chain
             t.learn_grads()
-            t.collect()
+            for _ in range(plies):
+                t.collect()
         if grads is not None and not args.independent:
             xd.allreduce_gradients(grads, world)
         t.learn_apply(1 if args.independent else world)
@@ -257,18 +287,20 @@ def main():
     stats = {s["name"]: s for s in t.dqn.kernel_stats(enable=0)}
     c1 = t.counters()
     # the other TD rule on the same trainer, same steady state, timed the same way (reported beside the headline)
-    other = "target" if args.td_net == "online" else "online"
-    t.set_td_net(_capi.TD_TARGET_NET if other == "target" else _capi.TD_ONLINE_NET)
-    one_step()
-    el_other, _ = timed(args.steps)
-    t.set_td_net(_capi.TD_ONLINE_NET if args.td_net == "online" else _capi.TD_TARGET_NET)
+    other, el_other = None, None
+    if args.config == 2 and args.td_net in ("online", "target"):
+        other = "target" if args.td_net == "online" else "online"
+        t.set_td_net(td_code[other])
+        one_step()
+        el_other, _ = timed(args.steps)
+        t.set_td_net(td_code[args.td_net])
     # workload statistics of the state the numbers were taken in (host reads, outside every timed region)
     import numpy as np
     _, meta = t.env.get_state()
     _, legal_counts = t.env.legal_moves(-1)
     rp_size, rp_cap, rp_total = t.replay.stats()
     iso = {}
-    if not args.no_overlap and world == 1:
+    if not args.no_overlap and world == 1 and args.config == 2:
         # the same two kernels with nothing beside them (device-wide sync between collect and learn), outside the timed region:
         # in the overlapped loop the env kernel shares the chip with the TD step, so its live duration is not its own
         t.dqn.kernel_stats(enable=3)
@@ -289,23 +321,24 @@ def main():
             print(f"replicas identical on {world} ranks: {digest.tolist()}", file=sys.stderr)
 
     if rank == 0:
-        env_steps = world * n_games * args.steps
+        env_steps = world * n_games * plies * args.steps
+        td_text = {"online": "online (max Q(s') from the online net, chessai.cpp:126)",
+                   "target": "target (max Q(s') from the target net, dqn.cpp:166)",
+                   "double": "double (a* = argmax_a Q_online(s',a), y = r + gamma Q_target(s',a*); build-defined)"}[args.td_net]
         line = {
             "metric": "env steps/sec + DQN updates/sec at 8192 parallel games, 1/2/4/8 MI355X",
             "value": env_steps / elapsed, "unit": "env steps/s",
             "updates_per_s": args.steps / elapsed,
             "transitions_trained_per_s": world * minibatch * args.steps / elapsed,
+            "metric_config": "BASELINE.json configs[%d]%s" % (args.config - 1, "" if args.config == 2 else " (NOT the headline configuration)"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "variant_td_" + other: {"value": world * n_games * args.steps / el_other, "unit": "env steps/s",
-                                    "updates_per_s": args.steps / el_other, "ms_per_step": 1e3 * el_other / args.steps},
-            "config": {"workload": "BASELINE configs[1]: 8192 self-play games per GPU, DQN 1260-256-256-8100 fp32, "
-                                   "replay 1M transitions, minibatch 8192, one update per ply",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": CFG["dtype"], "data": "synthetic",
+            "config": {"workload": CFG["workload"], "baseline_config": args.config,
                        "games_per_gpu": n_games, "layer_sizes": list(LAYERS), "replay_capacity": max(REPLAY, n_games),
-                       "minibatch": minibatch, "epsilon": 0.1, "backprop": "reference-compatible",
-                       "td_net": args.td_net + (" (max Q(s') from the online net, chessai.cpp:126)" if args.td_net == "online"
-                                                else " (max Q(s') from the target net, dqn.cpp:166)"),
+                       "minibatch": minibatch, "plies_per_update": plies, "epsilon": 0.1, "backprop": "reference-compatible",
+                       "td_net": td_text, "prioritized_replay": bool(CFG["prioritized"]),
+                       "q_net_precision": "bf16 forward (fp32 master weights, fp32 backward)" if CFG["bf16"] else "fp32",
                        "target_sync_interval": args.target_sync_interval,
                        "target_syncs_in_timed_region": (c1["updates"] // max(args.target_sync_interval, 1)
                                                         - c0["updates"] // max(args.target_sync_interval, 1)) if args.target_sync_interval else 0,
@@ -323,15 +356,20 @@ def main():
                                        f"behind the C ABI, two buckets released by their producers)" if comm is not None else
                                        f"dp{world} (games sharded, gradient all-reduce per update through torch.distributed)")},
         }
+        if other is not None:
+            line["variant_td_" + other] = {"value": world * n_games * plies * args.steps / el_other, "unit": "env steps/s",
+                                           "updates_per_s": args.steps / el_other, "ms_per_step": 1e3 * el_other / args.steps}
         g = stats.get("gemm_qmax_rowmax")
         if g and g["launches"]:
             ms = g["ms"] / g["launches"]
             fl = g["flops"] / g["launches"]
             ach = fl / (ms * 1e-3) / 1e12
-            tr, src = pmc_traffic("gemm_colmax_persistent_kernel")
-            line["roofline"] = {"kernel": "gemm_colmax_persistent_kernel<2,2> (max_a' Q(s'): 8100 x 8192 x 256, fp32 MFMA)",
-                                "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, offline)",
+            peak = PEAK_BF16_MFMA_TFLOPS if CFG["bf16"] else PEAK_F32_MFMA_TFLOPS
+            tr, src = pmc_traffic("gemm_colmax_persistent_kernel") if args.config == 2 else (None, None)
+            line["roofline"] = {"kernel": "gemm_colmax_persistent_kernel<2,2> (%s_a' Q(s'): 8100 x %d x %d, %s MFMA)" %
+                                          ("argmax" if args.td_net == "double" else "max", minibatch, LAYERS[-2], CFG["dtype"]),
+                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                                "frac": ach / peak, "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, offline)",
                                 "traffic_source": src, "avg_launch_ms": ms, "flops_per_launch": fl, "launches": g["launches"]}
             gi = iso.get("gemm_qmax_rowmax")
             if gi and gi["launches"]:
@@ -342,7 +380,7 @@ def main():
             ms = e["ms"] / e["launches"]
             by = e["bytes"] / e["launches"]
             ach = by / (ms * 1e-3) / 1e9
-            line["roofline_env"] = {"kernel": "env_kernel<SELFPLAY> (movegen+select+move+reward+reset, 8192 boards)",
+            line["roofline_env"] = {"kernel": "env_kernel<SELFPLAY> (movegen+select+move+reward+reset, %d boards)" % n_games,
                                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("env_kernel<2>")[0], "avg_launch_ms": ms,
                                     "bytes_per_launch": by, "launches": e["launches"]}
@@ -356,7 +394,7 @@ def main():
                                for k, v in stats.items()}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline()
+                line["cpu_baseline"] = cpu_baseline() if args.config == 2 else cpu_baseline(6.0)
             except Exception as e:           # never lose the measured line to the reporting leg
                 line["cpu_baseline"] = {"value": None, "unit": "env steps/s", "cores": 0, "kind": "port", "sample": "failed: " + str(e)[:160]}
         print(json.dumps(line), flush=True)
