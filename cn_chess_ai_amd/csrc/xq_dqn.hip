@@ -64,6 +64,7 @@ struct xq_dqn {
     int sel_cap = 0;
     bool small_tiles = false;                   // force 64x64 GEMM tiles (<= 80 VGPRs: fits beside the persistent GEMM)
     float* partial = nullptr;                   // row-max partials
+    float* zmax = nullptr;  int* zidx = nullptr;    // [kReduceParts][cap] their reduction per sample (colmax_reduce_kernel)
     float* qsa = nullptr;
     float* yv = nullptr;
     float* lossv = nullptr;
@@ -189,7 +190,49 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
         }
         return *reinterpret_cast<const float4*>(W0T + (long long)row * H + col);
     };
-    if ((H & 3) == 0) {
+    if (BF16 && (H & 7) == 0 && ((H >= 512 && (H & 511) == 0) || (H >= 64 && 512 % H == 0))) {
+        // 16-byte loads (8 bf16 per lane): a 1-KB row needs all 64 lanes; narrower rows are shared out — lane group g takes the
+        // rows i = g (mod G) — and the groups' partial sums are combined by a fixed shuffle tree
+        const int lpr = H >= 512 ? 64 : H / 8;            // lanes per row
+        const int G = 64 / lpr, grp = lane / lpr, lc = lane - grp * lpr;
+        for (int col = lc * 8; col < H; col += 512) {
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            auto add8 = [&](const uint4& x) {
+                a[0] += __builtin_bit_cast(float, x.x << 16); a[1] += __builtin_bit_cast(float, x.x & 0xFFFF0000u);
+                a[2] += __builtin_bit_cast(float, x.y << 16); a[3] += __builtin_bit_cast(float, x.y & 0xFFFF0000u);
+                a[4] += __builtin_bit_cast(float, x.z << 16); a[5] += __builtin_bit_cast(float, x.z & 0xFFFF0000u);
+                a[6] += __builtin_bit_cast(float, x.w << 16); a[7] += __builtin_bit_cast(float, x.w & 0xFFFF0000u);
+            };
+            int i = grp;
+            for (; i + 3 * G < cnt; i += 4 * G) {
+                const uint4 x0 = *reinterpret_cast<const uint4*>(W0B + (long long)rows[wid][i] * H + col);
+                const uint4 x1 = *reinterpret_cast<const uint4*>(W0B + (long long)rows[wid][i + G] * H + col);
+                const uint4 x2 = *reinterpret_cast<const uint4*>(W0B + (long long)rows[wid][i + 2 * G] * H + col);
+                const uint4 x3 = *reinterpret_cast<const uint4*>(W0B + (long long)rows[wid][i + 3 * G] * H + col);
+                add8(x0); add8(x1); add8(x2); add8(x3);
+            }
+            for (; i < cnt; i += G) add8(*reinterpret_cast<const uint4*>(W0B + (long long)rows[wid][i] * H + col));
+            for (int off = lpr; off < 64; off <<= 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] += __shfl_xor(a[k], off, 64);
+            }
+            if (grp == 0) {
+                const float4 ba = *reinterpret_cast<const float4*>(b0 + col), bb = *reinterpret_cast<const float4*>(b0 + col + 4);
+                const float bias[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+                uint16_t qv[8];
+                float tv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { qv[k] = bf16_bits(tanh_fast(a[k] + bias[k])); tv[k] = bf16_to_float(qv[k]); }
+                *reinterpret_cast<uint4*>(out_bf + (long long)b * H + col) =
+                    make_uint4((uint32_t)qv[0] | ((uint32_t)qv[1] << 16), (uint32_t)qv[2] | ((uint32_t)qv[3] << 16),
+                               (uint32_t)qv[4] | ((uint32_t)qv[5] << 16), (uint32_t)qv[6] | ((uint32_t)qv[7] << 16));
+                if (out) {
+                    *reinterpret_cast<float4*>(out + (long long)b * H + col) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+                    *reinterpret_cast<float4*>(out + (long long)b * H + col + 4) = make_float4(tv[4], tv[5], tv[6], tv[7]);
+                }
+            }
+        }
+    } else if ((H & 3) == 0) {
         for (int col = lane * 4; col < H; col += 256) {
             float4 acc = *reinterpret_cast<const float4*>(b0 + col);
             int i = 0;
@@ -340,9 +383,69 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
     }
 }
 
+// zmax[b] = max over the column-max GEMM's partial rows t of partial[t][b] (and, for Double DQN, the row index that came with
+// the first maximum).  The partials are [n_partial][n]: a block takes 64 consecutive samples so that every wave-instruction reads
+// 256 contiguous bytes of one partial row (td_delta_kernel's one-wave-per-sample walk touched a cache line per value); wave w
+// folds rows w, w+4, ... with 8 independent loads in flight, the four waves combine through LDS.
+// blockIdx.y = one of kReduceParts contiguous ranges of partial rows (4x the blocks in flight: the kernel is pure latency);
+// zmax / zidx are [kReduceParts][n], td_delta_kernel folds the last kReduceParts values of its sample itself.
+enum { kReduceParts = 4 };
+__global__ __launch_bounds__(256) void colmax_reduce_kernel(const float* __restrict__ partial_all, const int* __restrict__ partial_idx_all,
+                                                            int n_partial_all, int n, float* __restrict__ zmax_all, int* __restrict__ zidx_all) {
+    const int per = (n_partial_all + kReduceParts - 1) / kReduceParts;
+    const int t0 = (int)blockIdx.y * per;
+    const int n_partial = max(0, min(per, n_partial_all - t0));
+    const float* partial = partial_all + (long long)t0 * n;
+    const int* partial_idx = partial_idx_all ? partial_idx_all + (long long)t0 * n : nullptr;
+    float* zmax = zmax_all + (long long)blockIdx.y * n;
+    int* zidx = zidx_all + (long long)blockIdx.y * n;
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int lane = (int)(threadIdx.x & 63), wid = (int)(threadIdx.x >> 6);
+    const int b = (int)blockIdx.x * 64 + lane;
+    const bool ok = b < n;
+    float m = -__builtin_inff();
+    int mi = 0x7fffffff;
+    const bool arg = partial_idx != nullptr;
+    int t = wid;
+    for (; t + 28 < n_partial; t += 32) {
+        float v[8];
+        int vi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u] = ok ? partial[(long long)(t + 4 * u) * n + b] : -__builtin_inff();
+            vi[u] = (ok && arg) ? partial_idx[(long long)(t + 4 * u) * n + b] : 0x7fffffff;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (arg) { if (v[u] > m || (v[u] == m && vi[u] < mi)) { m = v[u]; mi = vi[u]; } }
+            else m = fmaxf(m, v[u]);
+        }
+    }
+    for (; t < n_partial; t += 4) {
+        const float v = ok ? partial[(long long)t * n + b] : -__builtin_inff();
+        const int vi = (ok && arg) ? partial_idx[(long long)t * n + b] : 0x7fffffff;
+        if (arg) { if (v > m || (v == m && vi < mi)) { m = v; mi = vi; } }
+        else m = fmaxf(m, v);
+    }
+    sv[wid][lane] = m; si[wid][lane] = mi;
+    __syncthreads();
+    if (wid == 0 && ok) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float v = sv[w][lane];
+            const int vi = si[w][lane];
+            if (arg) { if (v > m || (v == m && vi < mi)) { m = v; mi = vi; } }
+            else m = fmaxf(m, v);
+        }
+        zmax[b] = m;
+        if (arg) zidx[b] = mi;
+    }
+}
+
 // What the generalised TD step (BASELINE configs[4], build-defined) adds to td_delta_kernel; all optional.
 struct TdExtra {
-    const int* partial_idx;        // Double DQN: row index of each column-max partial (first maximum)
+    const int* partial_idx;        // Double DQN: row index of the maximum of every sample (first maximum), reduced
     const float* wout_t; const uint16_t* wout_t_bf; const float* bout_t;   // target net's output layer (fp32 master / bf16 shadow)
     const float* alast_t; const uint16_t* alast_t_bf;                      // a_last(s') of the target net (fp32 / bf16 bits)
     const uint16_t* wout_bf;       // bf16 Q-net: shadow of the online output layer for Q(s,a)
@@ -385,22 +488,14 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
         z += b_out[a];
-        float zm = -__builtin_inff();
-        int zi = 0x7fffffff;
-        for (int t = lane; t < n_partial; t += 64) {
+        float zm = partial[b];                         // max_k z_k(s'): the kReduceParts values colmax_reduce_kernel left per sample
+        int zi = X.double_dqn ? X.partial_idx[b] : 0;
+        for (int t = 1; t < n_partial; ++t) {
             const float v = partial[(long long)t * n + b];
             if (X.double_dqn) {
                 const int vi = X.partial_idx[(long long)t * n + b];
                 if (v > zm || (v == zm && vi < zi)) { zm = v; zi = vi; }
             } else zm = fmaxf(zm, v);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(zm, off, 64);
-            if (X.double_dqn) {
-                const int oi = __shfl_xor(zi, off, 64);
-                if (ov > zm || (ov == zm && oi < zi)) { zm = ov; zi = oi; }
-            } else zm = fmaxf(zm, ov);
         }
         if (X.double_dqn) {          // value of the online net's greedy action on the TARGET net
             const int astar = (zi >= 0 && zi < X.nout) ? zi : 0;
@@ -438,7 +533,10 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
         if (X.prio && live) {
             const float p = powf(fabsf(q - y) + X.per_eps, X.per_alpha);
             X.prio[s] = p;
-            atomicMax(X.pmax_live, __float_as_uint(p));          // positive floats order like their bit patterns
+            // the running maximum rarely moves once training is under way: test first, so that 16 K waves do not queue on one address
+            // (positive floats order like their bit patterns; a maximum is order-independent, hence still deterministic)
+            if (__float_as_uint(p) > __hip_atomic_load(X.pmax_live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(X.pmax_live, __float_as_uint(p));
         }
     }
 }
@@ -739,9 +837,10 @@ static int ensure_capacity(xq_dqn* d, int n) {
         XQ_HIP(hipMemsetAsync(d->tacts[i], 0, rows * (size_t)maxh * sizeof(float), d->stream));
     }
     const int ntn = (d->nout() + 63) / 64;             // column-max partials: 2 per 64- or 128-row tile
-    float** bufs[] = {&d->q90, &d->partial, &d->qsa, &d->yv, &d->lossv, &d->dsc, reinterpret_cast<float**>(&d->act_mb)};
-    const size_t sizes[] = {cap * 96, cap * (size_t)ntn * 2, cap, cap, cap, cap, cap};
-    for (int i = 0; i < 7; ++i) {
+    float** bufs[] = {&d->q90, &d->partial, &d->qsa, &d->yv, &d->lossv, &d->dsc, reinterpret_cast<float**>(&d->act_mb), &d->zmax,
+                      reinterpret_cast<float**>(&d->zidx)};
+    const size_t sizes[] = {cap * 96, cap * (size_t)ntn * 2, cap, cap, cap, cap, cap, cap * kReduceParts, cap * kReduceParts};
+    for (int i = 0; i < 9; ++i) {
         if (*bufs[i]) XQ_HIP(hipFree(*bufs[i]));
         XQ_HIP(hipMalloc(bufs[i], sizes[i] * sizeof(float)));
     }
@@ -1174,7 +1273,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     hipStreamSynchronize(d->stream);
     for (int i = 0; i < 2; ++i) { hipFree(d->params[i]); hipFree(d->tacts[i]); }
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts[l]); hipFree(d->deltas[l]); hipFree(d->sel_acts[l]); }
-    hipFree(d->gboards); hipFree(d->dsc); hipFree(d->act_mb); hipFree(d->q90); hipFree(d->sel_q90); hipFree(d->partial); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
+    hipFree(d->gboards); hipFree(d->dsc); hipFree(d->act_mb); hipFree(d->q90); hipFree(d->sel_q90); hipFree(d->partial); hipFree(d->zmax); hipFree(d->zidx); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
     hipFree(d->grads_td); hipFree(d->grads_full); hipFree(d->slabs); hipFree(d->bias_work); hipFree(d->xdense); hipFree(d->qfull); hipFree(d->tfull);
     hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
     d->prof.collect();
@@ -1529,6 +1628,12 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         }
     }
     XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
+    {   // the partial maxima of every sample folded into kReduceParts values (+ row indices): coalesced, block-cooperative
+        ProfScope ps(d, "colmax_reduce", (double)n * n_partial, (dbl ? 8.0 : 4.0) * n * (n_partial + kReduceParts));
+        hipLaunchKernelGGL(colmax_reduce_kernel, dim3((n + 63) / 64, kReduceParts), dim3(256), 0, d->cur, d->partial,
+                           dbl ? d->partial_idx : nullptr, n_partial, n, d->zmax, d->zidx);
+        XQ_HIP(hipGetLastError());
+    }
     // 3. Q(s, a), target, the scalar output delta and the delta of the last hidden layer (one launch, no GEMM)
     {
         const int lt = nl - 2;                               // last hidden layer
@@ -1539,7 +1644,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         TdExtra X; memset(&X, 0, sizeof X);
         X.nout = NO;
         if (dbl) {
-            X.double_dqn = 1; X.partial_idx = d->partial_idx;
+            X.double_dqn = 1; X.partial_idx = d->zidx;
             X.bout_t = d->bl(XQ_NET_TARGET, nl - 1);
             if (bf) { X.wout_t_bf = d->wl_bf(XQ_NET_TARGET, nl - 1); X.alast_t_bf = t2outs_bf[nl - 2]; }
             else { X.wout_t = d->wl(XQ_NET_TARGET, nl - 1); X.alast_t = t2outs[nl - 2]; }
@@ -1550,7 +1655,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             X.per_eps = per->eps; X.per_alpha = per->alpha;
         }
         hipLaunchKernelGGL(td_delta_kernel, dim3((n + 3) / 4), dim3(256), 0, d->cur, n, slots, action_to, reward, done,
-                           outs[nl - 2], Hl, d->wl(XQ_NET_ONLINE, nl - 1), d->bl(XQ_NET_ONLINE, nl - 1), d->partial, n_partial,
+                           outs[nl - 2], Hl, d->wl(XQ_NET_ONLINE, nl - 1), d->bl(XQ_NET_ONLINE, nl - 1), d->zmax, kReduceParts,
                            (float)d->gamma, view, view_ld, view_kmax, d->deltas[lt], d->dsc, d->act_mb, d->qsa, d->yv, d->lossv, X);
         XQ_HIP(hipGetLastError());
     }

@@ -34,6 +34,10 @@ enum { DT_F32 = 0, DT_BF16 = 1 };     // operand element type (accumulation is f
 __device__ __forceinline__ float bf16_round(float v) { return (float)(__bf16)v; }                       // RNE, v_cvt_pk_bf16_f32
 __device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
 __device__ __forceinline__ float bf16_to_float(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+// tanh for values that are rounded to bf16 right away (hidden activations of the bf16 Q-net): 1 - 2 / (1 + e^2x) on the hardware
+// exp and reciprocal — absolute error ~1e-7, far below half a bf16 ulp except for |x| < 1e-4 where it cannot matter; tanhf costs
+// ~40 instructions per value, which the bf16 MFMA no longer hides (the fp32 epilogues keep tanhf)
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 
 enum { L_KCONTIG = 0, L_MCONTIG = 1 };
 // EPI_COLMAX: per column n, max over the rows m of (acc + bias[m]) — the GEMM is launched "transposed" (rows = output
@@ -352,6 +356,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if (DT == DT_BF16 && EPI == EPI_BIAS_TANH) {
         // bf16 Q-net: a = bf16(tanh(acc + bias)); the bf16 bits feed the next layer's MFMA, the (optional) fp32 copy of the
         // SAME rounded value feeds the fp32 backward pass
+        if (g.Cb != nullptr && (m0 + BM <= g.M) && (n0 + BN <= g.N) && (g.ldcb & 7) == 0) {
+            // interior tile: the accumulator layout gives every lane ONE column (2-byte global stores, 64 of them per lane);
+            // instead each wave transposes its (32 TM) x (32 TN) sub-tile through the now idle operand LDS and stores whole
+            // 16-byte pieces of rows
+            constexpr int WR = 32 * TM, WC = 32 * TN, S = WC + 8;                // per-wave image [WR][S] bf16, conflict-free stride
+            __syncthreads();                                                     // every wave is done with As / Bs
+            uint16_t* stage = reinterpret_cast<uint16_t*>(wid < 2 ? As : Bs) + (wid & 1) * WR * S;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WC + j * 32 + r;
+                    const float bias = g.bias[n];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                        const __bf16 rb = (__bf16)tanh_fast(acc[i][j][q] + bias);
+                        stage[row * S + j * 32 + r] = __builtin_bit_cast(uint16_t, rb);
+                        if (Cz) Cz[(long long)(m0 + wm * WR + row) * g.ldc + n] = (float)rb;
+                    }
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            constexpr int PPR = WC / 8;                                          // 16-byte pieces per row
+#pragma unroll
+            for (int c = lane; c < WR * PPR; c += 64) {
+                const int row = c / PPR, part = c % PPR;
+                const uint4 x = *reinterpret_cast<const uint4*>(stage + row * S + part * 8);
+                *reinterpret_cast<uint4*>(g.Cb + (long long)(m0 + wm * WR + row) * g.ldcb + n0 + wn * WC + part * 8) = x;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -363,7 +400,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 for (int q = 0; q < 16; ++q) {
                     const int m = m0 + wm * 32 * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                     if (m >= g.M) continue;
-                    float v = tanhf(acc[i][j][q] + bias);
+                    float v = g.Cb ? tanh_fast(acc[i][j][q] + bias) : tanhf(acc[i][j][q] + bias);
                     if (g.Cb) {                                  // hidden layer: rounded; the Q head (no Cb) stays fp32
                         const __bf16 rb = (__bf16)v;
                         g.Cb[(long long)m * g.ldcb + n] = __builtin_bit_cast(uint16_t, rb);

@@ -120,7 +120,11 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerTree T, int batch, u
     const float w = powf((float)scalars[3] * prob, -beta);
     slots[k] = node;
     is_w[k] = w;
-    atomicMax(&scalars[2], __float_as_uint(w));
+    // batch maximum: one atomic per wave, not per sample (order-independent, so still reproducible)
+    float wm = w;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&scalars[2], __float_as_uint(wm));
 }
 
 static PerTree per_tree(const xq_replay* r) {

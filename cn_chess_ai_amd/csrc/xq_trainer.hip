@@ -32,6 +32,10 @@ struct xq_trainer {
     int excluded = 0;                       // ring slots the queued learn_grads left out of its minibatch (from write_pos - inflight)
     hipEvent_t ev_grads = nullptr;          // main: the queued learn_grads has finished reading the ring
     bool per_ready = false;                 // prioritized replay: the sum tree holds the ring as of the last learn_apply
+    // an event record costs the recording stream ~6 us (rocprofv3 trace): ev_params / ev_grads are only recorded when a collect
+    // actually has to wait for them (collect-first or mixed call orders), not on every iteration of the learn_grads -> collect loop
+    bool params_event_stale = true;         // ev_params has not been recorded since the last parameter update
+    bool grads_event_stale = true;          // ev_grads has not been recorded since the queued learn_grads
 };
 
 using namespace xq;
@@ -85,6 +89,7 @@ static int trainer_init(xq_trainer* t, const xq_trainer_config* cfg, void* hip_s
         XQ_HIP(hipEventCreateWithFlags(&t->ev_collect, hipEventDisableTiming));
         XQ_HIP(hipEventCreateWithFlags(&t->ev_grads, hipEventDisableTiming));
         XQ_HIP(hipEventRecord(t->ev_params, t->stream));      // orders the first collect after the handles' initialisation
+        t->params_event_stale = false;
     }
     return XQ_OK;
 }
@@ -115,11 +120,19 @@ static int collect_impl(xq_trainer* t) {
     hipStream_t on = nullptr;
     if (t->cstream) {
         on = t->cstream;
-        if (t->inflight == 0) XQ_HIP(hipStreamWaitEvent(on, t->ev_params, 0));
-        if (t->grads_queued && t->inflight == 0) XQ_HIP(hipStreamWaitEvent(on, dqn_qmax_event(t->dqn), 0));
+        if (t->grads_queued) {
+            // queued behind the column-max GEMM (which wants the chip to itself); that event lies behind every parameter update
+            if (t->inflight == 0) XQ_HIP(hipStreamWaitEvent(on, dqn_qmax_event(t->dqn), 0));
+        } else if (t->inflight == 0) {
+            if (t->params_event_stale) { XQ_HIP(hipEventRecord(t->ev_params, t->stream)); t->params_event_stale = false; }
+            XQ_HIP(hipStreamWaitEvent(on, t->ev_params, 0));
+        }
         // more plies than the queued learn_grads excluded from its minibatch (caller mixed the orders): these slots may be
         // among the ones it samples, so they can only be overwritten once it has read them
-        if (t->grads_queued && t->inflight + t->env->n > t->excluded) XQ_HIP(hipStreamWaitEvent(on, t->ev_grads, 0));
+        if (t->grads_queued && t->inflight + t->env->n > t->excluded) {
+            if (t->grads_event_stale) { XQ_HIP(hipEventRecord(t->ev_grads, t->stream)); t->grads_event_stale = false; }
+            XQ_HIP(hipStreamWaitEvent(on, t->ev_grads, 0));
+        }
     }
     hipStream_t s = on ? on : t->stream;
     XQ_TRY(dqn_q90_boards(t->dqn, t->env->boards, t->env->n, &q90, &stride, on));
@@ -163,7 +176,7 @@ int xq_trainer_random_plies(xq_trainer* t, int n_plies) {
     if (!t || n_plies < 0) return fail(XQ_ERR_INVALID_ARGUMENT, "bad argument");
     if (t->inflight > 0 || t->grads_queued) return fail(XQ_ERR_RUNTIME, "xq_trainer_random_plies: call between iterations (after learn_apply)");
     for (int i = 0; i < n_plies; ++i) XQ_TRY(env_selfplay_launch(t->env, nullptr, 0, 0u, nullptr, nullptr, t->stream));
-    if (t->cstream) XQ_HIP(hipEventRecord(t->ev_params, t->stream));     // the next collect (own stream) starts behind these plies
+    t->params_event_stale = true;                // the next collect (own stream) starts behind these plies
     return XQ_OK;
 }
 
@@ -187,7 +200,7 @@ static int learn_grads_prioritized(xq_trainer* t) {
     }
     XQ_TRY(replay_per_sample(t->replay, t->cfg.minibatch, t->stream));
     XQ_TRY(xq_dqn_td_grads_replay(t->dqn, t->replay, t->cfg.minibatch, t->cfg.td_net, t->cfg.backprop_mode));
-    if (t->cstream) XQ_HIP(hipEventRecord(t->ev_grads, t->stream));
+    t->grads_event_stale = true;
     t->grads_queued = true;
     return XQ_OK;
 }
@@ -227,7 +240,7 @@ int xq_trainer_learn_grads(xq_trainer* t) {
         XQ_TRY(replay_sample_implicit(t->replay, batch, start, count));     // no sampling kernel: the consumers recompute the slots
     }
     XQ_TRY(xq_dqn_td_grads_replay(t->dqn, t->replay, batch, t->cfg.td_net, t->cfg.backprop_mode));
-    if (t->cstream) XQ_HIP(hipEventRecord(t->ev_grads, t->stream));
+    t->grads_event_stale = true;
     t->grads_queued = true;
     return XQ_OK;
 }
@@ -251,10 +264,8 @@ int xq_trainer_learn_apply(xq_trainer* t, int world_size) {
         XQ_TRY(replay_per_rebuild(t->replay, r->write_pos, full ? std::min(m, r->dev.capacity) : 0, t->stream));
         t->per_ready = true;
     }
-    if (t->cstream) {
-        XQ_HIP(hipEventRecord(t->ev_params, t->stream));
-        t->inflight = 0;
-    }
+    t->params_event_stale = true;
+    t->inflight = 0;
     t->grads_queued = false;
     return XQ_OK;
 }
