@@ -42,10 +42,22 @@ struct EnvParams {
 
 __constant__ uint32_t c_start_words[kBoardWords];
 
+// meta.x = moveCount | player << 16 | flags.  META_TRACKED: the scores account for every piece missing from the board (own
+// material = 1480 - the other side's score) and each living general stands in its own palace — true from the start position on and
+// preserved by every move (movePiece credits the victim's value, chessboard.cpp:51-58; a general cannot leave its palace,
+// :328-343), re-checked by xq_env_set_state.  Then evaluateBoard (chessai.cpp:311-345), checkGameOver and getWinner
+// (chessboard.cpp:286-320) need no scan of the 90 squares: score(mover) = own score - other score, a general dies only by capture,
+// and the first general in index order is Red's while it lives.
+enum : uint32_t { META_TRACKED = 1u << 17, META_RED_GENERAL = 1u << 18, META_BLACK_GENERAL = 1u << 19,
+                  META_START = META_TRACKED | META_RED_GENERAL | META_BLACK_GENERAL };
+constexpr int kSideMaterial = 1000 + 2 * 20 + 2 * 20 + 2 * 40 + 2 * 90 + 2 * 45 + 5 * 10;      // 1480, chessboard.h:23-31
+
 template <int MODE>
 __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
     __shared__ WaveSlab slabs[4];
-    const int wid = (int)(threadIdx.x >> 6);
+    // everything per game is wave-uniform: keeping the wave index, the game index and the meta record in SGPRs lets the compiler
+    // run the bookkeeping and all ten Philox rounds on the scalar unit instead of on 64 identical lanes
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = lane_id();
     const int g = (int)blockIdx.x * 4 + wid;
     const bool active = g < P.n_games;
@@ -57,11 +69,14 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
         if (lane < kBoardWords) word = P.boards[(size_t)g * kBoardWords + lane];
         m = P.meta[g];
     }
+    m.x = __builtin_amdgcn_readfirstlane(m.x); m.y = __builtin_amdgcn_readfirstlane(m.y);
+    m.z = __builtin_amdgcn_readfirstlane(m.z); m.w = __builtin_amdgcn_readfirstlane(m.w);
     unpack_to_slab(word, S.sq);
     wave_sync();
 
     int move_count = (int)(m.x & 0xFFFFu);
     int player = (int)((m.x >> 16) & 1u);
+    uint32_t flags = m.x & (META_TRACKED | META_RED_GENERAL | META_BLACK_GENERAL);
     int red = (int)(m.y & 0xFFFFu), black = (int)(m.y >> 16);
     uint32_t plies = m.z, episodes = m.w;
 
@@ -112,7 +127,7 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
                     idx = b ? (__ffsll((long long)b) - 1) : 0;                 // all -inf: validActions[0] (dqn.cpp:40)
                 }
             }
-            action_code = (int)S.moves[idx];
+            action_code = __builtin_amdgcn_readfirstlane((int)S.moves[idx]);
             from = action_code / 90;
             to = action_code - from * 90;
             have_action = true;
@@ -132,8 +147,8 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
     // ---- movePiece (chessboard.cpp:38-64) -------------------------------------------------------------------
     int captured = 0;
     if (valid) {
-        const int moving = S.sq[from];
-        captured = S.sq[to];
+        const int moving = __builtin_amdgcn_readfirstlane((int)S.sq[from]);
+        captured = __builtin_amdgcn_readfirstlane((int)S.sq[to]);
         wave_sync();
         if (lane == 0) {
             S.sq[to] = (uint8_t)moving;
@@ -143,6 +158,8 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
         if (captured != 0) {
             const int sc = piece_value(captured);
             if (captured <= 7) black += sc; else red += sc;        // credited by the VICTIM's colour (:51-58)
+            if (captured == 1) flags &= ~META_RED_GENERAL;
+            if (captured == 8) flags &= ~META_BLACK_GENERAL;
         }
         move_count += 1;
         player ^= 1;
@@ -150,9 +167,25 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
     }
 
     // ---- reward, terminal test (chessai.cpp:115-119) ------------------------------------------------------------
-    const int reward = evaluate_board_wave(S.sq, mover, move_count);
-    const BoardStatus st = board_status_wave(S.sq);
-    const bool over = move_count >= 200 || !st.red_general || !st.black_general;   // chessboard.cpp:286-309
+    int reward, winner_now;
+    bool red_general, black_general;
+    if (flags & META_TRACKED) {          // no board scan: see META_TRACKED
+        const int score = mover == C_RED ? red - black : black - red;      // (1480 - lost own) - (1480 - lost enemy)
+        {
+#pragma clang fp contract(off)
+            const double pen = __dmul_rn((double)move_count, 0.1);         // `score -= moveCount * 0.1` on an int, chessai.cpp:342
+            reward = (int)__dsub_rn((double)score, pen);
+        }
+        red_general = (flags & META_RED_GENERAL) != 0;
+        black_general = (flags & META_BLACK_GENERAL) != 0;
+        winner_now = red_general ? C_RED : (black_general ? C_BLACK : C_NONE);
+    } else {
+        reward = evaluate_board_wave(S.sq, mover, move_count);
+        const BoardStatus st = board_status_wave(S.sq);
+        red_general = st.red_general; black_general = st.black_general;
+        winner_now = st.first_general_color;
+    }
+    const bool over = move_count >= 200 || !red_general || !black_general;         // chessboard.cpp:286-309
     const bool no_action = (MODE == MODE_SELFPLAY) && !have_action;                 // chessai.cpp:100-103
     const bool done = over || no_action || (move_count + 1 >= 200);
     const bool terminated = over || no_action;
@@ -160,7 +193,7 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
     // checkGameOver() probe, a retried step) reports `terminated` but changes nothing: no stats, no episode record, no reset
     const bool ended_now = terminated && (MODE == MODE_SELFPLAY || valid);
     const bool do_reset = ended_now && (MODE == MODE_SELFPLAY || P.auto_reset != 0);
-    const int winner = terminated ? st.first_general_color : C_NONE;
+    const int winner = terminated ? winner_now : C_NONE;
 
     const uint32_t next_word = pack_from_slab(S.sq);               // s' = board after the move, before any reset
 
@@ -224,11 +257,12 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
     if (do_reset) {                                                 // board->reset(), chessai.cpp:90
         out_word = lane < kBoardWords ? c_start_words[lane] : 0u;
         move_count = 0; player = C_RED; red = 0; black = 0;
+        flags = META_START;
         episodes += 1;
     }
     if (lane < kBoardWords) P.boards[(size_t)g * kBoardWords + lane] = out_word;
     if (lane == 0)
-        P.meta[g] = make_uint4((uint32_t)move_count | ((uint32_t)player << 16), (uint32_t)red | ((uint32_t)black << 16),
+        P.meta[g] = make_uint4((uint32_t)move_count | ((uint32_t)player << 16) | flags, (uint32_t)red | ((uint32_t)black << 16),
                                plies, episodes);
 }
 
@@ -287,7 +321,7 @@ __global__ void fill_start_kernel(uint32_t* boards, uint4* meta, uint4* stats, i
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i < n * kBoardWords) boards[i] = c_start_words[i % kBoardWords];
     if (i < n) {
-        meta[i] = make_uint4(0, 0, 0, 0);
+        meta[i] = make_uint4(META_START, 0, 0, 0);
         stats[i] = make_uint4(0, 0, 0, 0);
     }
 }
@@ -460,7 +494,25 @@ int xq_env_set_state(xq_env* e, int first, int n, const uint8_t* boards90, const
             mc = (uint32_t)meta4[i * 4 + 0] & 0xFFFFu; pl = (uint32_t)meta4[i * 4 + 1] & 1u;
             rs = (uint32_t)meta4[i * 4 + 2] & 0xFFFFu; bs = (uint32_t)meta4[i * 4 + 3] & 0xFFFFu;
         }
-        meta[i] = make_uint4(mc | (pl << 16), rs | (bs << 16), 0, 0);
+        // META_TRACKED when the scores explain the missing material and the generals (if alive) stand in their own palaces
+        int mat[2] = {0, 0}, gen_n[2] = {0, 0};
+        bool gen_home = true;
+        for (int s = 0; s < kSquares; ++s) {
+            const int c = boards90[(size_t)i * 90 + s];
+            if (c == 0) continue;
+            const int side = c > 7 ? 1 : 0, t = code_type(c);
+            static const int value[8] = {0, 1000, 20, 20, 40, 90, 45, 10};
+            mat[side] += value[t];
+            if (t == T_GENERAL) {
+                gen_n[side] += 1;
+                const int r = s / 9, col = s % 9;
+                gen_home = gen_home && col >= 3 && col <= 5 && (side == 0 ? r <= 2 : r >= 7);
+            }
+        }
+        uint32_t fl = 0;
+        if (gen_home && gen_n[0] <= 1 && gen_n[1] <= 1 && mat[0] == kSideMaterial - (int)bs && mat[1] == kSideMaterial - (int)rs)
+            fl = META_TRACKED | (gen_n[0] ? META_RED_GENERAL : 0u) | (gen_n[1] ? META_BLACK_GENERAL : 0u);
+        meta[i] = make_uint4(mc | (pl << 16) | fl, rs | (bs << 16), 0, 0);
     }
     XQ_HIP(hipStreamSynchronize(e->stream));
     // keep the per-slot RNG counter and episode count

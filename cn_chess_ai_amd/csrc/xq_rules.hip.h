@@ -86,20 +86,24 @@ __device__ inline bool is_valid_move(const uint8_t* sq, int fr, int fc, int tr, 
     return piece_rule(sq, code_type(f), fr, fc, tr, tc);
 }
 
-// inclusive wave prefix sum over 64 lanes
-__device__ __forceinline__ int wave_inclusive_scan(int v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
+// Cross-lane sums / maxima on the DPP network (row_shr 1,2,4,8 inside each row of 16 lanes, then row_bcast 15 / 31 across the
+// rows): 6 VALU instructions per scan, against 6 x (ds_bpermute + select + add) for the shuffle form.  Lanes whose DPP source
+// lies outside the row (or the row mask) receive the `old` operand: the identity of the operation.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_int(int identity, int v) {
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_inclusive_scan(int v) {           // inclusive prefix sum over the 64 lanes
+    v += dpp_int<0x111, 0xf>(0, v);      // row_shr:1
+    v += dpp_int<0x112, 0xf>(0, v);      // row_shr:2
+    v += dpp_int<0x114, 0xf>(0, v);      // row_shr:4
+    v += dpp_int<0x118, 0xf>(0, v);      // row_shr:8
+    v += dpp_int<0x142, 0xa>(0, v);      // row_bcast:15 into rows 1 and 3
+    v += dpp_int<0x143, 0xc>(0, v);      // row_bcast:31 into rows 2 and 3
     return v;
 }
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+__device__ __forceinline__ int wave_sum(int v) {                      // total, wave-uniform (lane 63 of the scan)
+    return __builtin_amdgcn_readlane(wave_inclusive_scan(v), 63);
 }
 // Orders LDS traffic between the lanes of ONE wave (each wave owns its slab; the LDS pipeline is in-order per wave):
 // a compiler + counter fence, no s_barrier, so it is legal inside wave-divergent control flow.
@@ -108,10 +112,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+__device__ __forceinline__ float wave_max(float v) {                  // maximum over the 64 lanes, wave-uniform
+    const int ninf = __float_as_int(-__builtin_inff());
+    auto step = [&](int t) { v = fmaxf(v, __int_as_float(t)); };
+    step(dpp_int<0x111, 0xf>(ninf, __float_as_int(v)));
+    step(dpp_int<0x112, 0xf>(ninf, __float_as_int(v)));
+    step(dpp_int<0x114, 0xf>(ninf, __float_as_int(v)));
+    step(dpp_int<0x118, 0xf>(ninf, __float_as_int(v)));
+    step(dpp_int<0x142, 0xa>(ninf, __float_as_int(v)));
+    step(dpp_int<0x143, 0xc>(ninf, __float_as_int(v)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Unpack 12 words (lanes 0..11) into the slab's byte board.  Caller synchronises afterwards.
@@ -144,10 +154,10 @@ __device__ __forceinline__ uint32_t pack_from_slab(const uint8_t* sq) {   // val
 // 90-bit board masks as two 64-bit words (bits 0..63 / 64..89)
 struct Mask90 { unsigned long long lo, hi; };
 __device__ __forceinline__ unsigned bits_at(const Mask90& m, int pos, unsigned mask) {   // bits [pos, pos+len) of the mask
-    unsigned long long v;
-    if (pos >= 64) v = m.hi >> (pos - 64);
-    else v = (m.lo >> pos) | (pos ? (m.hi << (64 - pos)) : 0ull);
-    return (unsigned)v & mask;
+    // branch-free: both halves are formed and one is selected ((hi << 1) << (63 - pos) is hi << (64 - pos), and 0 for pos = 0)
+    const unsigned long long a = (m.lo >> (pos & 63)) | ((m.hi << 1) << (63 - (pos & 63)));
+    const unsigned long long b = m.hi >> (pos & 63);
+    return (unsigned)(pos >= 64 ? b : a) & mask;
 }
 
 // One ray of a chariot / cannon resolved with bit operations on the line's occupancy (`line`: bit i = square i of the
@@ -155,24 +165,22 @@ __device__ __forceinline__ unsigned bits_at(const Mask90& m, int pos, unsigned m
 //   empties : empty squares before the first piece (chariot and cannon both emit them, chessboard.cpp:205-216/228-232)
 //   first   : index of the first piece or -1      (chariot: capturable iff enemy, then stop)
 //   second  : index of the next piece behind it or -1 (cannon: capturable iff enemy, chessboard.cpp:235-240)
+// A backward ray is the forward ray of the mirrored line (v_bfrev), so there is ONE scan and no divergent branch; the
+// indices are mirrored back at the end.
 struct RayHit { int empties, first, second; };
 __device__ __forceinline__ RayHit ray_scan(unsigned line, int pos, int len, bool forward) {
+    const unsigned l = forward ? line : (__brev(line) >> (32 - len));
+    const int p = forward ? pos : len - 1 - pos;
+    const unsigned x = l >> (p + 1);
+    const int e = __ffs((int)x) - 1;                       // -1 when the ray is empty
+    const unsigned y = x >> ((e + 1) & 31);                // e = -1: y = x = 0
+    const int e2 = __ffs((int)y) - 1;
+    int first = x ? p + 1 + e : -1;
+    int second = (x && y) ? p + 2 + e + e2 : -1;
     RayHit h;
-    if (forward) {
-        const unsigned x = line >> (pos + 1);
-        if (x == 0) { h.empties = len - 1 - pos; h.first = -1; h.second = -1; return h; }
-        const int e = __ffs((int)x) - 1;
-        h.empties = e; h.first = pos + 1 + e;
-        const unsigned y = x >> (e + 1);
-        h.second = y ? h.first + 1 + (__ffs((int)y) - 1) : -1;
-    } else {
-        const unsigned x = line & ((1u << pos) - 1u);
-        if (x == 0) { h.empties = pos; h.first = -1; h.second = -1; return h; }
-        const int f = 31 - __clz((int)x);
-        h.empties = pos - 1 - f; h.first = f;
-        const unsigned y = x & ((1u << f) - 1u);
-        h.second = y ? 31 - __clz((int)y) : -1;
-    }
+    h.empties = x ? e : len - 1 - p;
+    h.first = (first >= 0 && !forward) ? len - 1 - first : first;
+    h.second = (second >= 0 && !forward) ? len - 1 - second : second;
     return h;
 }
 
@@ -217,89 +225,75 @@ __device__ inline int gen_all_actions(WaveSlab& slab, int player) {
     for (int pass = 0; pass < 2; ++pass) {
         if (pass * 8 >= n_own) break;                      // wave-uniform
         const int k = pass * 8 + (lane >> 3), slot = lane & 7;
-        int n_run = 0, t0 = 0, delta = 0, extra = -1, from = 0;
-        if (k < n_own && k < 16) {
-            from = rank_sq[k];
-            const int p = sq[from];
-            const int row = from / 9, col = from - row * 9;
-            const int type = p > 7 ? p - 7 : p;
-            if (type == T_CHARIOT || type == T_CANNON) {
-                if (slot < 4) {                            // right, left, +row, -row (chessboard.cpp:199 / :221)
-                    const bool horiz = slot < 2, fwd = (slot & 1) == 0;
-                    const unsigned line = horiz ? bits_at(occ, row * 9, 0x1FFu) : bits_at(occT, col * 10, 0x3FFu);
-                    const int pos = horiz ? col : row, len = horiz ? 9 : 10;
-                    const RayHit h = ray_scan(line, pos, len, fwd);
-                    delta = horiz ? (fwd ? 1 : -1) : (fwd ? 9 : -9);
-                    t0 = from + delta;
-                    n_run = h.empties;
-                    if (type == T_CHARIOT) {
-                        if (h.first >= 0) {
-                            const int bs = horiz ? row * 9 + h.first : h.first * 9 + col;
-                            if ((sq[bs] > 7) != black) n_run += 1;         // enemy blocker: captured, it is the next square
-                        }
-                    } else if (h.second >= 0) {
-                        const int bs = horiz ? row * 9 + h.second : h.second * 9 + col;
-                        if ((sq[bs] > 7) != black) extra = bs;             // first piece behind the screen, iff enemy
-                    }
+        const bool active = k < n_own;                     // n_own <= 16
+        // Every lane evaluates its (piece, direction) slot with selects instead of a switch over the piece type: the seven
+        // case bodies of a switch all execute anyway (a wave mixes piece types) and each costs an exec-mask save / restore /
+        // branch on the scalar unit.  Inactive lanes compute on piece 0 and are masked at the end.
+        const int from = rank_sq[active ? k : 0];
+        const int p = sq[from];
+        const int row = (from * 57) >> 9, col = from - row * 9;               // from / 9 for from < 96
+        const int type = p > 7 ? p - 7 : p;
+        const bool isG = type == T_GENERAL, isA = type == T_ADVISOR, isE = type == T_ELEPHANT, isH = type == T_HORSE;
+        const bool isS = type == T_SOLDIER, isRay = type == T_CHARIOT || type == T_CANNON;
+        const bool lt4 = slot < 4, lt2 = slot < 2;
+        const int sg1 = (slot & 1) ? -1 : 1, sg2 = (slot & 2) ? -1 : 1;
+        const int fw = black ? -1 : 1;
+        const bool crossed = black ? row < 5 : row > 4;
+        // direction tables of chessboard.cpp:150 / :163 / :180 / :249 / :265-283, in generator order
+        const int mag = isE ? 2 : 1;
+        int dr = lt2 ? mag : -mag, dc = sg1 * mag;                             // advisor / elephant: (m,m) (m,-m) (-m,m) (-m,-m)
+        if (isG) { dr = lt2 ? sg1 : 0; dc = lt2 ? 0 : sg1; }                   // (1,0) (-1,0) (0,1) (0,-1)
+        if (isH) { dr = lt4 ? sg2 : 2 * sg2; dc = lt4 ? 2 * sg1 : sg1; }       // (1,2)(1,-2)(-1,2)(-1,-2)(2,1)(2,-1)(-2,1)(-2,-1)
+        if (isS) { dr = slot == 0 ? fw : 0; dc = slot == 1 ? -1 : (slot == 2 ? 1 : 0); }   // forward, col-1, col+1
+        const bool slot_ok = isH || (isS ? (slot == 0 || (slot < 3 && crossed)) : ((isG || isA || isE) && lt4));
+        const int nr = row + dr, nc = col + dc;
+        const bool in = inside(nr, nc);
+        const bool to_pal_col = nc >= 3 && nc <= 5;
+        const bool to_any_pal = to_pal_col && (nr <= 2 || nr >= 7);
+        const bool to_own_pal = to_pal_col && (black ? nr >= 7 : nr <= 2);
+        const bool rule = isG ? (in_any_palace(row, col) && to_any_pal)                          // :328-343
+                        : isA ? to_own_pal                                                       // :170-172
+                        : isE ? ((black ? nr >= 5 : nr <= 4) && ((row < 5) == (nr < 5)))         // :189-192, :359
+                        : true;
+        bool ok = active && slot_ok && in && rule;
+        // the square that must be empty (elephant eye, horse leg: truncating /2 as upstream) and the target; a slot that is
+        // already out reads `from` for both, which holds an own piece and so fails either test
+        const int gsq = (ok && (isE || isH)) ? (row + dr / 2) * 9 + col + dc / 2 : -1;
+        const int tsq = ok ? nr * 9 + nc : from;
+        const int gp = sq[gsq >= 0 ? gsq : from], tp = sq[tsq];
+        ok = ok && (gsq < 0 || gp == 0) && (tp == 0 || (tp > 7) != black);                       // :78-80
+        int n_run = ok ? 1 : 0, t0 = tsq, delta = 0, extra = -1;
+        if (active && isRay && lt4) {                          // right, left, +row, -row (chessboard.cpp:199 / :221)
+            const bool horiz = lt2, fwd = (slot & 1) == 0;
+            const unsigned line = horiz ? bits_at(occ, row * 9, 0x1FFu) : bits_at(occT, col * 10, 0x3FFu);
+            const int pos = horiz ? col : row, len = horiz ? 9 : 10;
+            const RayHit h = ray_scan(line, pos, len, fwd);
+            delta = horiz ? (fwd ? 1 : -1) : (fwd ? 9 : -9);
+            t0 = from + delta;
+            n_run = h.empties;
+            const int hit = type == T_CHARIOT ? h.first : h.second;   // chariot: the blocker itself; cannon: the piece behind the screen
+            if (hit >= 0) {
+                const int bs = horiz ? row * 9 + hit : hit * 9 + col;
+                if ((sq[bs] > 7) != black) {                   // enemy: capturable
+                    if (type == T_CHARIOT) n_run += 1;         // it is the next square of the run
+                    else extra = bs;
                 }
-            } else {
-                int dr = 0, dc = 0;
-                bool ok = false;
-                int guard = -1;                             // square that must be empty (horse leg / elephant eye)
-                switch (type) {
-                    case T_GENERAL:                         // (1,0) (-1,0) (0,1) (0,-1), chessboard.cpp:150
-                        if (slot < 4) { dr = slot == 0 ? 1 : slot == 1 ? -1 : 0; dc = slot == 2 ? 1 : slot == 3 ? -1 : 0; ok = true; }
-                        break;
-                    case T_ADVISOR:                         // (1,1) (1,-1) (-1,1) (-1,-1), :163
-                        if (slot < 4) { dr = slot < 2 ? 1 : -1; dc = (slot & 1) ? -1 : 1; ok = true; }
-                        break;
-                    case T_ELEPHANT:                        // (2,2) (2,-2) (-2,2) (-2,-2), :180
-                        if (slot < 4) { dr = slot < 2 ? 2 : -2; dc = (slot & 1) ? -2 : 2; ok = true; }
-                        break;
-                    case T_HORSE:                           // (1,2)(1,-2)(-1,2)(-1,-2)(2,1)(2,-1)(-2,1)(-2,-1), :249
-                        dr = slot < 4 ? ((slot & 2) ? -1 : 1) : ((slot & 2) ? -2 : 2);
-                        dc = slot < 4 ? ((slot & 1) ? -2 : 2) : ((slot & 1) ? -1 : 1);
-                        ok = true;
-                        break;
-                    case T_SOLDIER: {                       // forward, col-1, col+1, :265-283
-                        const int fw = black ? -1 : 1;
-                        const bool crossed = black ? row < 5 : row > 4;
-                        if (slot == 0) { dr = fw; ok = true; }
-                        else if (slot < 3 && crossed) { dc = slot == 1 ? -1 : 1; ok = true; }
-                        break;
-                    }
-                    default: break;
-                }
-                const int nr = row + dr, nc = col + dc;
-                ok = ok && inside(nr, nc);
-                if (ok) {
-                    switch (type) {
-                        case T_GENERAL: ok = in_any_palace(row, col) && in_any_palace(nr, nc); break;          // :328-343
-                        case T_ADVISOR: ok = in_own_palace(black ? C_BLACK : C_RED, nr, nc); break;            // :170-172
-                        case T_ELEPHANT:                                                                      // :189-192, :359
-                            ok = (black ? nr >= 5 : nr <= 4) && ((row < 5) == (nr < 5));
-                            guard = (row + dr / 2) * 9 + col + dc / 2;
-                            break;
-                        case T_HORSE: guard = (row + dr / 2) * 9 + col + dc / 2; break;                        // :254-258
-                        default: break;
-                    }
-                }
-                if (ok && guard >= 0) ok = sq[guard] == 0;
-                if (ok) {
-                    const int t = sq[nr * 9 + nc];
-                    ok = t == 0 || (t > 7) != black;                                                           // :78-80
-                }
-                if (ok) { n_run = 1; t0 = nr * 9 + nc; }
             }
         }
         const int cnt = n_run + (extra >= 0 ? 1 : 0);
         const int inc = wave_inclusive_scan(cnt);
-        int off = total + inc - cnt;
-        const int base = from * 90;
-        for (int i = 0; i < n_run; ++i, ++off)
-            if (off < kMaxMoves) slab.moves[off] = (uint16_t)(base + t0 + i * delta);
-        if (extra >= 0 && off < kMaxMoves) slab.moves[off] = (uint16_t)(base + extra);
-        total += __shfl(inc, 63, 64);
+        const int off = total + inc - cnt;
+        // The list holds kMaxMoves entries (a real position has at most ~85 moves; an arbitrary xq_env_set_state board may
+        // have more): the run is clipped ONCE, so the store loop carries no bound test — with one, the compiler unrolls it
+        // eight-fold into predicated stores and the exec-mask bookkeeping costs more than the stores.
+        const int room = kMaxMoves - off;
+        const int n_put = n_run < room ? n_run : (room > 0 ? room : 0);
+        uint16_t* dst = slab.moves + off;
+        int code = from * 90 + t0;
+#pragma clang loop unroll(disable)
+        for (int i = 0; i < n_put; ++i, code += delta) dst[i] = (uint16_t)code;
+        if (extra >= 0 && n_run < room) dst[n_run] = (uint16_t)(from * 90 + extra);
+        total += __builtin_amdgcn_readlane(inc, 63);
     }
     return total < kMaxMoves ? total : kMaxMoves;
 }
