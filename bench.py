@@ -232,7 +232,7 @@ def main():
                            precision=_capi.PRECISION_BF16 if CFG["bf16"] else _capi.PRECISION_F32)
     plies = CFG["plies"]
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
-    grads, comm = None, None
+    grads, comm, comm_error = None, None, ""
     if world == 1 or args.independent:
         t.dqn.set_fused_apply(True)          # nothing reads the gradient buffer between td_grads and apply_grads
     elif args.torch_allreduce or backend != "nccl":   # diagnostic / one-GPU gloo rehearsal: the exchange through torch.distributed
@@ -241,8 +241,23 @@ def main():
     else:
         # the exchange step lives behind the C ABI: learn_grads all-reduces the gradient buffer over RCCL itself, in two
         # buckets released by their producers (xq_dqn_set_comm); torch.distributed only carries the 128-byte id and barriers
-        comm = xd.Comm()
-        t.set_comm(comm)
+        ok = torch.ones(1, device="cuda")
+        try:
+            comm = xd.Comm()
+            t.set_comm(comm)
+        except Exception as e:               # keep the measurement: every rank falls back together to the torch.distributed exchange
+            comm_error = str(e)[:200]
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            if comm is not None:
+                t.set_comm(None)
+                comm.close()
+                comm = None
+            ptr, n = t.dqn.grad_buffer()
+            grads = xd.wrap_device_floats(ptr, n)
+            print(f"[rank {rank}] C-ABI communicator unavailable ({comm_error or 'another rank failed'}): all-reduce through torch.distributed",
+                  file=sys.stderr)
 
     def one_step():
         if args.no_overlap:
@@ -382,7 +397,7 @@ def main():
             ach = by / (ms * 1e-3) / 1e9
             line["roofline_env"] = {"kernel": "env_kernel<SELFPLAY> (movegen+select+move+reward+reset, %d boards)" % n_games,
                                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                    "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("env_kernel<2>")[0], "avg_launch_ms": ms,
+                                    "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("env_kernel<2>")[0] if args.config == 2 else None, "avg_launch_ms": ms,
                                     "bytes_per_launch": by, "launches": e["launches"]}
             ei = iso.get("env_selfplay_step")
             if ei and ei["launches"]:
