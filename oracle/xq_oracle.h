@@ -9,6 +9,8 @@
  *   - chessai.cpp pieces (state one-hot, evaluateBoard, action scan order): restatement, pinned by the
  *     known answers SURVEY.md records from the reference run (Appendix B move list, E18 reward values)
  *     and — for the scan order — by the real getValidMoves() per-square lists.
+ *   - ChessAI::getAIMove / startSelfPlay / onGameCompleted (chessai.cpp:29-83, :191-266, :370-393): restatement with the C
+ *     library rand() injected; no upstream vectors exist for them.
  *   - NN (dqn.cu / dqn.cpp): restatement only — dqn.cu needs nvcc/CUDA headers that this image lacks, so the
  *     reference NN cannot be built here without stand-ins: "parity unpinned" by execution; pinned only by the
  *     structural known answers in SURVEY.md (offsets, parameter counts, file size).
