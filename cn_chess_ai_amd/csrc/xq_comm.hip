@@ -126,6 +126,8 @@ int xq_comm_create_from_file(int rank, int world, const char* path, double timeo
     if (!path || !out) return fail(XQ_ERR_INVALID_ARGUMENT, "null pointer");
     uint8_t id[XQ_COMM_ID_BYTES];
     if (rank == 0) {
+        // a file left over from an earlier run would hand the other ranks a dead id (they may read it before this rank replaces it)
+        if (FILE* old = fopen(path, "rb")) { fclose(old); return fail(XQ_ERR_IO, "rendezvous file %s already exists: use a fresh path per run", path); }
         XQ_TRY(xq_comm_unique_id(id));
         const std::string tmp = std::string(path) + ".tmp";
         FILE* f = fopen(tmp.c_str(), "wb");

@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerTree T, int batch, u
         if (pick < 0) { pick = last < 0 ? 0 : last; u = 0.f; }
         node = node * 32 + pick;
     }
-    const float prob = __fdiv_rn(T.leaves[node], total);
-    const float w = powf((float)scalars[3] * prob, -beta);
+    // an empty tree (every priority zero) cannot be sampled proportionally: slot 0, weight 1 (callers check the ring is not empty)
+    const float prob = total > 0.f ? __fdiv_rn(T.leaves[node], total) : 0.f;
+    const float w = prob > 0.f ? powf((float)scalars[3] * prob, -beta) : 1.f;
     slots[k] = node;
     is_w[k] = w;
     // batch maximum: one atomic per wave, not per sample (order-independent, so still reproducible)

@@ -166,7 +166,7 @@ int xq_trainer_set_comm(xq_trainer* t, xq_comm* comm) {
 }
 
 int xq_trainer_set_td_net(xq_trainer* t, int td_net) {
-    if (!t || (td_net != XQ_TD_ONLINE_NET && td_net != XQ_TD_TARGET_NET)) return fail(XQ_ERR_INVALID_ARGUMENT, "bad td_net");
+    if (!t || (td_net != XQ_TD_ONLINE_NET && td_net != XQ_TD_TARGET_NET && td_net != XQ_TD_DOUBLE)) return fail(XQ_ERR_INVALID_ARGUMENT, "bad td_net");
     if (t->grads_queued) return fail(XQ_ERR_RUNTIME, "xq_trainer_set_td_net: call between iterations (after learn_apply)");
     t->cfg.td_net = td_net;
     return XQ_OK;

@@ -271,7 +271,8 @@ enum { XQ_COMM_ID_BYTES = 128 };
 int xq_comm_unique_id(uint8_t* id128);
 /* ncclCommInitRank on the calling process's current device (xq_set_device).  Collective: every rank calls it. */
 int xq_comm_create(int rank, int world, const uint8_t* id128, xq_comm** out);
-/* Same, with the id exchanged through a file every rank can see (rank 0 writes, the others poll up to timeout_s). */
+/* Same, with the id exchanged through a file every rank can see (rank 0 writes, the others poll up to timeout_s).  `path` must
+ * not exist beforehand (a fresh path per run: rank 0 refuses to reuse one, XQ_ERR_IO). */
 int xq_comm_create_from_file(int rank, int world, const char* path, double timeout_s, xq_comm** out);
 int xq_comm_destroy(xq_comm* c);
 int xq_comm_info(const xq_comm* c, int* rank, int* world, uint64_t* collectives_issued, uint64_t* floats_reduced);
@@ -331,8 +332,8 @@ int xq_trainer_set_comm(xq_trainer* t, xq_comm* comm);
  * desynchronises the games so that a measurement or a training run starts from a spread of game phases rather than from
  * n_games copies of the opening.  Call between iterations. */
 int xq_trainer_random_plies(xq_trainer* t, int n_plies);
-/* Which net gives max Q(s') from the next learn step on: XQ_TD_ONLINE_NET (ChessAI::train, chessai.cpp:126) or XQ_TD_TARGET_NET
- * (DQN::train, dqn.cpp:166).  Call between iterations. */
+/* Which rule gives the TD target from the next learn step on: XQ_TD_ONLINE_NET (ChessAI::train, chessai.cpp:126), XQ_TD_TARGET_NET
+ * (DQN::train, dqn.cpp:166) or XQ_TD_DOUBLE.  Call between iterations. */
 int xq_trainer_set_td_net(xq_trainer* t, int td_net);
 int xq_trainer_collect(xq_trainer* t);                       /* one ply in every game */
 int xq_trainer_learn_grads(xq_trainer* t);                   /* sample + gradients into the grad buffer */

@@ -95,6 +95,9 @@ def test_rccl_path_behind_the_c_abi_world_size_one(tmp_path):
     c2 = xd.Comm(rank=0, world=1, path=str(tmp_path / "xq_comm_id"))
     assert c2.info()["world"] == 1 and (tmp_path / "xq_comm_id").stat().st_size == 128
     c2.close()
+    with pytest.raises(xq.XqError) as e:                 # a stale file would hand out a dead id: rank 0 refuses to reuse the path
+        xd.Comm(rank=0, world=1, path=str(tmp_path / "xq_comm_id"))
+    assert e.value.code == 4
 
 
 def _rehearse(extra):
