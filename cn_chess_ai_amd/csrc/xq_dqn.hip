@@ -278,8 +278,11 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* acc = smem;                                  // [nsets][14][H]
     uint16_t* list = reinterpret_cast<uint16_t*>(smem + (long long)nsets * 14 * H);   // [chunk] (b_local | piece << 11)
-    const int s = (int)blockIdx.x;
-    const int c0 = (int)blockIdx.y * chunk;
+    // workgroups go to the 8 XCDs round-robin in linear order: chunk = linear id mod nchunks keeps all 90 square-blocks of a chunk
+    // (they stream the same 1 MB of delta rows, each up to 32 times) behind one XCD's L2 when there are 8 chunks
+    const int lin = (int)(blockIdx.x + gridDim.x * blockIdx.y), nch = (int)gridDim.y;
+    const int s = lin / nch;
+    const int c0 = (lin % nch) * chunk;
     const int c1 = min(n, c0 + chunk);
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // the chunk's piece codes first (up to 8 independent loads per thread in flight), accumulator zeroing under their latency
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
             }
     }
     __syncthreads();
-    float* out = partial + ((long long)blockIdx.y * kStateSize + (long long)s * 14) * H;
+    float* out = partial + ((long long)(lin % nch) * kStateSize + (long long)s * 14) * H;
     const int used = (H & 3) == 0 ? nsets : 1;
     for (int i = tid; i < 14 * H; i += 256) {
         float t = acc[i];

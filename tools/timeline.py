@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Prints the kernel timeline of one training step from a rocprofv3 --kernel-trace CSV (diagnostic)."""
+"""Prints the kernel timeline of one training step from a rocprofv3 --kernel-trace CSV (diagnostic).
+usage: timeline.py DIR [--all]     (--all: also kernels outside xq::, e.g. runtime fill/copy kernels)"""
 import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv'))[-1]
-rows = [r for r in csv.DictReader(open(f)) if 'xq::' in r['Kernel_Name']]
+keep_all = '--all' in sys.argv
+rows = [r for r in csv.DictReader(open(f)) if keep_all or 'xq::' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'env_kernel' in r['Kernel_Name']]
 a, b = idx[-3], idx[-2]
