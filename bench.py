@@ -12,9 +12,11 @@ runs its own 8192 games (game ids rank*8192..) and the gradient buffer is all-re
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the 8192x8100x256 row-max GEMM, MFMA-bound) with
-HIP events recorded around each of its launches inside the timed region; `roofline_env` does the same for the fused
-self-play step kernel (HBM-bound).  `cpu_baseline` times the CPU port of ChessAI::train (oracle) on a bounded sample.
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel with HIP events recorded around each of its launches inside
+the timed region: by default (`--qmax screened`) the 8100 x 8192 x 256 bf16-MFMA screening pass of max_a' Q(s',a') (its fp32
+re-evaluation kernel follows it), with `--qmax full` the fp32-MFMA column-max GEMM, which the default run
+also times as `variant_qmax_full_fp32_product` (own roofline inside).  `roofline_env` does the same for the fused self-play step
+kernel (HBM-bound).  `cpu_baseline` times the CPU port of ChessAI::train (oracle) on a bounded sample.
 """
 import argparse
 import ctypes as C
@@ -181,6 +183,8 @@ def main():
     ap.add_argument("--target-sync-interval", type=int, default=10, help="updates between updateTargetNetwork() calls")
     ap.add_argument("--torch-allreduce", action="store_true",
                     help="diagnostic, N > 1: all-reduce through torch.distributed after learn_grads instead of the bucketed RCCL path of the C ABI")
+    ap.add_argument("--qmax", choices=("screened", "full"), default="screened",
+                    help="max_a' Q(s',a') of the TD target: exact bf16 screening + fp32 re-evaluation (default) or the full fp32 product")
     ap.add_argument("--no-overlap", action="store_true",
                     help="queue collect and learn on one stream (collect -> learn -> apply) instead of running collect beside learn_grads")
     args = ap.parse_args()
@@ -232,6 +236,7 @@ def main():
                            precision=_capi.PRECISION_BF16 if CFG["bf16"] else _capi.PRECISION_F32)
     plies = CFG["plies"]
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
+    t.dqn.set_qmax_mode(_capi.QMAX_SCREENED if args.qmax == "screened" else _capi.QMAX_FULL)
     grads, comm, comm_error = None, None, ""
     if world == 1 or args.independent:
         t.dqn.set_fused_apply(True)          # nothing reads the gradient buffer between td_grads and apply_grads
@@ -297,6 +302,7 @@ def main():
         el = time.perf_counter() - t0
         return xd.max_over_ranks(el, device="cuda" if world > 1 else "cpu"), enq
 
+    qstat0 = t.dqn.qmax_stats()
     t.dqn.kernel_stats(enable=2 if args.profile_all else 3)
     elapsed, host_enqueue = timed(args.steps)
     stats = {s["name"]: s for s in t.dqn.kernel_stats(enable=0)}
@@ -309,6 +315,25 @@ def main():
         one_step()
         el_other, _ = timed(args.steps)
         t.set_td_net(td_code[args.td_net])
+    # the same loop with the full fp32 column-max product in place of the exact screen (bracketed the same way)
+    qmax_info, full_variant = None, None
+    screened_live = "gemm_qmax_screen" in stats
+    if args.qmax == "screened":
+        st = t.dqn.qmax_stats()
+        qmax_info = {"mode": "screened" if screened_live else "full (screen not applicable to this configuration)",
+                     "what": "max_a' Q(s',a') = maximum of fp32-evaluated outputs; candidates found by a bf16 MFMA pass with a "
+                             "rigorous error bound (DESIGN.md section 3)",
+                     "candidate_groups_per_sample": (st[2] - qstat0[2]) / max(st[1] - qstat0[1], 1),
+                     "whole_groups_per_sample": (st[3] - qstat0[3]) / max(st[1] - qstat0[1], 1)}
+        if screened_live and world == 1:
+            t.dqn.set_qmax_mode(_capi.QMAX_FULL)
+            one_step()
+            t.dqn.kernel_stats(enable=3)
+            el_full, _ = timed(args.steps)
+            full_variant = (el_full, {s["name"]: s for s in t.dqn.kernel_stats(enable=0)})
+            t.dqn.set_qmax_mode(_capi.QMAX_SCREENED)
+    else:
+        qmax_info = {"mode": "full fp32 product"}
     # workload statistics of the state the numbers were taken in (host reads, outside every timed region)
     import numpy as np
     _, meta = t.env.get_state()
@@ -349,6 +374,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": CFG["dtype"], "data": "synthetic",
+            "dtype_note": ("weights, activations, Q-values, TD targets and gradients fp32; with config.qmax.mode = screened the candidates for "
+                           "max_a' Q(s',a') are found on bf16 MFMA under a rigorous bound and re-evaluated in fp32 (same maximum)"
+                           if CFG["dtype"] == "f32" else "bf16 forward passes, fp32 accumulation, fp32 master weights and backward"),
             "config": {"workload": CFG["workload"], "baseline_config": args.config,
                        "games_per_gpu": n_games, "layer_sizes": list(LAYERS), "replay_capacity": max(REPLAY, n_games),
                        "minibatch": minibatch, "plies_per_update": plies, "epsilon": 0.1, "backprop": "reference-compatible",
@@ -374,22 +402,39 @@ def main():
         if other is not None:
             line["variant_td_" + other] = {"value": world * n_games * plies * args.steps / el_other, "unit": "env steps/s",
                                            "updates_per_s": args.steps / el_other, "ms_per_step": 1e3 * el_other / args.steps}
-        g = stats.get("gemm_qmax_rowmax")
-        if g and g["launches"]:
-            ms = g["ms"] / g["launches"]
-            fl = g["flops"] / g["launches"]
+        def gemm_roofline(st, iso_st, screened_kernel):
+            ms = st["ms"] / st["launches"]
+            fl = st["flops"] / st["launches"]
             ach = fl / (ms * 1e-3) / 1e12
-            peak = PEAK_BF16_MFMA_TFLOPS if CFG["bf16"] else PEAK_F32_MFMA_TFLOPS
-            tr, src = pmc_traffic("gemm_colmax_persistent_kernel") if args.config == 2 else (None, None)
-            line["roofline"] = {"kernel": "gemm_colmax_persistent_kernel<2,2> (%s_a' Q(s'): 8100 x %d x %d, %s MFMA)" %
-                                          ("argmax" if args.td_net == "double" else "max", minibatch, LAYERS[-2], CFG["dtype"]),
-                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                "frac": ach / peak, "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, offline)",
-                                "traffic_source": src, "avg_launch_ms": ms, "flops_per_launch": fl, "launches": g["launches"]}
-            gi = iso.get("gemm_qmax_rowmax")
-            if gi and gi["launches"]:
-                line["roofline"]["isolated_avg_launch_ms"] = gi["ms"] / gi["launches"]
-                line["roofline"]["isolated_frac"] = fl / (gi["ms"] / gi["launches"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+            bf16_pipe = screened_kernel or CFG["bf16"]
+            peak = PEAK_BF16_MFMA_TFLOPS if bf16_pipe else PEAK_F32_MFMA_TFLOPS
+            # template arguments as rocprofv3 prints them: <TM, TN, DT (0 f32 / 1 bf16), MODE (0 max / 1 arg-max / 2 top-2 screen)>
+            inst = "gemm_colmax_persistent_kernel<2, 2, %d, %d>" % (1 if bf16_pipe else 0,
+                                                                     2 if screened_kernel else 1 if args.td_net == "double" else 0)
+            tr, src = pmc_traffic(inst) if args.config == 2 else (None, None)
+            what = ("exact screen of max_a' Q(s'): all outputs once on bf16 MFMA, top-2 per 32-output group" if screened_kernel else
+                    "%s_a' Q(s')" % ("argmax" if args.td_net == "double" else "max"))
+            r = {"kernel": "%s (%s: 8100 x %d x %d, %s MFMA)" % (inst, what, minibatch, LAYERS[-2], "bf16" if bf16_pipe else "f32"),
+                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                 "frac": ach / peak, "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, offline)",
+                 "traffic_source": src, "avg_launch_ms": ms, "flops_per_launch": fl, "launches": st["launches"]}
+            if iso_st and iso_st["launches"]:
+                r["isolated_avg_launch_ms"] = iso_st["ms"] / iso_st["launches"]
+                r["isolated_frac"] = fl / (iso_st["ms"] / iso_st["launches"] * 1e-3) / 1e12 / peak
+            return r
+        g = stats.get("gemm_qmax_screen") or stats.get("gemm_qmax_rowmax")
+        if g and g["launches"]:
+            scr = "gemm_qmax_screen" in stats
+            line["roofline"] = gemm_roofline(g, iso.get("gemm_qmax_screen" if scr else "gemm_qmax_rowmax"), scr)
+        if qmax_info is not None:
+            line["config"]["qmax"] = qmax_info
+        if full_variant is not None:
+            el_full, st_full = full_variant
+            line["variant_qmax_full_fp32_product"] = {"value": world * n_games * plies * args.steps / el_full, "unit": "env steps/s",
+                                                      "updates_per_s": args.steps / el_full, "ms_per_step": 1e3 * el_full / args.steps}
+            gf = st_full.get("gemm_qmax_rowmax")
+            if gf and gf["launches"]:
+                line["variant_qmax_full_fp32_product"]["roofline"] = gemm_roofline(gf, None, False)
         e = stats.get("env_selfplay_step")
         if e and e["launches"]:
             ms = e["ms"] / e["launches"]

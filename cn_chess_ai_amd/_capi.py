@@ -17,6 +17,7 @@ NET_ONLINE, NET_TARGET = 0, 1
 BACKPROP_REFERENCE, BACKPROP_TEXTBOOK = 0, 1
 TD_ONLINE_NET, TD_TARGET_NET, TD_DOUBLE = 0, 1, 2
 PRECISION_F32, PRECISION_BF16 = 0, 1
+QMAX_FULL, QMAX_SCREENED = 0, 1
 
 STATUS_NAMES = {1: "XQ_ERR_INVALID_ARGUMENT", 2: "XQ_ERR_RUNTIME", 3: "XQ_ERR_NO_DEVICE", 4: "XQ_ERR_IO",
                 5: "XQ_ERR_UNDEFINED_UPSTREAM"}
@@ -112,6 +113,8 @@ PROTOTYPES = {
     "xq_dqn_create": [_pi, _i, _d, _d, _u64, _vp, _pvp],
     "xq_dqn_destroy": [_vp],
     "xq_dqn_set_precision": [_vp, _i],
+    "xq_dqn_set_qmax_mode": [_vp, _i],
+    "xq_dqn_qmax_stats": [_vp, C.POINTER(C.c_uint64)],
     "xq_dqn_num_params": [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "xq_dqn_set_params": [_vp, _i, _pd, _pd],
     "xq_dqn_get_params": [_vp, _i, _pd, _pd],

@@ -63,6 +63,15 @@ struct xq_dqn {
     float* sel_q90 = nullptr;
     int sel_cap = 0;
     bool small_tiles = false;                   // force 64x64 GEMM tiles (<= 80 VGPRs: fits beside the persistent GEMM)
+    // exact screening of max_a' Q(s', a') (xq_dqn_set_qmax_mode): bf16 copies of the output-layer weights and of
+    // the last hidden activations of s', the two screening partial arrays, the largest row norm of the weights, counters
+    int qmax_mode = XQ_QMAX_FULL;
+    uint16_t* scr_wb = nullptr;                 // [round_up(nout,128)][hlast] (rows >= nout zero)
+    uint16_t* scr_ab = nullptr;  int scr_cap = 0;   // [round_up(cap,128)][hlast]
+    float* scr_p1 = nullptr; float* scr_p2 = nullptr;   // [4*tiles_m][cap]
+    unsigned* scr_wmax = nullptr;               // bits of max_j ||W_out[j]||_2 (non-negative floats order like unsigned)
+    unsigned long long* scr_stats = nullptr;    // [4] TD steps, samples, candidate (sample, group) pairs, pairs recomputed as whole groups
+    unsigned long long scr_host_steps = 0, scr_host_samples = 0;
     float* partial = nullptr;                   // row-max partials
     float* zmax = nullptr;  int* zidx = nullptr;    // [kReduceParts][cap] their reduction per sample (colmax_reduce_kernel)
     float* qsa = nullptr;
@@ -139,6 +148,68 @@ __device__ __forceinline__ int slot_of(const SlotSrc& s, int b) {
 // the forward chains of a TD step (s on the online net, s' on the TD net, and for Double DQN s' on the target net as well)
 // share one launch per layer
 enum { kMaxChains = 3 };
+// bf16 copy of a weight matrix [NO][K] (K % 64 == 0) + the largest row norm (exact screening of max_a' Q(s',a'), see
+// qmax_refine_kernel).  A quarter-wave per row, 2 rows per quarter, all of a quarter's loads in flight together (pure latency:
+// 8 MB in, 4 MB out); block `blk` of 256 threads takes rows [32 blk, 32 blk + 32); rows >= NO of the padded copy stay zero.
+struct ShadowJob { const float* W; int NO, K; uint16_t* Wb; unsigned* wmax_bits; };
+enum { kShadowRows = 32 };
+__device__ __forceinline__ void screen_shadow_block(const ShadowJob& S, int blk, float* nrm /* LDS [4] */) {
+    const int ql = (int)(threadIdx.x & 15), quarter = (int)(threadIdx.x >> 4);
+    const int row0 = blk * kShadowRows + quarter * 2;
+    float mx = 0.f;
+    if (S.K == 256) {
+        float4 x[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                x[u][t] = *reinterpret_cast<const float4*>(S.W + (long long)min(row0 + u, S.NO - 1) * 256 + t * 64 + ql * 4);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float ss = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ss += x[u][t].x * x[u][t].x + x[u][t].y * x[u][t].y + x[u][t].z * x[u][t].z + x[u][t].w * x[u][t].w;
+                if (row0 + u < S.NO) {
+                    const uint16_t q0 = bf16_bits(x[u][t].x), q1 = bf16_bits(x[u][t].y), q2 = bf16_bits(x[u][t].z), q3 = bf16_bits(x[u][t].w);
+                    *reinterpret_cast<uint2*>(S.Wb + (long long)(row0 + u) * 256 + t * 64 + ql * 4) =
+                        make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
+                }
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+            mx = fmaxf(mx, row0 + u < S.NO ? ss : 0.f);
+        }
+    } else {
+        for (int u = 0; u < 2; ++u) {
+            float ss = 0.f;
+            if (row0 + u < S.NO)
+                for (int k = ql * 4; k < S.K; k += 64) {
+                    const float4 y = *reinterpret_cast<const float4*>(S.W + (long long)(row0 + u) * S.K + k);
+                    ss += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+                    const uint16_t q0 = bf16_bits(y.x), q1 = bf16_bits(y.y), q2 = bf16_bits(y.z), q3 = bf16_bits(y.w);
+                    *reinterpret_cast<uint2*>(S.Wb + (long long)(row0 + u) * S.K + k) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
+                }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+            mx = fmaxf(mx, ss);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 16; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) nrm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = sqrtf(fmaxf(fmaxf(nrm[0], nrm[1]), fmaxf(nrm[2], nrm[3])));
+        const unsigned mb = __builtin_bit_cast(unsigned, m);
+        if (mb > *reinterpret_cast<volatile unsigned*>(S.wmax_bits)) atomicMax(S.wmax_bits, mb);
+    }
+}
+__global__ __launch_bounds__(256) void screen_shadow_kernel(ShadowJob S) {
+    __shared__ float nrm[4];
+    screen_shadow_block(S, (int)blockIdx.x, nrm);
+}
+
 struct L0Jobs {
     const uint32_t* boards[kMaxChains];
     const float* W0T[kMaxChains];
@@ -148,6 +219,7 @@ struct L0Jobs {
     uint16_t* out_bf[kMaxChains];            // bf16 Q-net: bf16 bits of the activations
     uint32_t* gathered[kMaxChains];
     int njobs;
+    ShadowJob shadow;                        // W != nullptr: the blocks of grid row y == njobs convert the screening shadow (no extra launch)
 };
 
 // Layer 0 from packed boards: a_1 = tanh(b_0 + sum over occupied squares of W0^T[sq*14 + piece-1][:]).
@@ -156,6 +228,10 @@ struct L0Jobs {
 template <bool BF16>
 __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, int n, int H) {
     __shared__ int rows[4][96];
+    if ((int)blockIdx.y == J.njobs) {                   // block-uniform: the screening shadow rides in the same grid
+        if ((int)blockIdx.x * kShadowRows < J.shadow.NO) screen_shadow_block(J.shadow, (int)blockIdx.x, reinterpret_cast<float*>(&rows[0][0]));
+        return;
+    }
     const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int b = (int)blockIdx.x * 4 + wid;
     if (b >= n) return;
@@ -253,6 +329,9 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
                 const uint16_t q0 = bf16_bits(t.x), q1 = bf16_bits(t.y), q2 = bf16_bits(t.z), q3 = bf16_bits(t.w);
                 *reinterpret_cast<uint2*>(out_bf + (long long)b * H + col) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
                 t = make_float4(bf16_to_float(q0), bf16_to_float(q1), bf16_to_float(q2), bf16_to_float(q3));
+            } else if (out_bf) {            // fp32 net: a bf16 COPY beside the exact activations (screening operand, one hidden layer)
+                const uint16_t q0 = bf16_bits(t.x), q1 = bf16_bits(t.y), q2 = bf16_bits(t.z), q3 = bf16_bits(t.w);
+                *reinterpret_cast<uint2*>(out_bf + (long long)b * H + col) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
             }
             if (out) *reinterpret_cast<float4*>(out + (long long)b * H + col) = t;
         }
@@ -722,6 +801,177 @@ struct SegTable {
     uint16_t* dst_bf[16];      // bf16 Q-net: shadow of dst, refreshed with the rounded new value (nullptr: none)
     int nseg;
 };
+// ---- exact screening of z_max[b] = max_j (W_out[j] . a[b] + b_out[j])  (xq_dqn_set_qmax_mode(XQ_QMAX_SCREENED)) ------
+// The fp32 column-max GEMM computes 8100 outputs per sample to keep one.  Screening computes all of them once on the bf16 matrix
+// pipe (16x the fp32 MFMA rate), with a rigorous bound on what bf16 operands can hide, and recomputes in fp32 only the few outputs
+// that could still be the maximum:
+//   z~_j = fl32(sum_k bf16(W_jk) bf16(a_k)) + b_j,   |z~_j - z_j| <= B := kScreenEps * ||a||_2 * max_j ||W_j||_2
+//   (round-to-nearest bf16: relative error <= 2^-8 per operand, so <= 2^-7 + 2^-16 per product; Cauchy-Schwarz over k; the fp32
+//   accumulation of K <= 1024 exact products adds <= K 2^-23; the 5-bit position tag adds 2^-18 |z~| and has its own slack term)
+//   j* = argmax z_j  =>  z~_j* >= z_j* - B >= z_J - B >= z~_J - 2B with J = argmax z~: every output whose screened value is within
+//   2B of the screened maximum is a candidate and j* is among them.  The result is max over the candidates of the fp32 dot — the
+//   maximum of fp32-evaluated outputs, as before, not a bf16 quantity.
+// Pass 1 (gemm_colmax_persistent_kernel<.., DT_BF16, CM_TOP2>) leaves, per sample and per 32-row lane group, the largest screened
+// value (tagged with its row) and the second largest.  Pass 2 below: threshold per sample, then one fp32 dot per candidate group
+// whose second value is below the threshold (the usual case), 32 dots for a group with two values above it.
+constexpr float kScreenEps = 0.0078125f * 1.04f;      // (2^-7 + 2^-16 + 1024 * 2^-23) < 2^-7 * 1.017; margin for the fp32 norm products
+
+__device__ __forceinline__ int float_order_key(float f) {             // signed-int order == float order (no NaNs here)
+    const int b = __builtin_bit_cast(int, f);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float float_from_key(int k) { return __builtin_bit_cast(float, k ^ ((k >> 31) & 0x7fffffff)); }
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Pass 2.  Block = 32 consecutive samples x 8 group phases (thread = (sample, phase); P1 / P2 are [G][n], group-major, so a
+// half-wave reads 128 contiguous bytes per group).  G <= 512.  Every thread keeps its G/8 screened values in registers between the
+// maximum and the candidate scan.  Dynamic LDS: G * 32 single-row candidates (32 bits) + G * 32 whole-group candidates (16 bits) —
+// one entry per (sample, group) pair at most, so neither list can overflow.  The fp32 dots run a quarter-wave per row: singles two
+// per quarter and round (32 per round), a whole group as ONE round of the block (its 32 rows over the 16 quarters).
+// wmax_next: zeroed for the next step's shadow pass.  stats: [2] += candidate pairs, [3] += pairs recomputed as whole groups.
+enum { kRefineSamples = 32, kRefineMaxPerThread = 64 };
+
+// one fp32 dot per quarter-wave (16 lanes x float4 x K/64 passes), all loads of both operands issued before the first fma
+template <int KFIX>
+__device__ __forceinline__ float quarter_dot(const float* __restrict__ ap, const float* __restrict__ wp, int K, int ql) {
+    float acc = 0.f;
+    if (KFIX > 0) {
+        constexpr int NT = KFIX > 0 ? KFIX / 64 : 1;
+        float4 x[NT], w[NT];
+#pragma unroll
+        for (int t = 0; t < KFIX / 64; ++t) {
+            x[t] = *reinterpret_cast<const float4*>(ap + t * 64 + ql * 4);
+            w[t] = *reinterpret_cast<const float4*>(wp + t * 64 + ql * 4);
+        }
+#pragma unroll
+        for (int t = 0; t < KFIX / 64; ++t) {
+            acc = fmaf(x[t].x, w[t].x, acc); acc = fmaf(x[t].y, w[t].y, acc);
+            acc = fmaf(x[t].z, w[t].z, acc); acc = fmaf(x[t].w, w[t].w, acc);
+        }
+    } else {
+        for (int k = ql * 4; k < K; k += 64) {
+            const float4 x = *reinterpret_cast<const float4*>(ap + k);
+            const float4 w = *reinterpret_cast<const float4*>(wp + k);
+            acc = fmaf(x.x, w.x, acc); acc = fmaf(x.y, w.y, acc); acc = fmaf(x.z, w.z, acc); acc = fmaf(x.w, w.w, acc);
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ float quarter_sum(float v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int screen_row(int g, int code) {       // inverse of the CM_TOP2 position code
+    const int q = code & 15;
+    return (g >> 2) * 128 + ((g >> 1) & 1) * 64 + 4 * (g & 1) + (code >> 4) * 32 + (q & 3) + 8 * (q >> 2);
+}
+
+template <int KFIX>
+__global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restrict__ P1, const float* __restrict__ P2, int G, int n,
+                                                          const float* __restrict__ a_last, int K, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, int NO, const unsigned* __restrict__ wmax_bits,
+                                                          unsigned* __restrict__ wmax_next, float* __restrict__ zmax,
+                                                          unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cand[];            // [G * 32]: sample | row << 5
+    uint16_t* wlist = reinterpret_cast<uint16_t*>(cand + (size_t)G * kRefineSamples);    // [G * 32]: sample | group << 5
+    __shared__ float sv[8][32];
+    __shared__ float na[32], thr[32];
+    __shared__ int best[32];
+    __shared__ int cnt, nexp;
+    const int tid = (int)threadIdx.x;
+    const int sl = tid & 31, phase = tid >> 5;
+    const int ql = tid & 15, quarter = tid >> 4;
+    const int b0 = (int)blockIdx.x * kRefineSamples;
+    const int b = b0 + sl;
+    const bool ok = b < n;
+    if (tid == 0) { cnt = 0; nexp = 0; if (blockIdx.x == 0) *wmax_next = 0u; }
+    if (tid < 32) best[tid] = (int)0x80000000;
+    // this thread's screened values: groups phase, phase + 8, ...
+    float v[kRefineMaxPerThread];
+#pragma unroll
+    for (int u = 0; u < kRefineMaxPerThread; ++u) {
+        const int g = phase + 8 * u;
+        v[u] = (ok && g < G) ? P1[(long long)g * n + b] : kColmaxPadBias;
+    }
+    // ||a_b||^2: a quarter-wave per sample, two samples per quarter
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = quarter + 16 * r;
+        const float* ap = a_last + (long long)min(b0 + i, n - 1) * K;
+        const float ss = quarter_sum(quarter_dot<KFIX>(ap, ap, K, ql));
+        if (ql == 0) na[i] = ss;
+    }
+    float m = kColmaxPadBias;
+#pragma unroll
+    for (int u = 0; u < kRefineMaxPerThread; ++u) m = fmaxf(m, v[u]);
+    sv[phase][sl] = m;
+    __syncthreads();
+    if (tid < 32) {
+        m = sv[0][sl];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) m = fmaxf(m, sv[p][sl]);
+        const float B = kScreenEps * sqrtf(na[sl]) * __builtin_bit_cast(float, *wmax_bits);
+        thr[sl] = m - 2.f * B - 1.52587890625e-05f * (fabsf(m) + 2.f * B);       // 2^-16: the position tags, both ends
+    }
+    __syncthreads();
+    {
+        const float t = thr[sl];
+#pragma unroll
+        for (int u = 0; u < kRefineMaxPerThread; ++u) {
+            const int g = phase + 8 * u;
+            if (ok && g < G && v[u] >= t) {
+                if (P2[(long long)g * n + b] >= t) wlist[atomicAdd(&nexp, 1)] = (uint16_t)(sl | (g << 5));
+                else cand[atomicAdd(&cnt, 1)] = (uint32_t)sl | ((uint32_t)screen_row(g, (int)(__builtin_bit_cast(uint32_t, v[u]) & 31u)) << 5);
+            }
+        }
+    }
+    __syncthreads();
+    // fp32 dots of the candidates (the maximum does not depend on the order they are visited in)
+    const int singles = cnt, wholes = nexp;
+    for (int e0 = 0; e0 < singles; e0 += 32) {                   // 16 quarters x 2 rows per round
+        float z[2];
+        int s2[2];
+        bool live[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = e0 + quarter + 16 * r;
+            live[r] = e < singles;
+            const uint32_t ent = cand[live[r] ? e : 0];
+            s2[r] = (int)(ent & 31u);
+            const int row = min((int)(ent >> 5), NO - 1);
+            z[r] = quarter_dot<KFIX>(a_last + (long long)(b0 + s2[r]) * K, W + (long long)row * K, K, ql);
+            z[r] = quarter_sum(z[r]) + bias[row];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (live[r] && ql == 0) atomicMax(&best[s2[r]], float_order_key(z[r]));
+    }
+    for (int e = 0; e < wholes; ++e) {                           // a whole group: its 32 rows over the 16 quarters, one round
+        const int ent = wlist[e];
+        const int s2 = ent & 31, g = ent >> 5;
+        float zb = kColmaxPadBias;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = screen_row(g, quarter + 16 * r);
+            const int rc = min(row, NO - 1);
+            const float z = quarter_sum(quarter_dot<KFIX>(a_last + (long long)(b0 + s2) * K, W + (long long)rc * K, K, ql)) + bias[rc];
+            if (row < NO) zb = fmaxf(zb, z);
+        }
+        if (ql == 0) atomicMax(&best[s2], float_order_key(zb));
+    }
+    __syncthreads();
+    if (tid < 32 && ok) zmax[b] = float_from_key(best[sl]);
+    if (tid == 0) {
+        atomicAdd(&stats[2], (unsigned long long)(singles + wholes));
+        atomicAdd(&stats[3], (unsigned long long)wholes);
+    }
+}
+
 // bf16 shadow of a weight range (set_params / load_model / set_precision)
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -900,15 +1150,43 @@ static SlotSrc explicit_slots(const int32_t* slots) {
 
 // One forward chain of a launch group: a_1 .. a_{nl-1} of `net` for n packed boards; outs[l] receives a_{l+1} in fp32 (may be
 // nullptr per chain in bf16 mode when only the next layer reads it), outs_bf[l] its bf16 bits (bf16 Q-net only).
+// buffers of the screened maximum (xq_dqn_set_qmax_mode), allocated on first use
+static int ensure_screen_capacity(xq_dqn* d, int n) {
+    const int NO = d->nout(), Hl = d->hlast();
+    const size_t wrows = (size_t)round_up(NO, 128);
+    if (!d->scr_wb) {
+        XQ_HIP(hipMalloc(&d->scr_wb, wrows * Hl * sizeof(uint16_t)));
+        XQ_HIP(hipMemset(d->scr_wb, 0, wrows * Hl * sizeof(uint16_t)));
+        XQ_HIP(hipMalloc(&d->scr_wmax, 2 * sizeof(unsigned)));
+        XQ_HIP(hipMemset(d->scr_wmax, 0, 2 * sizeof(unsigned)));
+        XQ_HIP(hipMalloc(&d->scr_stats, 4 * sizeof(unsigned long long)));
+        XQ_HIP(hipMemset(d->scr_stats, 0, 4 * sizeof(unsigned long long)));
+    }
+    if (n > d->scr_cap) {
+        XQ_HIP(hipDeviceSynchronize());
+        const size_t rows = (size_t)round_up(n, 128), G = (size_t)4 * ((NO + 127) / 128);
+        if (d->scr_ab) XQ_HIP(hipFree(d->scr_ab));
+        if (d->scr_p1) XQ_HIP(hipFree(d->scr_p1));
+        if (d->scr_p2) XQ_HIP(hipFree(d->scr_p2));
+        XQ_HIP(hipMalloc(&d->scr_ab, rows * Hl * sizeof(uint16_t)));
+        XQ_HIP(hipMemset(d->scr_ab, 0, rows * Hl * sizeof(uint16_t)));
+        XQ_HIP(hipMalloc(&d->scr_p1, G * (size_t)n * sizeof(float)));
+        XQ_HIP(hipMalloc(&d->scr_p2, G * (size_t)n * sizeof(float)));
+        d->scr_cap = n;
+    }
+    return XQ_OK;
+}
+
 struct ChainJob {
     int net;
     const uint32_t* boards;
     float* const* outs;
     uint16_t* const* outs_bf;
     uint32_t* gathered;
+    uint16_t* last_bf;          // fp32 net: != nullptr => bf16 copy of the chain's LAST hidden activations (screening operand)
 };
 // Up to three chains run in the same launches: one gather grid with blockIdx.y = chain, grouped GEMMs with blockIdx.z = chain.
-static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src, int n) {
+static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src, int n, const ShadowJob* shadow = nullptr) {
     if (d->L[0] != kStateSize) return fail(XQ_ERR_INVALID_ARGUMENT, "board input needs layer_sizes[0] == 1260 (got %d)", d->L[0]);
     if (njobs < 1 || njobs > kMaxChains) return fail(XQ_ERR_INVALID_ARGUMENT, "1..3 forward chains per launch group");
     const bool bf = d->bf16();
@@ -920,10 +1198,23 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
             J.boards[k] = jobs[k].boards; J.W0T[k] = d->w0t(jobs[k].net); J.b0[k] = d->bl(jobs[k].net, 0);
             J.out[k] = jobs[k].outs ? jobs[k].outs[0] : nullptr; J.gathered[k] = jobs[k].gathered;
             if (bf) { J.W0T_bf[k] = d->wl_bf(jobs[k].net, 0); J.out_bf[k] = jobs[k].outs_bf[0]; }
+            else if (d->nl == 2) J.out_bf[k] = jobs[k].last_bf;
+        }
+        // the screening shadow of the output-layer weights rides in the same grid (one more row of blocks) when the grid is wide
+        // enough for it; a launch of its own otherwise
+        bool ride = false;
+        if (shadow) {
+            const int sblocks = (shadow->NO + kShadowRows - 1) / kShadowRows;
+            ride = sblocks <= (n + 3) / 4;
+            if (ride) J.shadow = *shadow;
+            else {
+                hipLaunchKernelGGL(screen_shadow_kernel, dim3(sblocks), dim3(256), 0, d->cur, *shadow);
+                XQ_HIP(hipGetLastError());
+            }
         }
         ProfScope ps(d, "l0_forward_gather", 2.0 * njobs * n * 32 * H, (double)njobs * n * (48 + 32.0 * H * (bf ? 2 : 4) + H * 4));
         if (bf) hipLaunchKernelGGL(l0_forward_kernel<true>, dim3((n + 3) / 4, njobs), dim3(256), 0, d->cur, J, src, n, H);
-        else hipLaunchKernelGGL(l0_forward_kernel<false>, dim3((n + 3) / 4, njobs), dim3(256), 0, d->cur, J, src, n, H);
+        else hipLaunchKernelGGL(l0_forward_kernel<false>, dim3((n + 3) / 4, njobs + (ride ? 1 : 0)), dim3(256), 0, d->cur, J, src, n, H);
         XQ_HIP(hipGetLastError());
     }
     for (int l = 1; l + 1 < d->nl; ++l) {
@@ -943,10 +1234,11 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
             }
             XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH, DT_BF16>(d, g, 1, "gemm_hidden_fwd")));
         } else {
-            g.K = d->L[l]; g.lda = g.ldb = d->L[l]; g.ldc = d->L[l + 1];
+            g.K = d->L[l]; g.lda = g.ldb = d->L[l]; g.ldc = d->L[l + 1]; g.ldcb = d->L[l + 1];
             for (int k = 0; k < njobs; ++k) {
-                if (k == 0) { g.A = jobs[k].outs[l - 1]; g.B = d->wl(jobs[k].net, l); g.C = jobs[k].outs[l]; g.bias = d->bl(jobs[k].net, l); }
-                else { g.Ax[k - 1] = jobs[k].outs[l - 1]; g.Bx[k - 1] = d->wl(jobs[k].net, l); g.Cx[k - 1] = jobs[k].outs[l]; g.biasx[k - 1] = d->bl(jobs[k].net, l); }
+                uint16_t* cb = (l == d->nl - 2) ? jobs[k].last_bf : nullptr;
+                if (k == 0) { g.A = jobs[k].outs[l - 1]; g.B = d->wl(jobs[k].net, l); g.C = jobs[k].outs[l]; g.bias = d->bl(jobs[k].net, l); g.Cb = cb; }
+                else { g.Ax[k - 1] = jobs[k].outs[l - 1]; g.Bx[k - 1] = d->wl(jobs[k].net, l); g.Cx[k - 1] = jobs[k].outs[l]; g.biasx[k - 1] = d->bl(jobs[k].net, l); g.Cbx[k - 1] = cb; }
             }
             XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH>(d, g, 1, "gemm_hidden_fwd")));
         }
@@ -1290,6 +1582,8 @@ int xq_dqn_destroy(xq_dqn* d) {
     if (d->ev_delta) hipEventDestroy(d->ev_delta);
     if (d->ev_qmax) hipEventDestroy(d->ev_qmax);
     if (d->ev_l0) hipEventDestroy(d->ev_l0);
+    for (void* q : {(void*)d->scr_wb, (void*)d->scr_ab, (void*)d->scr_p1, (void*)d->scr_p2, (void*)d->scr_wmax, (void*)d->scr_stats})
+        if (q) hipFree(q);
     if (d->own_stream) hipStreamDestroy(d->stream);
     delete d;
     return XQ_OK;
@@ -1343,6 +1637,23 @@ static int refresh_shadow(xq_dqn* d, int net) {
     if (!d->bf16()) return XQ_OK;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(1024), dim3(256), 0, d->stream, d->params[net], d->params_bf[net], (long long)d->nw);
     XQ_HIP(hipGetLastError());
+    return XQ_OK;
+}
+
+int xq_dqn_set_qmax_mode(xq_dqn* d, int mode) {
+    if (!d || (mode != XQ_QMAX_FULL && mode != XQ_QMAX_SCREENED)) return fail(XQ_ERR_INVALID_ARGUMENT, "bad qmax mode");
+    d->qmax_mode = mode;
+    return XQ_OK;
+}
+
+int xq_dqn_qmax_stats(xq_dqn* d, uint64_t stats[4]) {
+    if (!d || !stats) return fail(XQ_ERR_INVALID_ARGUMENT, "null");
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (d->scr_stats) {
+        XQ_HIP(hipDeviceSynchronize());
+        XQ_HIP(hipMemcpy(h, d->scr_stats, sizeof h, hipMemcpyDeviceToHost));
+    }
+    stats[0] = d->scr_host_steps; stats[1] = d->scr_host_samples; stats[2] = h[2]; stats[3] = h[3];
     return XQ_OK;
 }
 
@@ -1580,13 +1891,63 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         touts[l] = bf ? nullptr : d->tacts[l & 1]; touts_bf[l] = d->tacts_bf[l & 1];
         t2outs[l] = bf ? nullptr : d->t2acts[l & 1]; t2outs_bf[l] = d->t2acts_bf[l & 1];
     }
-    ChainJob jobs[3] = {{XQ_NET_ONLINE, boards, outs, outs_bf, d->gboards}, {sel_net, next_boards, touts, touts_bf, nullptr},
-                        {XQ_NET_TARGET, next_boards, t2outs, t2outs_bf, nullptr}};
-    XQ_TRY(chain_boards(d, jobs, dbl ? 3 : 2, slots, n));
     // launched transposed (rows = output neurons, columns = samples): the max over the 8100 outputs then runs over
     // accumulator registers inside one lane instead of across the 32 lanes of a row
     const bool big_tiles = (long long)((NO + 127) / 128) * ((n + 127) / 128) >= 512;
     const int n_partial = 2 * (big_tiles ? (NO + 127) / 128 : (NO + 63) / 64);
+    const size_t bias_lds_all = (size_t)((NO + 127) / 128) * 128 * sizeof(float);
+    const bool screened = d->qmax_mode == XQ_QMAX_SCREENED && !bf && !dbl && big_tiles && (Hl % 64) == 0 && Hl <= 1024 &&
+                          bias_lds_all <= 40 * 1024 && (NO + 127) / 128 * 4 <= 8 * kRefineMaxPerThread;
+    if (screened) {
+        XQ_TRY(ensure_screen_capacity(d, n));
+    }
+    // bf16 copy + largest row norm of the selecting net's output-layer weights (they change with every SGD step); the norm lands
+    // in slot `screened steps & 1`, which the refine kernel of the previous screened step zeroed
+    ShadowJob shadow{d->wl(sel_net, nl - 1), NO, Hl, d->scr_wb, d->scr_wmax ? d->scr_wmax + (d->scr_host_steps & 1) : nullptr};
+    ChainJob jobs[3] = {{XQ_NET_ONLINE, boards, outs, outs_bf, d->gboards, nullptr}, {sel_net, next_boards, touts, touts_bf, nullptr, screened ? d->scr_ab : nullptr},
+                        {XQ_NET_TARGET, next_boards, t2outs, t2outs_bf, nullptr, nullptr}};
+    XQ_TRY(chain_boards(d, jobs, dbl ? 3 : 2, slots, n, screened ? &shadow : nullptr));
+    int zparts = kReduceParts;
+    if (screened) {
+        const int tiles_m = (NO + 127) / 128, total = tiles_m * ((n + 127) / 128), G = 4 * tiles_m;
+        GemmArgs g; memset(&g, 0, sizeof g);
+        g.M = NO; g.N = n;
+        g.K = Hl / 2; g.lda = g.ldb = Hl / 2;
+        g.A = reinterpret_cast<const float*>(d->scr_wb);
+        g.B = reinterpret_cast<const float*>(d->scr_ab);
+        g.bias = d->bl(sel_net, nl - 1);
+        g.partial = d->scr_p1; g.partial2 = d->scr_p2;
+        g.a_vec = g.b_vec = 1; g.k_chunk = g.K;
+        g.bias_padded = ((((uintptr_t)g.bias) % 16 == 0) && (NO % 4) == 0) ? 1 : 0;
+        const int grid = std::min(total, 2 * d->ncu);
+        if (grid >= 2 && (grid & 1) == 0 && total >= 4 * grid) {
+            g.prio_split = grid / 2;
+            g.prio_tiles = (total / 2) / tiles_m * tiles_m;
+            if (g.prio_tiles <= 0 || g.prio_tiles >= total) { g.prio_split = 0; g.prio_tiles = 0; }
+        }
+        {
+            ProfScope ps(d, "gemm_qmax_screen", 2.0 * g.M * g.N * Hl, 2.0 * ((double)g.M * Hl + (double)g.N * Hl) + 8.0 * G * g.N);
+            hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_BF16, CM_TOP2>), dim3(grid), dim3(256), bias_lds_all, d->cur, g, tiles_m, total);
+            XQ_HIP(hipGetLastError());
+        }
+        XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
+        {
+            ProfScope ps(d, "qmax_refine", 2.0 * n * Hl * 3, 12.0 * G * n + 4.0 * n * Hl);
+            const size_t lds = (size_t)G * kRefineSamples * (sizeof(uint32_t) + sizeof(uint16_t));
+            const dim3 grid((n + kRefineSamples - 1) / kRefineSamples);
+            unsigned* w_now = d->scr_wmax + (d->scr_host_steps & 1);
+            unsigned* w_next = d->scr_wmax + ((d->scr_host_steps & 1) ^ 1);
+            if (Hl == 256) hipLaunchKernelGGL(qmax_refine_kernel<256>, grid, dim3(256), lds, d->cur, d->scr_p1, d->scr_p2, G, n, touts[nl - 2], Hl,
+                                              d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, w_now, w_next, d->zmax, d->scr_stats);
+            else if (Hl == 512) hipLaunchKernelGGL(qmax_refine_kernel<512>, grid, dim3(256), lds, d->cur, d->scr_p1, d->scr_p2, G, n, touts[nl - 2], Hl,
+                                                   d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, w_now, w_next, d->zmax, d->scr_stats);
+            else hipLaunchKernelGGL(qmax_refine_kernel<0>, grid, dim3(256), lds, d->cur, d->scr_p1, d->scr_p2, G, n, touts[nl - 2], Hl,
+                                    d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, w_now, w_next, d->zmax, d->scr_stats);
+            XQ_HIP(hipGetLastError());
+        }
+        d->scr_host_steps += 1; d->scr_host_samples += (unsigned long long)n;
+        zparts = 1;
+    } else {
     {
         GemmArgs g; memset(&g, 0, sizeof g);
         g.M = NO; g.N = n;
@@ -1619,10 +1980,10 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
                 if (g.prio_tiles <= 0 || g.prio_tiles >= total) { g.prio_split = 0; g.prio_tiles = 0; }
             }
             ProfScope ps(d, "gemm_qmax_rowmax", 2.0 * g.M * g.N * Hl, (bf ? 2.0 : 4.0) * ((double)g.M * Hl + (double)g.N * Hl) + 8.0 * tiles_m * g.N);
-            if (bf && dbl) hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_BF16, true>), dim3(grid), dim3(256), bias_lds, d->cur, g, tiles_m, total);
-            else if (bf) hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_BF16, false>), dim3(grid), dim3(256), bias_lds, d->cur, g, tiles_m, total);
-            else if (dbl) hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_F32, true>), dim3(grid), dim3(256), bias_lds, d->cur, g, tiles_m, total);
-            else hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_F32, false>), dim3(grid), dim3(256), bias_lds, d->cur, g, tiles_m, total);
+            if (bf && dbl) hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_BF16, CM_ARG>), dim3(grid), dim3(256), bias_lds, d->cur, g, tiles_m, total);
+            else if (bf) hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_BF16, CM_MAX>), dim3(grid), dim3(256), bias_lds, d->cur, g, tiles_m, total);
+            else if (dbl) hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_F32, CM_ARG>), dim3(grid), dim3(256), bias_lds, d->cur, g, tiles_m, total);
+            else hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_F32, CM_MAX>), dim3(grid), dim3(256), bias_lds, d->cur, g, tiles_m, total);
             XQ_HIP(hipGetLastError());
         } else if (bf) {
             XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_COLMAX, DT_BF16>(d, g, 1, "gemm_qmax_rowmax")));
@@ -1637,6 +1998,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
                            dbl ? d->partial_idx : nullptr, n_partial, n, d->zmax, d->zidx);
         XQ_HIP(hipGetLastError());
     }
+    }   // !screened
     // 3. Q(s, a), target, the scalar output delta and the delta of the last hidden layer (one launch, no GEMM)
     {
         const int lt = nl - 2;                               // last hidden layer
@@ -1658,7 +2020,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             X.per_eps = per->eps; X.per_alpha = per->alpha;
         }
         hipLaunchKernelGGL(td_delta_kernel, dim3((n + 3) / 4), dim3(256), 0, d->cur, n, slots, action_to, reward, done,
-                           outs[nl - 2], Hl, d->wl(XQ_NET_ONLINE, nl - 1), d->bl(XQ_NET_ONLINE, nl - 1), d->zmax, kReduceParts,
+                           outs[nl - 2], Hl, d->wl(XQ_NET_ONLINE, nl - 1), d->bl(XQ_NET_ONLINE, nl - 1), d->zmax, zparts,
                            (float)d->gamma, view, view_ld, view_kmax, d->deltas[lt], d->dsc, d->act_mb, d->qsa, d->yv, d->lossv, X);
         XQ_HIP(hipGetLastError());
     }

@@ -67,6 +67,7 @@ struct GemmArgs {
     // its result to bf16 and writes it to Cb (bf16 bits, row stride ldcb) — and, when C != nullptr, the rounded value to C too.
     uint16_t* Cb; long long ldcb; uint16_t* Cbx[2];
     int* partial_idx;             // EPI_COLMAX: != nullptr => also the row index of each partial maximum (first maximum wins)
+    float* partial2;              // persistent kernel, CM_TOP2: second-largest value of every 32-row lane group (see below)
     int bias_padded;              // EPI_COLMAX: bias[] is 16-byte aligned and readable up to the last tile's edge
     int prio_split;               // persistent kernel: blocks >= prio_split run at s_setprio 1 (0 = off) ...
     int prio_tiles;               // ... and own tiles [0, prio_tiles); the other blocks own [prio_tiles, total)
@@ -433,6 +434,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
                     if (EPI == EPI_DELTA) v = v * (1.f - hv[q] * hv[q]);
                     Cz[(long long)(mb + (q & 3) + 8 * (q >> 2)) * g.ldc + n] = v;
+                    // fp32 net: a bf16 COPY of the exact activation beside it (operand of the screening pass)
+                    if (EPI == EPI_BIAS_TANH && g.Cb) g.Cb[(long long)(mb + (q & 3) + 8 * (q >> 2)) * g.ldcb + n] = bf16_bits(v);
                 }
             }
         return;
@@ -456,6 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     v = v * (1.f - a * a);
                 }
                 Cz[(long long)m * g.ldc + n] = v;
+                if (EPI == EPI_BIAS_TANH && g.Cb) g.Cb[(long long)m * g.ldcb + n] = bf16_bits(v);
             }
         }
 }
@@ -468,10 +472,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // the current one.  Requires K % 32 == 0, 16-byte aligned operands, and both operands readable up to the next multiple of
 // 128 rows (the callers pad their allocations, finite contents); rows beyond M never win the max (their bias is -inf in
 // LDS), columns beyond N are not stored.  Dynamic LDS: tiles_m * 128 floats (the bias vector).
-// ARG: also the row index of each partial maximum (g.partial_idx; first maximum wins, see epilogue_colmax) — Double DQN.
+// MODE = CM_ARG: also the row index of each partial maximum (g.partial_idx; first maximum wins, see epilogue_colmax) — Double DQN.
+// MODE = CM_TOP2 (screening pass of the exact fp32 column maximum): no exchange between the half-waves; every lane
+// keeps the LARGEST and the SECOND-LARGEST value of the 32 rows it holds of a column, the largest carrying its position in the low
+// five mantissa bits (code = 16 i + q; row = tile_m*128 + wm*64 + 32 i + (q&3) + 8 (q>>2) + 4 h).  partial / partial2 are
+// [tiles_m * 4][N], group = (tile_m*2 + wm)*2 + h.  Padding rows carry a bias of -3e38 (finite: tagging -inf would make a NaN).
 // DT_BF16: bf16 operands (K counts pairs), same loop; the MFMA share of a k-step drops 16x, so the kernel is then bound by
 // its LDS staging, not by the matrix pipe.
-template <int TM, int TN, int DT = DT_F32, bool ARG = false>
+enum { CM_MAX = 0, CM_ARG = 1, CM_TOP2 = 2 };
+constexpr float kColmaxPadBias = -3.0e38f;      // CM_TOP2: bias of the padding rows
+
+template <int TM, int TN, int DT = DT_F32, int MODE = CM_MAX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_colmax_persistent_kernel(const GemmArgs g,
                                                                                                         int tiles_m, int total) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     stage_load<L_KCONTIG, BN, true>(g, g.B, g.ldb, 1, tn * BN, g.N, 0, g.K, vb);
     if (g.bias_padded) {            // bias 16-byte aligned and M % 4 == 0: unconditional (clamped) float4 loads, 8 in flight per thread
         const int n4 = tiles_m * BM / 4, m4 = g.M / 4;
-        const float NEGF = -__builtin_inff();
+        const float NEGF = MODE == CM_TOP2 ? kColmaxPadBias : -__builtin_inff();
         for (int c0 = 0; c0 < n4; c0 += 256 * 8) {
             float4 bv[8];
 #pragma unroll
@@ -519,7 +530,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     } else {
-        for (int m = tid; m < tiles_m * BM; m += 256) Bias_s[m] = m < g.M ? g.bias[m] : -__builtin_inff();
+        for (int m = tid; m < tiles_m * BM; m += 256) Bias_s[m] = m < g.M ? g.bias[m] : (MODE == CM_TOP2 ? kColmaxPadBias : -__builtin_inff());
     }
     for (;;) {
         f32x16 acc[TM][TN];
@@ -548,6 +559,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) — four runs of 4 consecutive rows per tile, one ds_read_b128 each; the
         // other 4-row groups live in the other half-wave.  (The first k-step's barrier orders the Bias_s fill before this.)
         const float* bt = Bias_s + tm * BM + wm * 32 * TM + 4 * h;
+        if (MODE == CM_TOP2) {
+            static_assert(TM == 2, "the 5-bit position code assumes 32 rows per lane");
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float m1 = kColmaxPadBias, m2 = kColmaxPadBias;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const float4 x = *reinterpret_cast<const float4*>(bt + i * 32 + 8 * gq);
+                        const float bq[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t bits = __builtin_bit_cast(uint32_t, acc[i][j][4 * gq + e] + bq[e]);
+                            const float v = __builtin_bit_cast(float, (bits & ~31u) | (uint32_t)(i * 16 + 4 * gq + e));
+                            m2 = __builtin_amdgcn_fmed3f(m1, m2, v);        // second-largest so far
+                            m1 = fmaxf(m1, v);
+                        }
+                    }
+                const int n = tn * BN + wn * 32 * TN + j * 32 + r;
+                if (n < g.N) {
+                    const long long o = (((long long)tm * 2 + wm) * 2 + h) * g.N + n;
+                    g.partial[o] = m1;
+                    g.partial2[o] = m2;
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float c = -__builtin_inff();
@@ -558,7 +596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const float4 x = *reinterpret_cast<const float4*>(bt + i * 32 + 8 * gq);
-                    if (ARG) {                     // rows ascending within the lane + strict > : the lane's FIRST maximum
+                    if (MODE == CM_ARG) {          // rows ascending within the lane + strict > : the lane's FIRST maximum
                         const float v0 = acc[i][j][4 * gq] + x.x, v1 = acc[i][j][4 * gq + 1] + x.y;
                         const float v2 = acc[i][j][4 * gq + 2] + x.z, v3 = acc[i][j][4 * gq + 3] + x.w;
                         const int rb = row0 + i * 32 + 8 * gq;
@@ -573,7 +611,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             const float oc = __shfl_xor(c, 32, 64);
             const int n = tn * BN + wn * 32 * TN + j * 32 + r;
-            if (ARG) {
+            if (MODE == CM_ARG) {
                 const int oi = __shfl_xor(ci, 32, 64);
                 const bool take = oc > c || (oc == c && oi < ci);
                 if (h == 0 && n < g.N) {
@@ -584,6 +622,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 c = fmaxf(c, oc);
                 if (h == 0 && n < g.N) g.partial[((long long)tm * 2 + wm) * g.N + n] = c;
             }
+        }
         }
         if (tnext >= tend) break;
         t = tnext; tm = t % tiles_m; tn = t / tiles_m;

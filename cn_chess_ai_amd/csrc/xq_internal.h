@@ -96,7 +96,8 @@ struct Profiler {
     }
     int begin(const char* name, hipStream_t s) {
         if (!enabled) return -1;
-        if (roofline_only && strcmp(name, "gemm_qmax_rowmax") != 0 && strcmp(name, "env_selfplay_step") != 0) return -1;
+        if (roofline_only && strcmp(name, "gemm_qmax_rowmax") != 0 && strcmp(name, "gemm_qmax_screen") != 0 &&
+            strcmp(name, "env_selfplay_step") != 0) return -1;
         Rec r; r.cat = cat_id(name); r.a = get_event(); r.b = get_event();
         (void)hipEventRecord(r.a, s);
         recs.push_back(r);

@@ -173,6 +173,22 @@ def _set_precision(self, precision):
 DQN.set_precision = _set_precision
 
 
+def _set_qmax_mode(self, mode):
+    """_capi.QMAX_FULL / QMAX_SCREENED: how the TD step finds max_a' Q(s', a') (exact bf16 screening + fp32 re-evaluation)."""
+    call("xq_dqn_set_qmax_mode", self._h, int(mode))
+
+
+def _qmax_stats(self):
+    """(TD steps screened, samples, candidate (sample, group) pairs, pairs re-evaluated as whole groups); synchronises."""
+    st = (C.c_uint64 * 4)()
+    call("xq_dqn_qmax_stats", self._h, st)
+    return tuple(int(x) for x in st)
+
+
+DQN.set_qmax_mode = _set_qmax_mode
+DQN.qmax_stats = _qmax_stats
+
+
 def _set_comm(self, comm):
     """Attach an xq_comm (dist.Comm) or None: td_grads then all-reduces the gradient buffer itself, in buckets."""
     call("xq_dqn_set_comm", self._h, comm.handle if comm is not None else None)

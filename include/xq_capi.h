@@ -190,6 +190,11 @@ enum { XQ_PRECISION_F32 = 0,       /* fp32 MFMA everywhere (the reference comput
                                     * activations rounded to bf16 (RNE), fp32 accumulation, biases and outputs fp32; backward and SGD
                                     * in fp32 on the master weights */
 
+enum { XQ_QMAX_FULL = 0,           /* max_a' Q(s',a') of the TD target (chessai.cpp:126-127, dqn.cpp:166-167): every output in fp32 */
+       XQ_QMAX_SCREENED = 1 };     /* the same fp32 maximum, found by exact screening: all outputs once on the bf16 matrix pipe with a
+                                    * rigorous error bound, then only the outputs within the bound of the screened maximum again in
+                                    * fp32.  The value returned is the maximum of fp32-evaluated outputs. */
+
 /* DQN::DQN(layerSizes, lr, gamma) (dqn.cpp:12-20) -> NeuralNetwork ctor (dqn.cu:14-57): W ~ U(-0.05,0.05) from a
  * seeded generator, biases 0; target = copy of online.  layer_sizes[0] must be 1260 for the board-input fast path;
  * any sizes work through the dense-state entry points. */
@@ -199,6 +204,12 @@ int xq_dqn_destroy(xq_dqn* d);
 /* XQ_PRECISION_*: arithmetic of the forward passes on packed boards (action select, TD targets, Q(s,a)).  The dense-state entry
  * points (xq_dqn_forward / xq_dqn_backpropagate: the reference's std::vector<double> API) always compute in fp32. */
 int xq_dqn_set_precision(xq_dqn* d, int precision);
+/* XQ_QMAX_*: how the TD step finds max_a' Q(s',a').  XQ_QMAX_SCREENED applies to fp32 nets with XQ_TD_ONLINE_NET / XQ_TD_TARGET_NET
+ * whose last hidden width is a multiple of 64 and whose product is large enough for the persistent GEMM (>= 512 tiles of 128 x 128);
+ * every other case silently keeps the full fp32 product.  stats[4] (xq_dqn_qmax_stats, synchronises): TD steps screened, samples,
+ * candidate (sample, 32-output group) pairs re-evaluated in fp32, pairs whose whole group was re-evaluated. */
+int xq_dqn_set_qmax_mode(xq_dqn* d, int mode);
+int xq_dqn_qmax_stats(xq_dqn* d, uint64_t stats[4]);
 int xq_dqn_num_params(const xq_dqn* d, size_t* n_weights, size_t* n_biases);
 /* host_weights / host_biases in the REFERENCE flat layout (row-major [out][in] per layer, layers concatenated,
  * dqn.cu:112-140), fp64 like upstream.  set = copyToDevice() (dqn.cu:480-485), get = copyFromDevice() (:487-492). */

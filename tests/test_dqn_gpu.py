@@ -428,3 +428,92 @@ def test_td_targets_on_the_persistent_gemm_match_oracle(xq):
     assert len(arg) > 20 and max(arg) >= 96              # the max really ranges over all 8100 outputs
     assert np.abs(y - want_y).max() < QTOL and np.abs(qsa - want_q).max() < QTOL
     env.close(); d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes,scale", [(CFG2_NET, 3.0), (CFG2_NET, 0.2), ((1260, 128, 8100), 1.0), ((1260, 512, 512, 512, 8100), 1.0)])
+def test_screened_qmax_equals_full_product(xq, sizes, scale):
+    """xq_dqn_set_qmax_mode(XQ_QMAX_SCREENED): the TD targets are the maxima of fp32-evaluated outputs — equal to the full fp32
+    column-max GEMM up to summation order (MFMA k-order vs one fp32 fma chain per candidate) and to the oracle within QTOL.
+    Weight scales 0.2 .. 3 move the pre-activations from the linear range deep into tanh saturation; every layer has biases."""
+    from cn_chess_ai_amd import _capi
+    n = 1100
+    env = xq.VecEnv(n, seed=99)
+    for _ in range(31):
+        env.selfplay_step(None)
+    S, _ = env.get_state()
+    res = env.selfplay_step(None)
+    S2, _ = env.get_state()
+    A = (res["action"] % 90).astype(np.int32)
+    R = (res["reward"] / 100.0).astype(np.float32)
+    D = res["done"].copy()
+    D[::5] = 1
+    d, w, b = make_net(xq, sizes, seed=8)
+    wt, _ = xo.init_weights(sizes, 78)
+    wt = wt * scale
+    bt = np.random.default_rng(6).uniform(-0.3, 0.3, size=len(b))
+    d.set_params(wt, bt, net=1)
+    ys = {}
+    for mode in (_capi.QMAX_FULL, _capi.QMAX_SCREENED):
+        d.set_qmax_mode(mode)
+        qsa, y = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+        ys[mode] = (qsa.copy(), y.copy())
+    steps, samples, pairs, whole = d.qmax_stats()
+    assert steps == 1 and samples == n
+    assert pairs >= n                                         # every sample has at least its own maximum as a candidate
+    assert pairs < 64 * n                                     # ... and the screen really prunes: far fewer than the 254 groups
+    assert np.array_equal(ys[0][0], ys[1][0])                 # Q(s, a) does not depend on the mode
+    assert np.abs(ys[0][1] - ys[1][1]).max() < 2e-6
+    want_y = np.empty(n)
+    for i in range(0, n, 3):
+        if D[i]:
+            want_y[i] = float(R[i])
+        else:
+            want_y[i] = float(R[i]) + 0.99 * xo.nn_forward(sizes, wt, bt, xo.state_repr(xo.board_from(S2[i]))).max()
+    assert np.abs(ys[1][1][::3] - want_y[::3]).max() < QTOL
+    # online-net rule as well (the screen reads the online weights then), and a second step reuses the buffers
+    d.set_qmax_mode(_capi.QMAX_FULL)
+    _, y_full = d.td_update(S, S2, A, R, D, td_net=0, mode=0, learning_rate=0.0, grad_scale=1.0)
+    d.set_qmax_mode(_capi.QMAX_SCREENED)
+    _, y_scr = d.td_update(S, S2, A, R, D, td_net=0, mode=0, learning_rate=0.0, grad_scale=1.0)
+    assert np.abs(y_full - y_scr).max() < 2e-6
+    env.close(); d.close()
+
+
+@pytest.mark.gpu
+def test_screened_qmax_degenerate_outputs(xq):
+    """Worst case for the screen: every output row identical (all 8100 outputs tie) — every group is a candidate, most of them
+    as whole groups; the result must still be the fp32 maximum.  Then a net whose maximum sits in the last, partly padded group."""
+    from cn_chess_ai_amd import _capi
+    sizes = CFG2_NET
+    n = 1100
+    env = xq.VecEnv(n, seed=5)
+    for _ in range(9):
+        env.selfplay_step(None)
+    S, _ = env.get_state()
+    res = env.selfplay_step(None)
+    S2, _ = env.get_state()
+    A = (res["action"] % 90).astype(np.int32)
+    R = np.zeros(n, np.float32)
+    D = np.zeros(n, np.uint8)
+    d, w, b = make_net(xq, sizes, seed=8)
+    wt, bt0 = xo.init_weights(sizes, 79)
+    nw_out = 8100 * 256
+    wt = wt.copy(); bt = np.zeros(len(b))
+    wt[-nw_out:] = np.tile(wt[-nw_out:-nw_out + 256], 8100)          # all output rows equal
+    d.set_params(wt, bt, net=1)
+    d.set_qmax_mode(_capi.QMAX_FULL)
+    _, y_full = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+    d.set_qmax_mode(_capi.QMAX_SCREENED)
+    _, y_scr = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+    _, _, pairs, whole = d.qmax_stats()
+    assert np.abs(y_full - y_scr).max() < 2e-6
+    assert pairs >= 250 * n and whole >= 200 * n
+    # the winner is output 8099 (last row of the last, padded tile)
+    bt[-1] = 5.0
+    d.set_params(wt, bt, net=1)
+    _, y_scr = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+    d.set_qmax_mode(_capi.QMAX_FULL)
+    _, y_full = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+    assert np.abs(y_full - y_scr).max() < 2e-6 and y_scr.min() > 0.98
+    env.close(); d.close()
