@@ -14,7 +14,7 @@ runs its own 8192 games (game ids rank*8192..) and the gradient buffer is all-re
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel with HIP events recorded around each of its launches inside
 the timed region: by default (`--qmax screened`) the 8100 x 8192 x 256 bf16-MFMA screening pass of max_a' Q(s',a') (its fp32
-re-evaluation kernel follows it; DESIGN.md section 3), with `--qmax full` the fp32-MFMA column-max GEMM, which the default run
+re-evaluation kernel follows it; DESIGN.md section 4), with `--qmax full` the fp32-MFMA column-max GEMM, which the default run
 also times as `variant_qmax_full_fp32_product` (own roofline inside).  `roofline_env` does the same for the fused self-play step
 kernel (HBM-bound).  `cpu_baseline` times the CPU port of ChessAI::train (oracle) on a bounded sample.
 """
@@ -322,7 +322,7 @@ def main():
         st = t.dqn.qmax_stats()
         qmax_info = {"mode": "screened" if screened_live else "full (screen not applicable to this configuration)",
                      "what": "max_a' Q(s',a') = maximum of fp32-evaluated outputs; candidates found by a bf16 MFMA pass with a "
-                             "rigorous error bound (DESIGN.md section 3)",
+                             "rigorous error bound (DESIGN.md section 4)",
                      "candidate_groups_per_sample": (st[2] - qstat0[2]) / max(st[1] - qstat0[1], 1),
                      "whole_groups_per_sample": (st[3] - qstat0[3]) / max(st[1] - qstat0[1], 1)}
         if screened_live and world == 1:

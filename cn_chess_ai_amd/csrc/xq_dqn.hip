@@ -63,7 +63,7 @@ struct xq_dqn {
     float* sel_q90 = nullptr;
     int sel_cap = 0;
     bool small_tiles = false;                   // force 64x64 GEMM tiles (<= 80 VGPRs: fits beside the persistent GEMM)
-    // exact screening of max_a' Q(s', a') (xq_dqn_set_qmax_mode, DESIGN.md §3): bf16 copies of the output-layer weights and of
+    // exact screening of max_a' Q(s', a') (xq_dqn_set_qmax_mode, DESIGN.md §4): bf16 copies of the output-layer weights and of
     // the last hidden activations of s', the two screening partial arrays, the largest row norm of the weights, counters
     int qmax_mode = XQ_QMAX_FULL;
     uint16_t* scr_wb = nullptr;                 // [round_up(nout,128)][hlast] (rows >= nout zero)
@@ -801,20 +801,23 @@ struct SegTable {
     uint16_t* dst_bf[16];      // bf16 Q-net: shadow of dst, refreshed with the rounded new value (nullptr: none)
     int nseg;
 };
-// ---- exact screening of z_max[b] = max_j (W_out[j] . a[b] + b_out[j])  (xq_dqn_set_qmax_mode(XQ_QMAX_SCREENED), DESIGN.md §3) ------
+// ---- exact screening of z_max[b] = max_j (W_out[j] . a[b] + b_out[j])  (xq_dqn_set_qmax_mode(XQ_QMAX_SCREENED), DESIGN.md §4) ------
 // The fp32 column-max GEMM computes 8100 outputs per sample to keep one.  Screening computes all of them once on the bf16 matrix
-// pipe (16x the fp32 MFMA rate), with a rigorous bound on what bf16 operands can hide, and recomputes in fp32 only the few outputs
-// that could still be the maximum:
-//   z~_j = fl32(sum_k bf16(W_jk) bf16(a_k)) + b_j,   |z~_j - z_j| <= B := kScreenEps * ||a||_2 * max_j ||W_j||_2
-//   (round-to-nearest bf16: relative error <= 2^-8 per operand, so <= 2^-7 + 2^-16 per product; Cauchy-Schwarz over k; the fp32
-//   accumulation of K <= 1024 exact products adds <= K 2^-23; the 5-bit position tag adds 2^-18 |z~| and has its own slack term)
+// pipe (16x the fp32 MFMA rate), with a rigorous bound on what bf16 operands can hide, and re-evaluates in fp32 only the few
+// outputs that could still be the maximum.  With u = 2^-8 (round-to-nearest bf16, 8-bit significand):
+//   z~_j = fl32(sum_k bf16(W_jk) bf16(a_k)) + b_j
+//   |z~_j - z_j| <= (2u + u^2) sum_k |W_jk a_k|  [operand rounding]  +  2K 2^-23 sum_k |W_jk a_k|  [fp32 accumulation of the exact
+//                   products inside and between the MFMAs, K <= 1024]
+//               <= B := kScreenEps ||a||_2 max_j ||W_j||_2           [Cauchy-Schwarz; kScreenEps = 2^-7 * 1.0625 >= 2^-7 + 2^-16 + 2^-12]
 //   j* = argmax z_j  =>  z~_j* >= z_j* - B >= z_J - B >= z~_J - 2B with J = argmax z~: every output whose screened value is within
-//   2B of the screened maximum is a candidate and j* is among them.  The result is max over the candidates of the fp32 dot — the
-//   maximum of fp32-evaluated outputs, as before, not a bf16 quantity.
+//   2B of the screened maximum is a candidate and j* is among them.  The threshold used is m~ - 2B (1 + 2^-5) - 2^-16 (|m~| + 2B):
+//   the 2^-5 absorbs the rounding of the fp32 re-evaluation itself (<= K 2^-24 sum|W a| <= 2^-14/kScreenEps B per value), so the
+//   result is the maximum over ALL outputs of the fp32-evaluated value, not only a value close to it; the last term covers the
+//   5-bit position tag (<= 2^-18 relative at both ends).
 // Pass 1 (gemm_colmax_persistent_kernel<.., DT_BF16, CM_TOP2>) leaves, per sample and per 32-row lane group, the largest screened
-// value (tagged with its row) and the second largest.  Pass 2 below: threshold per sample, then one fp32 dot per candidate group
-// whose second value is below the threshold (the usual case), 32 dots for a group with two values above it.
-constexpr float kScreenEps = 0.0078125f * 1.04f;      // (2^-7 + 2^-16 + 1024 * 2^-23) < 2^-7 * 1.017; margin for the fp32 norm products
+// value (tagged with its row) and the second largest.  Pass 2 (qmax_refine_kernel): threshold per sample, then one fp32 dot per
+// candidate group whose second value is below the threshold (the usual case), 32 dots for a group with two values above it.
+constexpr float kScreenEps = 0.0078125f * 1.0625f;
 
 __device__ __forceinline__ int float_order_key(float f) {             // signed-int order == float order (no NaNs here)
     const int b = __builtin_bit_cast(int, f);
@@ -916,7 +919,7 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
 #pragma unroll
         for (int p = 1; p < 8; ++p) m = fmaxf(m, sv[p][sl]);
         const float B = kScreenEps * sqrtf(na[sl]) * __builtin_bit_cast(float, *wmax_bits);
-        thr[sl] = m - 2.f * B - 1.52587890625e-05f * (fabsf(m) + 2.f * B);       // 2^-16: the position tags, both ends
+        thr[sl] = m - 2.f * B * 1.03125f - 1.52587890625e-05f * (fabsf(m) + 2.f * B);
     }
     __syncthreads();
     {

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
                     if (EPI == EPI_DELTA) v = v * (1.f - hv[q] * hv[q]);
                     Cz[(long long)(mb + (q & 3) + 8 * (q >> 2)) * g.ldc + n] = v;
-                    // fp32 net: a bf16 COPY of the exact activation beside it (operand of the screening pass, DESIGN.md §3)
+                    // fp32 net: a bf16 COPY of the exact activation beside it (operand of the screening pass, DESIGN.md §4)
                     if (EPI == EPI_BIAS_TANH && g.Cb) g.Cb[(long long)(mb + (q & 3) + 8 * (q >> 2)) * g.ldcb + n] = bf16_bits(v);
                 }
             }
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // 128 rows (the callers pad their allocations, finite contents); rows beyond M never win the max (their bias is -inf in
 // LDS), columns beyond N are not stored.  Dynamic LDS: tiles_m * 128 floats (the bias vector).
 // MODE = CM_ARG: also the row index of each partial maximum (g.partial_idx; first maximum wins, see epilogue_colmax) — Double DQN.
-// MODE = CM_TOP2 (screening pass of the exact fp32 column maximum, DESIGN.md §3): no exchange between the half-waves; every lane
+// MODE = CM_TOP2 (screening pass of the exact fp32 column maximum, DESIGN.md §4): no exchange between the half-waves; every lane
 // keeps the LARGEST and the SECOND-LARGEST value of the 32 rows it holds of a column, the largest carrying its position in the low
 // five mantissa bits (code = 16 i + q; row = tile_m*128 + wm*64 + 32 i + (q&3) + 8 (q>>2) + 4 h).  partial / partial2 are
 // [tiles_m * 4][N], group = (tile_m*2 + wm)*2 + h.  Padding rows carry a bias of -3e38 (finite: tagging -inf would make a NaN).

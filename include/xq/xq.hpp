@@ -528,6 +528,7 @@ private:
         dqn->getParameters(w, b);                // continue from this agent's weights
         check(xq_dqn_set_params(td, XQ_NET_ONLINE, w.data(), b.data()));
         check(xq_dqn_update_target(td));
+        check(xq_dqn_set_qmax_mode(td, XQ_QMAX_SCREENED));    // same max_a' Q(s',a'), found by exact screening (large batches only)
         if (comm_) check(xq_trainer_set_comm(t, comm_->handle()));
         std::vector<xq_episode_record> rec(4096);
         // Every rank must run the same number of iterations (each carries a collective): the loop ends when the episodes

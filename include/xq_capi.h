@@ -193,7 +193,7 @@ enum { XQ_PRECISION_F32 = 0,       /* fp32 MFMA everywhere (the reference comput
 enum { XQ_QMAX_FULL = 0,           /* max_a' Q(s',a') of the TD target (chessai.cpp:126-127, dqn.cpp:166-167): every output in fp32 */
        XQ_QMAX_SCREENED = 1 };     /* the same fp32 maximum, found by exact screening: all outputs once on the bf16 matrix pipe with a
                                     * rigorous error bound, then only the outputs within the bound of the screened maximum again in
-                                    * fp32 (DESIGN.md section 3).  The value returned is the maximum of fp32-evaluated outputs. */
+                                    * fp32 (DESIGN.md section 4).  The value returned is the maximum of fp32-evaluated outputs. */
 
 /* DQN::DQN(layerSizes, lr, gamma) (dqn.cpp:12-20) -> NeuralNetwork ctor (dqn.cu:14-57): W ~ U(-0.05,0.05) from a
  * seeded generator, biases 0; target = copy of online.  layer_sizes[0] must be 1260 for the board-input fast path;
