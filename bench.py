@@ -185,6 +185,7 @@ def main():
                     help="diagnostic, N > 1: all-reduce through torch.distributed after learn_grads instead of the bucketed RCCL path of the C ABI")
     ap.add_argument("--qmax", choices=("screened", "full"), default="screened",
                     help="max_a' Q(s',a') of the TD target: exact bf16 screening + fp32 re-evaluation (default) or the full fp32 product")
+    ap.add_argument("--bracket-all", action="store_true", help="HIP-event bracket around EVERY launch of the dominant GEMM (default: every 4th)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="queue collect and learn on one stream (collect -> learn -> apply) instead of running collect beside learn_grads")
     args = ap.parse_args()
@@ -303,7 +304,9 @@ def main():
         return xd.max_over_ranks(el, device="cuda" if world > 1 else "cpu"), enq
 
     qstat0 = t.dqn.qmax_stats()
-    t.dqn.kernel_stats(enable=2 if args.profile_all else 3)
+    # the dominant GEMM is bracketed with HIP events on every 4th launch of the timed region (--bracket-all: every launch): a
+    # bracket is two event records, and a record drains the recording queue — ~10 us each time on a 250-us step
+    t.dqn.kernel_stats(enable=2 if args.profile_all else 3 if args.bracket_all else 4)
     elapsed, host_enqueue = timed(args.steps)
     stats = {s["name"]: s for s in t.dqn.kernel_stats(enable=0)}
     c1 = t.counters()
@@ -328,7 +331,7 @@ def main():
         if screened_live and world == 1:
             t.dqn.set_qmax_mode(_capi.QMAX_FULL)
             one_step()
-            t.dqn.kernel_stats(enable=3)
+            t.dqn.kernel_stats(enable=3 if args.bracket_all else 4)
             el_full, _ = timed(args.steps)
             full_variant = (el_full, {s["name"]: s for s in t.dqn.kernel_stats(enable=0)})
             t.dqn.set_qmax_mode(_capi.QMAX_SCREENED)
@@ -417,7 +420,9 @@ def main():
             r = {"kernel": "%s (%s: 8100 x %d x %d, %s MFMA)" % (inst, what, minibatch, LAYERS[-2], "bf16" if bf16_pipe else "f32"),
                  "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                  "frac": ach / peak, "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, offline)",
-                 "traffic_source": src, "avg_launch_ms": ms, "flops_per_launch": fl, "launches": st["launches"]}
+                 "traffic_source": src, "avg_launch_ms": ms, "flops_per_launch": fl, "launches": st["launches"],
+                 "launches_note": "HIP-event brackets inside the timed region, on " + ("every launch" if args.bracket_all or args.profile_all else
+                                  "every 4th launch (two event records per bracket drain the stream's queue, ~10 us; --bracket-all for every launch)")}
             if iso_st and iso_st["launches"]:
                 r["isolated_avg_launch_ms"] = iso_st["ms"] / iso_st["launches"]
                 r["isolated_frac"] = fl / (iso_st["ms"] / iso_st["launches"] * 1e-3) / 1e12 / peak

@@ -2207,10 +2207,12 @@ int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_st
         }
     }
     if (n_stats) *n_stats = n;
-    if (enable >= 0) {   // 0 off, 1 on, 2 on + clear, 3 on + clear, only the kernels bench.py prices (roofline leg)
+    if (enable >= 0) {   // 0 off, 1 on, 2 on + clear, 3 on + clear, only the kernels bench.py prices (roofline leg), 4 = 3 sampled 1-in-4
         if ((enable != 0) != d->prof.enabled || enable >= 2) d->prof.reset();
         d->prof.enabled = enable != 0;
-        d->prof.roofline_only = enable == 3;
+        d->prof.roofline_only = enable == 3 || enable == 4;
+        d->prof.sample_period = enable == 4 ? 4 : 1;
+        d->prof.sample_phase = 0;
     }
     return XQ_OK;
 }

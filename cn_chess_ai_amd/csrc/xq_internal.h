@@ -81,6 +81,8 @@ struct Profiler {
     std::vector<Span> spans;
     bool enabled = false;
     bool roofline_only = false;   // bracket only the two kernels bench.py prices (keeps the timed region undisturbed)
+    int sample_period = 1;        // roofline_only: bracket every sample_period-th launch of a priced kernel (an event record drains
+    int sample_phase = 0;         // the recording queue: ~10 us per bracket on a stream of 10-50 us kernels, tools/sync_probe.hip)
     std::vector<Cat> cats;
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -98,6 +100,7 @@ struct Profiler {
         if (!enabled) return -1;
         if (roofline_only && strcmp(name, "gemm_qmax_rowmax") != 0 && strcmp(name, "gemm_qmax_screen") != 0 &&
             strcmp(name, "env_selfplay_step") != 0) return -1;
+        if (roofline_only && sample_period > 1 && strcmp(name, "env_selfplay_step") != 0 && (sample_phase++ % sample_period) != 0) return -1;
         Rec r; r.cat = cat_id(name); r.a = get_event(); r.b = get_event();
         (void)hipEventRecord(r.a, s);
         recs.push_back(r);

@@ -261,7 +261,9 @@ int xq_dqn_td_update_host(xq_dqn* d, int n, const uint8_t* boards90, const uint8
 /* Sum-of-squared TD error of the last xq_dqn_td_grads (synchronises). */
 int xq_dqn_last_loss(xq_dqn* d, double* loss);
 /* Per-kernel HIP-event timing on the handle stream, for bench.py (name -> summed ms, launches, algorithmic flops/bytes).
- * enable: -1 leave, 0 off, 1 on, 2 on + clear, 3 on + clear but bracket only gemm_qmax_rowmax and env_selfplay_step. */
+ * enable: -1 leave, 0 off, 1 on, 2 on + clear, 3 on + clear but bracket only the TD step's dominant GEMM (gemm_qmax_rowmax /
+ * gemm_qmax_screen) and env_selfplay_step, 4 = 3 with the GEMM bracketed on every 4th launch only (a pair of event records
+ * drains the stream's queue: ~10 us per bracket). */
 typedef struct { char name[48]; float ms; int launches; double flops; double bytes; } xq_kernel_stat;
 int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_stats, int* n_stats);
 /* Live timeline of the brackets gathered by the last xq_dqn_kernel_stats call (enable 1/2 sessions): start/end of every
