@@ -239,7 +239,12 @@ def main():
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
     t.dqn.set_qmax_mode(_capi.QMAX_SCREENED if args.qmax == "screened" else _capi.QMAX_FULL)
     grads, comm, comm_error = None, None, ""
-    if world == 1 or args.independent:
+    if world == 1 and os.environ.get("XQ_BENCH_COMM1"):
+        # rehearsal on one GPU: a one-rank communicator attached, so that the whole N > 1 code path of the library runs (bucketed
+        # all-reduce on the communicator's stream, unfused slab reductions) — shows what that path costs besides the wire time
+        comm = xd.Comm(rank=0, world=1)
+        t.set_comm(comm)
+    elif world == 1 or args.independent:
         t.dqn.set_fused_apply(True)          # nothing reads the gradient buffer between td_grads and apply_grads
     elif args.torch_allreduce or backend != "nccl":   # diagnostic / one-GPU gloo rehearsal: the exchange through torch.distributed
         ptr, n = t.dqn.grad_buffer()

@@ -6,6 +6,7 @@
 //   2  K2 itself stores a flag at its start, B waits with hipStreamWaitValue32          (no packet on A)
 // Prints the chain time on A per iteration and when B's kernel started relative to K1's end.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -43,7 +44,8 @@ int main() {
     unsigned* flag2 = nullptr;
     if (flag) { CK(hipExtMallocWithFlags((void**)&flag2, 8, hipMallocSignalMemory)); CK(hipMemset(flag2, 0, 8)); }
     hipEvent_t evB; CK(hipEventCreateWithFlags(&evB, hipEventDisableTiming));
-    for (int variant = 0; variant < 5; ++variant) {
+    //   5  K1 launched with hipExtLaunchKernelGGL(..., stopEvent = ev): the event rides on K1's own completion signal, no marker packet
+    for (int variant = 0; variant < 6; ++variant) {
         if ((variant == 2 || variant == 3) && !flag) continue;
         for (int warm = 0; warm < 2; ++warm) {
             CK(hipDeviceSynchronize());
@@ -56,12 +58,14 @@ int main() {
                     if (variant == 3) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, B, p + 1024, 1, flag2, epoch, (unsigned long long*)nullptr);
                     else CK(hipEventRecord(evB, B));
                 }
-                hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, A, p, iters, (unsigned*)nullptr, 0u, (unsigned long long*)nullptr);   // K1
+                if (variant == 5) hipExtLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, A, nullptr, ev, 0, p, iters, (unsigned*)nullptr, 0u, (unsigned long long*)nullptr);
+                else hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, A, p, iters, (unsigned*)nullptr, 0u, (unsigned long long*)nullptr);   // K1
                 if (variant == 3 && r > 0) CK(hipStreamWaitValue32(A, flag2, epoch - 1, hipStreamWaitValueGte, 0xFFFFFFFFu));
                 if (variant == 4 && r > 0) CK(hipStreamWaitEvent(A, evB, 0));
                 if (variant == 1) { CK(hipEventRecord(ev, A)); CK(hipStreamWaitEvent(B, ev, 0)); }
+                if (variant == 5) CK(hipStreamWaitEvent(B, ev, 0));
                 if (variant == 2) CK(hipStreamWaitValue32(B, flag, epoch, hipStreamWaitValueGte, 0xFFFFFFFFu));
-                if (variant == 1 || variant == 2) hipLaunchKernelGGL(spin_kernel, dim3(64), dim3(256), 0, B, p + 512, iters, (unsigned*)nullptr, 0u, stamps + 2 * r + 1);
+                if (variant == 1 || variant == 2 || variant == 5) hipLaunchKernelGGL(spin_kernel, dim3(64), dim3(256), 0, B, p + 512, iters, (unsigned*)nullptr, 0u, stamps + 2 * r + 1);
                 for (int k = 1; k < chain; ++k)     // K2 stamps its start (= K1's end) and, variant 2, raises the flag
                     hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, A, p, iters, (k == 1 && variant == 2) ? flag : nullptr, epoch,
                                        k == 1 ? stamps + 2 * r : nullptr);
@@ -73,7 +77,7 @@ int main() {
             if (warm) {
                 printf("variant %d: %.2f us per iteration of %d kernels on stream A (%.2f us per kernel)", variant, 1e3f * ms / reps, chain,
                        1e3f * ms / reps / chain);
-                if (variant == 1 || variant == 2) {
+                if (variant == 1 || variant == 2 || variant == 5) {
                     CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
                     double sum = 0, mx = 0;
                     for (int r = 0; r < reps; ++r) { const double d = ((double)hs[2 * r + 1] - (double)hs[2 * r]) * 0.01; sum += d; if (d > mx) mx = d; }
