@@ -892,7 +892,7 @@ __device__ __forceinline__ int screen_row(int g, int code) {       // inverse of
     return (g >> 2) * 128 + ((g >> 1) & 1) * 64 + 4 * (g & 1) + (code >> 4) * 32 + (q & 3) + 8 * (q >> 2);
 }
 
-template <int KFIX>
+template <int KFIX, int NPT>                 // NPT = screened values per thread = ceil(G / 8), unrolled (32 for 8100 outputs)
 __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restrict__ P1, const float* __restrict__ P2, int G, int n,
                                                           const float* __restrict__ a_last, int K, const float* __restrict__ W,
                                                           const float* __restrict__ bias, int NO, const unsigned* __restrict__ wmax_bits,
@@ -913,12 +913,18 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
     if (tid == 0) { cnt = 0; nexp = 0; if (blockIdx.x == 0) *wmax_next = 0u; }
     if (tid < 32) best[tid] = (int)0x80000000;
     // this thread's screened values: groups phase, phase + 8, ...
-    float v[kRefineMaxPerThread];
+    // (unconditional, clamped loads: a predicate per load compiles to a branch per load)
+    float v[NPT], v2[NPT];                          // the second values too, up front: one memory round trip less
+    const int bc = min(b, n - 1);
 #pragma unroll
-    for (int u = 0; u < kRefineMaxPerThread; ++u) {
-        const int g = phase + 8 * u;
-        v[u] = (ok && g < G) ? P1[(long long)g * n + b] : kColmaxPadBias;
+    for (int u = 0; u < NPT; ++u) {
+        const int g = min(phase + 8 * u, G - 1);
+        v[u] = P1[(long long)g * n + bc];
+        v2[u] = P2[(long long)g * n + bc];
     }
+#pragma unroll
+    for (int u = 0; u < NPT; ++u)
+        if (!ok || phase + 8 * u >= G) { v[u] = kColmaxPadBias; v2[u] = kColmaxPadBias; }
     // ||a_b||^2: a quarter-wave per sample, two samples per quarter
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -929,7 +935,7 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
     }
     float m = kColmaxPadBias;
 #pragma unroll
-    for (int u = 0; u < kRefineMaxPerThread; ++u) m = fmaxf(m, v[u]);
+    for (int u = 0; u < NPT; ++u) m = fmaxf(m, v[u]);
     sv[phase][sl] = m;
     __syncthreads();
     if (tid < 32) {
@@ -937,16 +943,16 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
 #pragma unroll
         for (int p = 1; p < 8; ++p) m = fmaxf(m, sv[p][sl]);
         const float B = kScreenEps * sqrtf(na[sl]) * __builtin_bit_cast(float, *wmax_bits);
-        thr[sl] = m - 2.f * B * 1.03125f - 1.52587890625e-05f * (fabsf(m) + 2.f * B);
+        thr[sl] = b0 + sl < n ? m - 2.f * B * 1.03125f - 1.52587890625e-05f * (fabsf(m) + 2.f * B) : __builtin_inff();   // no candidates past n
     }
     __syncthreads();
     {
         const float t = thr[sl];
 #pragma unroll
-        for (int u = 0; u < kRefineMaxPerThread; ++u) {
+        for (int u = 0; u < NPT; ++u) {
             const int g = phase + 8 * u;
-            if (ok && g < G && v[u] >= t) {
-                if (P2[(long long)g * n + b] >= t) wlist[atomicAdd(&nexp, 1)] = (uint16_t)(sl | (g << 5));
+            if (v[u] >= t) {                         // padding values are far below every threshold
+                if (v2[u] >= t) wlist[atomicAdd(&nexp, 1)] = (uint16_t)(sl | (g << 5));
                 else cand[atomicAdd(&cnt, 1)] = (uint32_t)sl | ((uint32_t)screen_row(g, (int)(__builtin_bit_cast(uint32_t, v[u]) & 31u)) << 5);
             }
         }
@@ -954,23 +960,24 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
     __syncthreads();
     // fp32 dots of the candidates (the maximum does not depend on the order they are visited in)
     const int singles = cnt, wholes = nexp;
-    for (int e0 = 0; e0 < singles; e0 += 32) {                   // 16 quarters x 2 rows per round
-        float z[2];
-        int s2[2];
-        bool live[2];
+    for (int e0 = 0; e0 < singles; e0 += 64) {                   // 16 quarters x 4 rows per round, all loads of a round in flight
+        float z[4];
+        int s2[4], row[4];
+        bool live[4];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < 4; ++r) {
             const int e = e0 + quarter + 16 * r;
             live[r] = e < singles;
             const uint32_t ent = cand[live[r] ? e : 0];
             s2[r] = (int)(ent & 31u);
-            const int row = min((int)(ent >> 5), NO - 1);
-            z[r] = quarter_dot<KFIX>(a_last + (long long)(b0 + s2[r]) * K, W + (long long)row * K, K, ql);
-            z[r] = quarter_sum(z[r]) + bias[row];
+            row[r] = min((int)(ent >> 5), NO - 1);
+            z[r] = quarter_dot<KFIX>(a_last + (long long)(b0 + s2[r]) * K, W + (long long)row[r] * K, K, ql);
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < 4; ++r) {
+            z[r] = quarter_sum(z[r]) + bias[row[r]];
             if (live[r] && ql == 0) atomicMax(&best[s2[r]], float_order_key(z[r]));
+        }
     }
     for (int e = 0; e < wholes; ++e) {                           // a whole group: its 32 rows over the 16 quarters, one round
         const int ent = wlist[e];
@@ -1959,12 +1966,14 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             const dim3 grid((n + kRefineSamples - 1) / kRefineSamples);
             unsigned* w_now = d->scr_wmax + (d->scr_host_steps & 1);
             unsigned* w_next = d->scr_wmax + ((d->scr_host_steps & 1) ^ 1);
-            if (Hl == 256) hipLaunchKernelGGL(qmax_refine_kernel<256>, grid, dim3(256), lds, d->cur, d->scr_p1, d->scr_p2, G, n, touts[nl - 2], Hl,
-                                              d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, w_now, w_next, d->zmax, d->scr_stats);
-            else if (Hl == 512) hipLaunchKernelGGL(qmax_refine_kernel<512>, grid, dim3(256), lds, d->cur, d->scr_p1, d->scr_p2, G, n, touts[nl - 2], Hl,
-                                                   d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, w_now, w_next, d->zmax, d->scr_stats);
-            else hipLaunchKernelGGL(qmax_refine_kernel<0>, grid, dim3(256), lds, d->cur, d->scr_p1, d->scr_p2, G, n, touts[nl - 2], Hl,
-                                    d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, w_now, w_next, d->zmax, d->scr_stats);
+            auto launch = [&](auto kern) {
+                hipLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, d->scr_p1, d->scr_p2, G, n, touts[nl - 2], Hl, d->wl(sel_net, nl - 1),
+                                   d->bl(sel_net, nl - 1), NO, w_now, w_next, d->zmax, d->scr_stats);
+            };
+            const bool small = G <= 8 * 32;
+            if (Hl == 256) { if (small) launch(qmax_refine_kernel<256, 32>); else launch(qmax_refine_kernel<256, 64>); }
+            else if (Hl == 512) { if (small) launch(qmax_refine_kernel<512, 32>); else launch(qmax_refine_kernel<512, 64>); }
+            else { if (small) launch(qmax_refine_kernel<0, 32>); else launch(qmax_refine_kernel<0, 64>); }
             XQ_HIP(hipGetLastError());
         }
         d->scr_host_steps += 1; d->scr_host_samples += (unsigned long long)n;
