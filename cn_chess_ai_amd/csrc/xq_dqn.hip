@@ -72,6 +72,15 @@ struct xq_dqn {
     unsigned* scr_wmax = nullptr;               // bits of max_j ||W_out[j]||_2 (non-negative floats order like unsigned)
     unsigned long long* scr_stats = nullptr;    // [4] TD steps, samples, candidate (sample, group) pairs, pairs recomputed as whole groups
     unsigned long long scr_host_steps = 0, scr_host_samples = 0;
+    // guard: every kScreenCheckEvery screened steps the candidate counters come back asynchronously; a net that leaves the screen too
+    // many candidates (outputs all within the bf16 bound of each other) gets the full product for the next kScreenHoldSteps steps
+    unsigned long long* scr_guard_host = nullptr;      // pinned copy of scr_stats
+    hipEvent_t scr_guard_ev = nullptr;
+    bool scr_guard_pending = false;
+    unsigned long long scr_guard_samples = 0;          // scr_host_samples when the pending copy was queued
+    unsigned long long scr_seen[3] = {0, 0, 0};        // samples, pairs, whole groups at the last evaluation
+    int scr_hold = 0;                                  // > 0: that many TD steps still run the full product
+    unsigned long long scr_fallbacks = 0;
     float* partial = nullptr;                   // row-max partials
     float* zmax = nullptr;  int* zidx = nullptr;    // [kReduceParts][cap] their reduction per sample (colmax_reduce_kernel)
     float* qsa = nullptr;
@@ -836,6 +845,9 @@ struct SegTable {
 // value (tagged with its row) and the second largest.  Pass 2 (qmax_refine_kernel): threshold per sample, then one fp32 dot per
 // candidate group whose second value is below the threshold (the usual case), 32 dots for a group with two values above it.
 constexpr float kScreenEps = 0.0078125f * 1.0625f;
+enum { kScreenCheckEvery = 32, kScreenHoldSteps = 512 };
+constexpr double kScreenMaxPairs = 24.0, kScreenMaxWhole = 1.0;     // candidate groups / whole groups per sample above which the
+                                                                    // fp32 re-evaluation costs more than the product it replaces
 
 __device__ __forceinline__ int float_order_key(float f) {             // signed-int order == float order (no NaNs here)
     const int b = __builtin_bit_cast(int, f);
@@ -1189,6 +1201,9 @@ static int ensure_screen_capacity(xq_dqn* d, int n) {
         XQ_HIP(hipMemset(d->scr_wmax, 0, 2 * sizeof(unsigned)));
         XQ_HIP(hipMalloc(&d->scr_stats, 4 * sizeof(unsigned long long)));
         XQ_HIP(hipMemset(d->scr_stats, 0, 4 * sizeof(unsigned long long)));
+        XQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->scr_guard_host), 4 * sizeof(unsigned long long), hipHostMallocDefault));
+        memset(d->scr_guard_host, 0, 4 * sizeof(unsigned long long));
+        XQ_HIP(hipEventCreateWithFlags(&d->scr_guard_ev, hipEventDisableTiming));
     }
     if (n > d->scr_cap) {
         XQ_HIP(hipDeviceSynchronize());
@@ -1612,6 +1627,8 @@ int xq_dqn_destroy(xq_dqn* d) {
     if (d->ev_l0) hipEventDestroy(d->ev_l0);
     for (void* q : {(void*)d->scr_wb, (void*)d->scr_ab, (void*)d->scr_p1, (void*)d->scr_p2, (void*)d->scr_wmax, (void*)d->scr_stats})
         if (q) hipFree(q);
+    if (d->scr_guard_host) hipHostFree(d->scr_guard_host);
+    if (d->scr_guard_ev) hipEventDestroy(d->scr_guard_ev);
     if (d->own_stream) hipStreamDestroy(d->stream);
     delete d;
     return XQ_OK;
@@ -1671,6 +1688,7 @@ static int refresh_shadow(xq_dqn* d, int net) {
 int xq_dqn_set_qmax_mode(xq_dqn* d, int mode) {
     if (!d || (mode != XQ_QMAX_FULL && mode != XQ_QMAX_SCREENED)) return fail(XQ_ERR_INVALID_ARGUMENT, "bad qmax mode");
     d->qmax_mode = mode;
+    d->scr_hold = 0;                       // an explicit request starts with the screen switched on again
     return XQ_OK;
 }
 
@@ -1925,10 +1943,27 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     const bool big_tiles = (long long)((NO + 127) / 128) * ((n + 127) / 128) >= 512;
     const int n_partial = 2 * (big_tiles ? (NO + 127) / 128 : (NO + 63) / 64);
     const size_t bias_lds_all = (size_t)((NO + 127) / 128) * 128 * sizeof(float);
-    const bool screened = d->qmax_mode == XQ_QMAX_SCREENED && !bf && !dbl && big_tiles && (Hl % 64) == 0 && Hl <= 1024 &&
+    const bool want_screen = d->qmax_mode == XQ_QMAX_SCREENED && !bf && !dbl && big_tiles && (Hl % 64) == 0 && Hl <= 1024 &&
                           bias_lds_all <= 40 * 1024 && (NO + 127) / 128 * 4 <= 8 * kRefineMaxPerThread;
+    bool screened = want_screen;
     if (screened) {
         XQ_TRY(ensure_screen_capacity(d, n));
+        bool arrived = false;
+        if (d->scr_guard_pending) {
+            arrived = hipEventQuery(d->scr_guard_ev) == hipSuccess;
+            if (!arrived) (void)hipGetLastError();           // hipErrorNotReady is an answer, not a failure
+        }
+        if (arrived) {
+            d->scr_guard_pending = false;
+            const unsigned long long* h = d->scr_guard_host;
+            const double ds = (double)(d->scr_guard_samples - d->scr_seen[0]);
+            if (ds > 0 && ((double)(h[2] - d->scr_seen[1]) > kScreenMaxPairs * ds || (double)(h[3] - d->scr_seen[2]) > kScreenMaxWhole * ds)) {
+                d->scr_hold = kScreenHoldSteps;
+                d->scr_fallbacks += 1;
+            }
+            d->scr_seen[0] = d->scr_guard_samples; d->scr_seen[1] = h[2]; d->scr_seen[2] = h[3];
+        }
+        if (d->scr_hold > 0) { --d->scr_hold; screened = false; }
     }
     // bf16 copy + largest row norm of the selecting net's output-layer weights (they change with every SGD step); the norm lands
     // in slot `screened steps & 1`, which the refine kernel of the previous screened step zeroed
@@ -1977,6 +2012,12 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             XQ_HIP(hipGetLastError());
         }
         d->scr_host_steps += 1; d->scr_host_samples += (unsigned long long)n;
+        if (d->scr_host_steps % kScreenCheckEvery == 0 && !d->scr_guard_pending) {
+            XQ_HIP(hipMemcpyAsync(d->scr_guard_host, d->scr_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d->cur));
+            XQ_HIP(hipEventRecord(d->scr_guard_ev, d->cur));
+            d->scr_guard_pending = true;
+            d->scr_guard_samples = d->scr_host_samples;
+        }
         zparts = 1;
     } else {
     {

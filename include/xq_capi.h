@@ -206,8 +206,11 @@ int xq_dqn_destroy(xq_dqn* d);
 int xq_dqn_set_precision(xq_dqn* d, int precision);
 /* XQ_QMAX_*: how the TD step finds max_a' Q(s',a').  XQ_QMAX_SCREENED applies to fp32 nets with XQ_TD_ONLINE_NET / XQ_TD_TARGET_NET
  * whose last hidden width is a multiple of 64 and whose product is large enough for the persistent GEMM (>= 512 tiles of 128 x 128);
- * every other case silently keeps the full fp32 product.  stats[4] (xq_dqn_qmax_stats, synchronises): TD steps screened, samples,
- * candidate (sample, 32-output group) pairs re-evaluated in fp32, pairs whose whole group was re-evaluated. */
+ * every other case silently keeps the full fp32 product.  Guard: every 32 screened steps the candidate counters are read back
+ * asynchronously; when the screen leaves more than 24 candidate groups (or 1 whole group) per sample — a net whose outputs all lie
+ * within the bf16 bound of each other — the next 512 TD steps run the full product, then the screen is tried again.  stats[4]
+ * (xq_dqn_qmax_stats, synchronises): TD steps screened, samples, candidate (sample, 32-output group) pairs re-evaluated in fp32,
+ * pairs whose whole group was re-evaluated. */
 int xq_dqn_set_qmax_mode(xq_dqn* d, int mode);
 int xq_dqn_qmax_stats(xq_dqn* d, uint64_t stats[4]);
 int xq_dqn_num_params(const xq_dqn* d, size_t* n_weights, size_t* n_biases);

@@ -509,6 +509,14 @@ def test_screened_qmax_degenerate_outputs(xq):
     _, _, pairs, whole = d.qmax_stats()
     assert np.abs(y_full - y_scr).max() < 2e-6
     assert pairs >= 250 * n and whole >= 200 * n
+    # guard: a net like this one is detected after 32 screened steps (asynchronous read-back of the counters) and the following
+    # steps run the full product — same results, and the screened-step counter stops
+    for _ in range(40):
+        _, y_again = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+    steps_screened = d.qmax_stats()[0]
+    assert 32 <= steps_screened <= 36, steps_screened
+    assert np.abs(y_again - y_full).max() < 2e-6
+    d.set_qmax_mode(_capi.QMAX_SCREENED)                                # an explicit request switches the screen back on
     # the winner is output 8099 (last row of the last, padded tile)
     bt[-1] = 5.0
     d.set_params(wt, bt, net=1)

@@ -294,3 +294,34 @@ def test_overlapped_trainer_mixed_call_order(xq):
     assert np.array_equal(boards, tboards) and np.array_equal(meta, tmeta)
     assert np.array_equal(w, tw) and np.array_equal(b, tb)
     t.close(); env.close(); d.close(); rp.close()
+
+
+def test_screened_qmax_in_the_overlapped_trainer(xq):
+    """xq_dqn_set_qmax_mode(XQ_QMAX_SCREENED) inside the real loop (BASELINE configs[1] at full size: 8192 games, three streams,
+    replay sampling, target syncs): (1) a rerun is bit-identical — the screen has no float atomics and no order dependence;
+    (2) the trained weights stay within float rounding of the trainer that runs the full fp32 product (the TD targets are the
+    same fp32 maxima up to summation order); (3) the screen really prunes (a handful of candidate groups per sample)."""
+    from cn_chess_ai_amd import _capi
+
+    def run(mode, iters=6):
+        cfg = xq.TrainerConfig(n_games=8192, layer_sizes=CFG2_NET, replay_capacity=1 << 16, minibatch=8192, target_sync_interval=3,
+                               td_net=0, overlap_collect=1, seed=0x5EED, mean_gradient=1)
+        t = xq.Trainer(cfg)
+        t.dqn.set_qmax_mode(mode)
+        t.random_plies(60)
+        for _ in range(8):
+            t.collect()
+        t.step(iters)
+        w, b = t.dqn.get_params()
+        st = t.dqn.qmax_stats()
+        c = t.counters()
+        loss = t.dqn.last_loss()
+        t.close()
+        return w, b, st, c, loss
+    w_s, b_s, st, c, loss_s = run(_capi.QMAX_SCREENED)
+    w_s2, b_s2, st2, c2, loss_s2 = run(_capi.QMAX_SCREENED)
+    assert np.array_equal(w_s, w_s2) and np.array_equal(b_s, b_s2) and st == st2 and c == c2 and loss_s == loss_s2
+    assert st[0] == 6 and st[1] == 6 * 8192 and 1.0 <= st[2] / st[1] < 16.0
+    w_f, b_f, st_f, c_f, loss_f = run(_capi.QMAX_FULL)
+    assert st_f[0] == 0 and c_f == c
+    assert np.abs(w_s - w_f).max() < 1e-7 and np.abs(b_s - b_f).max() < 1e-7 and abs(loss_s - loss_f) < 1e-4 * abs(loss_f)
