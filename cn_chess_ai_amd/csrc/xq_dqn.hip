@@ -356,6 +356,13 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
     }
 }
 
+// block -> square: the squares of the start position first.  A block's run time grows with the number of samples that have a piece on
+// its square (a home square of the back rank: nearly all of them; a square in the middle of the board: a few per cent) and the grid
+// runs in two rounds of blocks (59 KB of LDS: two per CU) — the long blocks must be in the first round, or the kernel ends with a
+// few of them running alone (device timestamps in the training loop: 36.5 us from first block start to last block end with the
+// squares in board order, 28.1 us in this order; per block 1.5 us loads + 1.8 compaction + 6.9 streaming (mean) + 2.5 output)
+__constant__ unsigned char kL0SquareOrder[90] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 19, 25, 27, 29, 31, 33, 35, 54, 56, 58, 60, 62, 64, 70, 81, 82, 83, 84, 85, 86, 87, 88, 89, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 21, 22, 23, 24, 26, 28, 30, 32, 34, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 55, 57, 59, 61, 63, 65, 66, 67, 68, 69, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80};
+
 // Layer-0 weight gradient gW0^T[(sq,piece)][:] = sum over the samples that have `piece` on `sq` of delta_0[sample][:]
 // (the one-hot input of chessai.cpp:268-289 transposed).  A dense one-hot GEMM would spend 2*1260*H FLOP per sample on
 // zeros; here block (sq, chunk) compacts the samples of its chunk that occupy `sq` (ascending sample order, so the sums
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
     // workgroups go to the 8 XCDs round-robin in linear order: chunk = linear id mod nchunks keeps all 90 square-blocks of a chunk
     // (they stream the same 1 MB of delta rows, each up to 32 times) behind one XCD's L2 when there are 8 chunks
     const int lin = (int)(blockIdx.x + gridDim.x * blockIdx.y), nch = (int)gridDim.y;
-    const int s = lin / nch;
+    const int s = kL0SquareOrder[lin / nch];
     const int c0 = (lin % nch) * chunk;
     const int c1 = min(n, c0 + chunk);
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -379,8 +386,9 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
 #pragma unroll
     for (int it = 0; it < kMaxIters; ++it) {
         const int b = c0 + it * 256 + tid;
-        uint32_t nib = 0;
-        if (b < c1) nib = (gboards[(long long)b * kBoardWords + (s >> 3)] >> (4 * (s & 7))) & 15u;
+        // (unconditional, clamped: a predicated load compiles to a branch with its own wait, one memory round trip per load)
+        uint32_t nib = (gboards[(long long)min(b, c1 - 1) * kBoardWords + (s >> 3)] >> (4 * (s & 7))) & 15u;
+        if (b >= c1) nib = 0;
         nibs |= nib << (4 * it);
     }
     if (((nsets * 14 * H) & 3) == 0) {
@@ -657,9 +665,8 @@ __global__ __launch_bounds__(256) void out_grad_kernel(const int32_t* __restrict
 #pragma unroll
     for (int it = 0; it < kMaxIters; ++it) {
         const int b = c0 + it * 256 + tid;
-        int cls = -1;
-        if (b < c1) { const int a = act[b]; if (a >= 4 * g && a < 4 * g + 4) cls = a - 4 * g; }
-        clsv[it] = cls;
+        const int a = act[min(b, c1 - 1)];                // unconditional, clamped (see l0_grad_kernel)
+        clsv[it] = (b < c1 && a >= 4 * g && a < 4 * g + 4) ? a - 4 * g : -1;
     }
     for (int i = tid; i < 16 * H; i += 256) acc[i] = 0.f;
 #pragma unroll

@@ -59,18 +59,12 @@ int main() {
     struct Var { const char* name; long long p_bytes; int p_spin; int p_grid; int s_lds; int s_grid; int s_sigarg; int other; int store_mode; int alloc; };
     // other: 0 idle, 1 B blocked in hipStreamWaitValue32 (released at the end), 2 B runs spin kernels concurrently
     const Var vars[] = {
-        {"tiny P (256 blocks) -> tiny S", 0, 300, 256, 0, 256, 0, 0, 0, 0},
-        {"tiny P (2048 blocks) -> tiny S", 0, 300, 2048, 0, 256, 0, 0, 0, 0},
-        {"P writes 512 KB -> tiny S", 512 << 10, 0, 1024, 0, 256, 0, 0, 0, 0},
-        {"P writes 2 MB -> tiny S", 2 << 20, 0, 1024, 0, 256, 0, 0, 0, 0},
-        {"P writes 16 MB -> tiny S", 16 << 20, 0, 1024, 0, 256, 0, 0, 0, 0},
-        {"P writes 16 MB nontemporal -> tiny S", 16 << 20, 0, 1024, 0, 256, 0, 0, 1, 0},
-        {"P writes 16 MB (UNCACHED allocation) -> tiny S", 16 << 20, 0, 1024, 0, 256, 0, 0, 0, 1},
-        {"P writes 16 MB + spins 20 us first -> tiny S", 16 << 20, 2500, 1024, 0, 256, 0, 0, 0, 0},
-        {"tiny P -> S with 60 KB LDS, 720 blocks", 0, 300, 256, 60 * 1024, 720, 0, 0, 0, 0},
-        {"tiny P -> S takes a signal-memory pointer", 0, 300, 256, 0, 256, 1, 0, 0, 0},
-        {"tiny P -> tiny S, stream B blocked in a wait", 0, 300, 256, 0, 256, 0, 1, 0, 0},
-        {"tiny P -> tiny S, stream B running kernels", 0, 300, 256, 0, 256, 0, 2, 0, 0},
+        {"tiny P -> S 720 blocks, no LDS", 0, 300, 256, 0, 720, 0, 0, 0, 0},
+        {"tiny P -> S 720 blocks, 16 KB LDS", 0, 300, 256, 16 * 1024, 720, 0, 0, 0, 0},
+        {"tiny P -> S 720 blocks, 32 KB LDS", 0, 300, 256, 32 * 1024, 720, 0, 0, 0, 0},
+        {"tiny P -> S 720 blocks, 60 KB LDS", 0, 300, 256, 60 * 1024, 720, 0, 0, 0, 0},
+        {"tiny P -> S 512 blocks, 60 KB LDS", 0, 300, 256, 60 * 1024, 512, 0, 0, 0, 0},
+        {"tiny P -> S 1440 blocks, 30 KB LDS", 0, 300, 256, 30 * 1024, 1440, 0, 0, 0, 0},
     };
     for (const Var& v : vars) {
         CK(hipMemset(st, 0, sizeof(Stamps) * 2 * reps));
@@ -93,13 +87,15 @@ int main() {
         std::vector<unsigned long long> he((size_t)kMaxGrid * 2 * reps);
         CK(hipMemcpy(he.data(), ends, sizeof(unsigned long long) * he.size(), hipMemcpyDeviceToHost));
         for (int k = 0; k < 2 * reps; ++k) { unsigned long long m = 0; for (int b = 0; b < kMaxGrid; ++b) m = std::max(m, he[(size_t)k * kMaxGrid + b]); h[k].end = m; }
-        std::vector<double> gaps, gaps2, pd;
+        std::vector<double> gaps, gaps2, pd, sd;
         for (int r = 5; r < reps; ++r) {
             gaps.push_back(((double)h[2 * r + 1].start - (double)h[2 * r].end) * 0.01);
             gaps2.push_back(((double)h[2 * r].start - (double)h[2 * r - 1].end) * 0.01);
             pd.push_back(((double)h[2 * r].end - (double)h[2 * r].start) * 0.01);
+            sd.push_back(((double)h[2 * r + 1].end - (double)h[2 * r + 1].start) * 0.01);
         }
-        std::sort(gaps.begin(), gaps.end()); std::sort(gaps2.begin(), gaps2.end()); std::sort(pd.begin(), pd.end());
+        std::sort(gaps.begin(), gaps.end()); std::sort(gaps2.begin(), gaps2.end()); std::sort(pd.begin(), pd.end()); std::sort(sd.begin(), sd.end());
+        printf("   S runs %6.1f us   ", sd[sd.size() / 2]);
         printf("%-58s gap P->S median %6.2f us (max %6.2f)   S->next P %6.2f us   P runs %6.1f us\n", v.name, gaps[gaps.size() / 2], gaps.back(),
                gaps2[gaps2.size() / 2], pd[pd.size() / 2]);
     }
