@@ -1,0 +1,109 @@
+// tools/bf16_probe.hip — what bounds the bf16 tile family? (diagnostic, not part of libxqhip)
+// LDS -> fragment -> v_mfma_f32_32x32x16_bf16 loops of tile_mma<.., DT_BF16> with different wave tiles, no global traffic:
+//   (TM, TN) = wave tile (32 TM) x (32 TN); block = 2 x 2 waves; `restage` adds the ds_write_b128 restaging + two barriers per k-tile.
+// Prints TFLOP/s at 2 blocks per CU (or 1 when the accumulators need it).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "../cn_chess_ai_amd/csrc/xq_gemm.hip.h"
+using namespace xq;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <int TM, int TN, int RESTAGE>
+__global__ __launch_bounds__(256) void probe(float* out, int iters, GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* As = sm;
+    float* Bs = sm + g_tile_floats(BM);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < g_tile_floats(BM); i += 256) As[i] = 0.001f * (i % 97);
+    for (int i = tid; i < g_tile_floats(BN); i += 256) Bs[i] = 0.002f * (i % 89);
+    __syncthreads();
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    float4 va[BM / 32], vb[BN / 32];
+    for (int j = 0; j < BM / 32; ++j) va[j] = make_float4(1.f, 2.f, 3.f, 4.f);
+    for (int j = 0; j < BN / 32; ++j) vb[j] = make_float4(1.f, 2.f, 3.f, 4.f);
+    const int tiles_m = g.M / BM, tiles_n = g.N / BN;
+    int tm = blockIdx.x % tiles_m, tn = (blockIdx.x / tiles_m) % tiles_n;
+    const int ksteps = g.K / GBK;                    // k-tiles per output tile (K counts bf16 pairs)
+    float m1 = 0.f, m2 = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        if (RESTAGE) {
+            __syncthreads();
+            stage_store<L_KCONTIG, BM>(As, va);
+            stage_store<L_KCONTIG, BN>(Bs, vb);
+            __syncthreads();
+        }
+        if (RESTAGE >= 2) {                          // next k-tile's operands from global memory (L2-resident panels)
+            const int k0 = ((it + 1) % ksteps) * GBK;
+            if (k0 == 0) { tm = (tm + 7) % tiles_m; if (tm < 7) tn = (tn + 1) % tiles_n; }
+            stage_load<L_KCONTIG, BM, true>(g, g.A, g.lda, 1, tm * BM, g.M, k0, g.K, va);
+            stage_load<L_KCONTIG, BN, true>(g, g.B, g.ldb, 1, tn * BN, g.N, k0, g.K, vb);
+        }
+        tile_mma<L_KCONTIG, L_KCONTIG, BM, BN, TM, TN, DT_BF16>(As, Bs, wid >> 1, wid & 1, r, h, acc);
+        if (RESTAGE >= 3 && (it % ksteps) == ksteps - 1) {      // top-2 epilogue (tag + med3 + max per value) and accumulator reset
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const uint32_t bits = __builtin_bit_cast(uint32_t, acc[i][j][q] + 0.25f);
+                        const float v = __builtin_bit_cast(float, (bits & ~63u) | (uint32_t)(i * 16 + q));
+                        m2 = __builtin_amdgcn_fmed3f(m1, m2, v);
+                        m1 = fmaxf(m1, v);
+                        acc[i][j][q] = 0.f;
+                    }
+                if (RESTAGE >= 4) {                  // + the two partial stores per column
+                    const int n = tn * BN + (wid & 1) * 32 * TN + j * 32 + r;
+                    g.partial[(long long)((tm * 2 + (wid >> 1)) * 2 + h) * g.N + n] = m1;
+                    g.partial2[(long long)((tm * 2 + (wid >> 1)) * 2 + h) * g.N + n] = m2;
+                }
+            }
+        }
+    }
+    if (m1 + m2 == 12345.f) out[tid] = m1;
+    float s = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int q = 0; q < 16; ++q) s += acc[i][j][q];
+    if (s == 12345.f) out[tid] = s;
+}
+
+template <int TM, int TN, int RESTAGE>
+static void run(const char* name, int grid, float* o, const GemmArgs& g) {
+    const size_t lds = (size_t)(g_tile_floats(64 * TM) + g_tile_floats(64 * TN)) * 4;
+    CK(hipFuncSetAttribute((const void*)probe<TM, TN, RESTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int iters = 2048;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL((probe<TM, TN, RESTAGE>), dim3(grid), dim3(256), lds, 0, o, iters, g);
+    hipEventRecord(a, 0);
+    hipLaunchKernelGGL((probe<TM, TN, RESTAGE>), dim3(grid), dim3(256), lds, 0, o, iters, g);
+    hipLaunchKernelGGL((probe<TM, TN, RESTAGE>), dim3(grid), dim3(256), lds, 0, o, iters, g);
+    hipEventRecord(b, 0); CK(hipEventSynchronize(b));
+    float ms = 0; hipEventElapsedTime(&ms, a, b); ms /= 2;
+    const double f = (double)grid * 4 * iters * (TM * TN * 4) * 32768.0;       // 4 waves, 4 chunks per k-tile, 32x32x16 MFMA
+    printf("%-46s grid %4d  LDS %5.1f KB/block: %7.1f TFLOP/s\n", name, grid, lds / 1024.0, f / ms / 1e9);
+}
+
+int main() {
+    float* o; CK(hipMalloc(&o, 4096));
+    const int M = 8192, N = 8192, K = 128;           // K in bf16 pairs = 256 bf16
+    float *A, *B, *P1, *P2;
+    CK(hipMalloc(&A, (size_t)M * K * 4)); CK(hipMalloc(&B, (size_t)N * K * 4));
+    CK(hipMemset(A, 0, (size_t)M * K * 4)); CK(hipMemset(B, 0, (size_t)N * K * 4));
+    CK(hipMalloc(&P1, (size_t)4 * (M / 128) * N * 4)); CK(hipMalloc(&P2, (size_t)4 * (M / 128) * N * 4));
+    GemmArgs g; memset(&g, 0, sizeof g);
+    g.M = M; g.N = N; g.K = K; g.A = A; g.lda = K; g.B = B; g.ldb = K; g.partial = P1; g.partial2 = P2; g.a_vec = g.b_vec = 1; g.k_chunk = K;
+    run<2, 2, 0>("64x64 wave tile, fragment reads only", 512, o, g);
+    run<2, 2, 1>("64x64 wave tile, + restage + 2 barriers", 512, o, g);
+    run<2, 2, 2>("64x64 wave tile, + global operand loads", 512, o, g);
+    run<2, 2, 3>("64x64 wave tile, + top-2 epilogue every 4 k-tiles", 512, o, g);
+    run<2, 2, 4>("64x64 wave tile, + partial stores", 512, o, g);
+    run<4, 2, 1>("128x64 wave tile, + restage + 2 barriers", 512, o, g);
+    run<4, 2, 2>("128x64 wave tile, + global operand loads", 512, o, g);
+    run<4, 2, 3>("128x64 wave tile, + top-2 epilogue every 4 k-tiles", 512, o, g);
+    run<2, 4, 2>("64x128 wave tile, + global operand loads", 512, o, g);
+    run<2, 4, 3>("64x128 wave tile, + top-2 epilogue every 4 k-tiles", 512, o, g);
+    return 0;
+}
