@@ -42,21 +42,35 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, GemmArgs g) 
             stage_load<L_KCONTIG, BM, true>(g, g.A, g.lda, 1, tm * BM, g.M, k0, g.K, va);
             stage_load<L_KCONTIG, BN, true>(g, g.B, g.ldb, 1, tn * BN, g.N, k0, g.K, vb);
         }
-        tile_mma<L_KCONTIG, L_KCONTIG, BM, BN, TM, TN, DT_BF16>(As, Bs, wid >> 1, wid & 1, r, h, acc);
-        if (RESTAGE >= 3 && (it % ksteps) == ksteps - 1) {      // top-2 epilogue (tag + med3 + max per value) and accumulator reset
+        if (RESTAGE == 6 && (it % ksteps) == 0) {    // what the library does now: the tile's first MFMAs take the bias as C operand
+            f32x16 cinit[TM];
+            const float* bi = As + (wid >> 1) * 32 * TM + 4 * h;       // any LDS floats will do for the probe
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 x = *reinterpret_cast<const float4*>(bi + i * 32 + 8 * gq);
+                    cinit[i][4 * gq] = x.x; cinit[i][4 * gq + 1] = x.y; cinit[i][4 * gq + 2] = x.z; cinit[i][4 * gq + 3] = x.w;
+                }
+            tile_mma<L_KCONTIG, L_KCONTIG, BM, BN, TM, TN, DT_BF16, true>(As, Bs, wid >> 1, wid & 1, r, h, acc, cinit);
+        } else {
+            tile_mma<L_KCONTIG, L_KCONTIG, BM, BN, TM, TN, DT_BF16>(As, Bs, wid >> 1, wid & 1, r, h, acc);
+        }
+        if (RESTAGE >= 3 && (it % ksteps) == ksteps - 1) {
+            if (RESTAGE == 6) { m1 = -3e38f; m2 = -3e38f; }      // top-2 epilogue (tag + med3 + max per value) and accumulator reset
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        const uint32_t bits = __builtin_bit_cast(uint32_t, acc[i][j][q] + 0.25f);
+                        const uint32_t bits = __builtin_bit_cast(uint32_t, RESTAGE >= 5 ? acc[i][j][q] : acc[i][j][q] + 0.25f);
                         const float v = __builtin_bit_cast(float, (bits & ~63u) | (uint32_t)(i * 16 + q));
                         m2 = __builtin_amdgcn_fmed3f(m1, m2, v);
                         m1 = fmaxf(m1, v);
-                        acc[i][j][q] = 0.f;
+                        if (RESTAGE < 5) acc[i][j][q] = 0.f;
                     }
-                if (RESTAGE >= 4) {                  // + the two partial stores per column
+                if (RESTAGE == 4 || RESTAGE == 6) {  // + the two partial stores per column
                     const int n = tn * BN + (wid & 1) * 32 * TN + j * 32 + r;
                     g.partial[(long long)((tm * 2 + (wid >> 1)) * 2 + h) * g.N + n] = m1;
                     g.partial2[(long long)((tm * 2 + (wid >> 1)) * 2 + h) * g.N + n] = m2;
@@ -100,6 +114,8 @@ int main() {
     run<2, 2, 2>("64x64 wave tile, + global operand loads", 512, o, g);
     run<2, 2, 3>("64x64 wave tile, + top-2 epilogue every 4 k-tiles", 512, o, g);
     run<2, 2, 4>("64x64 wave tile, + partial stores", 512, o, g);
+    run<2, 2, 5>("64x64 wave tile, 3-op epilogue (no add, no reset)", 512, o, g);
+    run<2, 2, 6>("64x64 wave tile, C-init from LDS + 3-op epilogue + stores", 512, o, g);
     run<4, 2, 1>("128x64 wave tile, + restage + 2 barriers", 512, o, g);
     run<4, 2, 2>("128x64 wave tile, + global operand loads", 512, o, g);
     run<4, 2, 3>("128x64 wave tile, + top-2 epilogue every 4 k-tiles", 512, o, g);
