@@ -228,6 +228,8 @@ struct L0Jobs {
     uint16_t* out_bf[kMaxChains];            // bf16 Q-net: bf16 bits of the activations
     uint32_t* gathered[kMaxChains];
     int njobs;
+    int derive_next;                         // 1: job 0's waves also produce job 1 (s' = s after one move, SAME net) from their own layer-0 sums:
+                                             // z1(s') = z1(s) - rows of the squares that changed + rows of what stands there now
     ShadowJob shadow;                        // W != nullptr: the blocks of grid row y == njobs convert the screening shadow (no extra launch)
 };
 
@@ -267,6 +269,31 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // s' from s: the squares whose piece code differs (a move changes two), in ascending order, as (row to take out, row to put in);
+    // boards that are not a move apart (an unused slot, a foreign pair) get the full row list of s' instead
+    __shared__ int dpair[4][8][2];
+    __shared__ int rows2[4][96];
+    int nd = -1, cnt2 = 0;                                // nd = -1: nothing derived here; nd > 8: cnt2 rows in rows2
+    if (!BF16 && J.derive_next) {
+        const uint32_t* bw2 = J.boards[1] + (long long)srow * kBoardWords;
+        const uint32_t p0 = (bw2[s0 >> 3] >> (4 * (s0 & 7))) & 15u;
+        const uint32_t p1 = s1 < kSquares ? (bw2[s1 >> 3] >> (4 * (s1 & 7))) & 15u : 0u;
+        const unsigned long long d0 = __ballot(p0 != n0), d1 = __ballot(p1 != n1);
+        nd = __popcll(d0) + __popcll(d1);
+        if (nd <= 8) {
+            if (p0 != n0) { const int k = __popcll(d0 & below); dpair[wid][k][0] = n0 ? s0 * 14 + (int)n0 - 1 : -1; dpair[wid][k][1] = p0 ? s0 * 14 + (int)p0 - 1 : -1; }
+            if (p1 != n1) { const int k = __popcll(d0) + __popcll(d1 & below); dpair[wid][k][0] = n1 ? s1 * 14 + (int)n1 - 1 : -1; dpair[wid][k][1] = p1 ? s1 * 14 + (int)p1 - 1 : -1; }
+        } else {
+            const unsigned long long q0 = __ballot(p0 != 0), q1 = __ballot(p1 != 0);
+            const int e0 = __popcll(q0);
+            if (p0) rows2[wid][__popcll(q0 & below)] = s0 * 14 + (int)p0 - 1;
+            if (p1) rows2[wid][e0 + __popcll(q1 & below)] = s1 * 14 + (int)p1 - 1;
+            cnt2 = e0 + __popcll(q1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     auto load4 = [&](int row, int col) -> float4 {
         if (BF16) {
             const uint2 x = *reinterpret_cast<const uint2*>(W0B + (long long)row * H + col);
@@ -343,6 +370,26 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
                 *reinterpret_cast<uint2*>(out_bf + (long long)b * H + col) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
             }
             if (out) *reinterpret_cast<float4*>(out + (long long)b * H + col) = t;
+            if (!BF16 && nd >= 0) {                       // the s' chain of the same sample, same net
+                float4 a2;
+                if (nd <= 8) {
+                    a2 = acc;
+                    for (int k = 0; k < nd; ++k) {        // wave-uniform
+                        const int ro = dpair[wid][k][0], ri = dpair[wid][k][1];
+                        if (ro >= 0) { const float4 w = load4(ro, col); a2.x -= w.x; a2.y -= w.y; a2.z -= w.z; a2.w -= w.w; }
+                        if (ri >= 0) { const float4 w = load4(ri, col); a2.x += w.x; a2.y += w.y; a2.z += w.z; a2.w += w.w; }
+                    }
+                } else {
+                    a2 = *reinterpret_cast<const float4*>(b0 + col);
+                    for (int k = 0; k < cnt2; ++k) { const float4 w = load4(rows2[wid][k], col); a2.x += w.x; a2.y += w.y; a2.z += w.z; a2.w += w.w; }
+                }
+                const float4 t2 = make_float4(tanhf(a2.x), tanhf(a2.y), tanhf(a2.z), tanhf(a2.w));
+                if (J.out_bf[1]) {
+                    const uint16_t q0 = bf16_bits(t2.x), q1 = bf16_bits(t2.y), q2 = bf16_bits(t2.z), q3 = bf16_bits(t2.w);
+                    *reinterpret_cast<uint2*>(J.out_bf[1] + (long long)b * H + col) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
+                }
+                if (J.out[1]) *reinterpret_cast<float4*>(J.out[1] + (long long)b * H + col) = t2;
+            }
         }
     } else {
         for (int col = lane; col < H; col += 64) {
@@ -1252,6 +1299,11 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
         }
         // the screening shadow of the output-layer weights rides in the same grid (one more row of blocks) when the grid is wide
         // enough for it; a launch of its own otherwise
+        // online TD rule on an fp32 net: the s' chain (job 1, same net, same slots) is derived inside job 0's waves
+        static const bool no_derive = getenv("XQ_NO_DERIVE") != nullptr;
+        const bool derive = !bf && njobs == 2 && jobs[0].net == jobs[1].net && (H & 3) == 0 && jobs[1].gathered == nullptr &&
+                            no_derive == false;
+        J.derive_next = derive ? 1 : 0;
         bool ride = false;
         if (shadow) {
             const int sblocks = (shadow->NO + kShadowRows - 1) / kShadowRows;
@@ -1264,7 +1316,11 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
         }
         ProfScope ps(d, "l0_forward_gather", 2.0 * njobs * n * 32 * H, (double)njobs * n * (48 + 32.0 * H * (bf ? 2 : 4) + H * 4));
         if (bf) hipLaunchKernelGGL(l0_forward_kernel<true>, dim3((n + 3) / 4, njobs), dim3(256), 0, d->cur, J, src, n, H);
-        else hipLaunchKernelGGL(l0_forward_kernel<false>, dim3((n + 3) / 4, njobs + (ride ? 1 : 0)), dim3(256), 0, d->cur, J, src, n, H);
+        else {
+            // (grid rows: the job rows that are really gathered, then the shadow row; the kernel tests blockIdx.y == J.njobs for it)
+            if (derive) J.njobs = 1;
+            hipLaunchKernelGGL(l0_forward_kernel<false>, dim3((n + 3) / 4, J.njobs + (ride ? 1 : 0)), dim3(256), 0, d->cur, J, src, n, H);
+        }
         XQ_HIP(hipGetLastError());
     }
     for (int l = 1; l + 1 < d->nl; ++l) {

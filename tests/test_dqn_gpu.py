@@ -541,3 +541,29 @@ def test_screened_qmax_degenerate_outputs(xq):
         q2 = xo.nn_forward(sizes, wt, bt, xo.state_repr(xo.board_from(S2[i])))
         assert abs(y_scr[i] - 0.99 * q2.max()) < 2e-6, (i, y_scr[i], 0.99 * q2.max())
     env.close(); d.close()
+
+
+@pytest.mark.gpu
+def test_online_td_next_state_chain_derived_and_direct(xq):
+    """With the online TD rule the layer-0 sums of s' are derived from those of s (minus the rows of the squares that changed, plus
+    the rows of what stands there now) when the two boards are a move apart, and gathered in full otherwise.  Both routes against
+    the oracle: real transitions (one move apart), and pairs of unrelated positions (dozens of squares differ)."""
+    sizes = CFG2_NET
+    n = 300
+    env = xq.VecEnv(n, seed=321)
+    for _ in range(17):
+        env.selfplay_step(None)
+    S, _ = env.get_state()
+    res = env.selfplay_step(None)
+    S2, _ = env.get_state()
+    A = (res["action"] % 90).astype(np.int32)
+    R = (res["reward"] / 100.0).astype(np.float32)
+    D = np.zeros(n, np.uint8)
+    d, w, b = make_net(xq, sizes, seed=12)
+    for name, nxt in (("one move apart", S2), ("unrelated", np.roll(S2, 7, axis=0))):
+        assert ((S != nxt).sum(axis=1) > 8).any() == (name == "unrelated")
+        qsa, y = d.td_update(S, nxt, A, R, D, td_net=0, mode=0, learning_rate=0.0, grad_scale=1.0)
+        for i in range(0, n, 7):
+            want = float(R[i]) + 0.99 * xo.nn_forward(sizes, w, b, xo.state_repr(xo.board_from(nxt[i]))).max()
+            assert abs(y[i] - want) < 2e-6, (name, i, y[i], want)
+    env.close(); d.close()
