@@ -627,6 +627,35 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
     const bool live = a >= 0 && a < 96;
     float delta = 0.f, q = 0.f, y = 0.f;
     const float* ar = a_last + (long long)b * H;
+    if (H == 256 && !X.wout_bf && !X.double_dqn && n_partial <= 4) {
+        // fp32 net, 256-wide last hidden layer, no arg-max: every load that depends only on (b, s, a) is
+        // issued up front as one 16-byte load per lane — the general path below is a chain of five dependent memory round trips
+        const int ac = live ? a : 0;
+        const float4 av = *reinterpret_cast<const float4*>(ar + lane * 4);
+        const float4 wv = *reinterpret_cast<const float4*>(w_out + (long long)ac * 256 + lane * 4);
+        const bool has_view = live && a < view_kmax;
+        const float4 vv = has_view ? *reinterpret_cast<const float4*>(view + (long long)a * view_ld + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float zm = partial[b];                         // the (up to kReduceParts) maxima left per sample
+#pragma unroll
+        for (int t = 1; t < 4; ++t) zm = fmaxf(zm, partial[(long long)min(t, n_partial - 1) * n + b]);
+        const float bo = b_out[ac], r = reward[s];
+        const bool dn = done[s] != 0;
+        const float isw = X.is_w ? X.is_w[b] / X.is_wmax[0] : 1.f;
+        float z = (av.x * wv.x + av.y * wv.y) + (av.z * wv.z + av.w * wv.w);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+        if (live) {
+            q = tanhf(z + bo);
+            y = dn ? r : r + gamma * tanhf(zm);
+            delta = (q - y) * (1.f - q * q) * isw;
+        }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_view) {
+            o.x = delta * vv.x * (1.f - av.x * av.x); o.y = delta * vv.y * (1.f - av.y * av.y);
+            o.z = delta * vv.z * (1.f - av.z * av.z); o.w = delta * vv.w * (1.f - av.w * av.w);
+        }
+        *reinterpret_cast<float4*>(dtop + (long long)b * 256 + lane * 4) = o;
+    } else {
     if (live) {
         float z = 0.f;
         if (X.wout_bf) { const uint16_t* wr = X.wout_bf + (long long)a * H; for (int i = lane; i < H; i += 64) z += bf16_to_float(wr[i]) * ar[i]; }
@@ -670,6 +699,7 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
         }
     } else {
         for (int i = lane; i < H; i += 64) drow[i] = 0.f;
+    }
     }
     if (lane == 0) {
         dsc[b] = delta;
