@@ -9,8 +9,9 @@ weights, self-play from the start position ("synthetic": nothing is read from di
 runs its own 8192 games (game ids rank*8192..) and the gradient buffer is all-reduced over RCCL every update.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus N --steps K --warmup W            # no launcher: spawns its own N ranks (one fresh process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W               # under a launcher: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel with HIP events recorded around each of its launches inside
 the timed region: by default (`--qmax screened`) the 8100 x 8192 x 256 bf16-MFMA screening pass of max_a' Q(s',a') (its fp32
@@ -134,6 +135,23 @@ def pmc_traffic(kernel_substring):
     return None, None
 
 
+def env_instruction_mix():
+    """Wave-instructions per board of env_kernel<SELFPLAY> from the newest committed PMC summary (profiles/*env_kernel_instruction*.json,
+    tools/env_pmc.sh: SQ_INSTS_* of the env-only launch at 8192 boards).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*env_kernel_instruction*.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        m = d.get("after", d)["instruction_mix_per_launch_8192_boards"]
+        return {"total": m["wave_instructions_per_board"], "valu": m["SQ_INSTS_VALU_per_board"], "salu": m["SQ_INSTS_SALU_per_board"],
+                "lds": m["SQ_INSTS_LDS_per_board"], "smem": m["SQ_INSTS_SMEM_per_board"], "vmem": m["SQ_INSTS_VMEM_per_board"],
+                "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+
+
 def env_only(args, xq, tstream):
     """Env-only random-policy stepping (BASELINE.md §3 C2 on the GPU): legal moves + uniform choice + movePiece + reward +
     terminal + auto-reset for every game, nothing else.  Prints one JSON line (diagnostic, not the headline metric)."""
@@ -155,6 +173,45 @@ def env_only(args, xq, tstream):
                       "games": args.games, "steps": args.steps, "us_per_launch": ms * 1e3,
                       "algorithmic_GBps": bytes_per / (ms * 1e-3) / 1e9, "episodes_finished": c["episodes"]}), flush=True)
     env.close()
+
+
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this very script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, one GPU each), pass rank 0's stdout through and fail if any rank fails.  The
+    parent never imports torch and never touches HIP — a process that has initialised the GPU must not be replaced or forked."""
+    import signal
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs between processes on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        live = set(range(n_ranks))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"[bench.py] rank {r} exited with code {code}: stopping the other ranks", file=sys.stderr)
+                    for q in live:
+                        procs[q].send_signal(signal.SIGTERM)
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
 
 
 def main():
@@ -186,12 +243,18 @@ def main():
     ap.add_argument("--qmax", choices=("screened", "full"), default="screened",
                     help="max_a' Q(s',a') of the TD target: exact bf16 screening + fp32 re-evaluation (default) or the full fp32 product")
     ap.add_argument("--bracket-all", action="store_true", help="HIP-event bracket around EVERY launch of the dominant GEMM (default: every 4th)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the variant legs (other TD net, full fp32 product): A/B runs")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (exactly --steps steps, barrier + synchronize on both sides) is run this many times back to "
+                         "back; ms_per_step / value are the MEDIAN repetition, all of them are listed in ms_per_step_samples")
     ap.add_argument("--no-overlap", action="store_true",
                     help="queue collect and learn on one stream (collect -> learn -> apply) instead of running collect beside learn_grads")
     args = ap.parse_args()
     if args.cpu_worker > 0:                      # child of cpu_all_cores(): CPU only, never touches the GPU
         print(json.dumps(cpu_train_loop(args.cpu_worker)), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # no launcher: be our own (before torch / HIP are touched)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import cn_chess_ai_amd as xq
@@ -200,8 +263,8 @@ def main():
 
     rank, local_rank, world = xd.env_rank()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or no launcher at all: bench.py spawns its ranks itself)"
+                         % (args.gpus, world))
     if not torch.cuda.is_available() or _capi.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # rehearsal hooks (one-GPU box only): XQ_FORCE_DEVICE pins every rank to one device, XQ_DIST_BACKEND=gloo replaces RCCL —
@@ -294,7 +357,7 @@ def main():
     torch.cuda.synchronize()
     c0 = t.counters()
 
-    def timed(steps):
+    def timed_once(steps):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -308,20 +371,28 @@ def main():
         el = time.perf_counter() - t0
         return xd.max_over_ranks(el, device="cuda" if world > 1 else "cpu"), enq
 
+    def timed(steps, repeats=None):
+        """The driver's short window (--steps 20 = 5 ms) is one sample of a noisy quantity: the same region `repeats` times,
+        the median repetition is the reported one (every rank sees the same max-over-ranks times, so all pick the same)."""
+        runs = [timed_once(steps) for _ in range(max(1, repeats or args.repeats))]
+        order = sorted(range(len(runs)), key=lambda i: runs[i][0])
+        mid = order[(len(runs) - 1) // 2]
+        return runs[mid][0], runs[mid][1], [r[0] for r in runs]
+
     qstat0 = t.dqn.qmax_stats()
     # the dominant GEMM is bracketed with HIP events on every 4th launch of the timed region (--bracket-all: every launch): a
     # bracket is two event records, and a record drains the recording queue — ~10 us each time on a 250-us step
     t.dqn.kernel_stats(enable=2 if args.profile_all else 3 if args.bracket_all else 4)
-    elapsed, host_enqueue = timed(args.steps)
+    elapsed, host_enqueue, samples = timed(args.steps)
     stats = {s["name"]: s for s in t.dqn.kernel_stats(enable=0)}
     c1 = t.counters()
     # the other TD rule on the same trainer, same steady state, timed the same way (reported beside the headline)
     other, el_other = None, None
-    if args.config == 2 and args.td_net in ("online", "target"):
+    if args.config == 2 and args.td_net in ("online", "target") and not args.no_variants:
         other = "target" if args.td_net == "online" else "online"
         t.set_td_net(td_code[other])
         one_step()
-        el_other, _ = timed(args.steps)
+        el_other, _, _ = timed(args.steps)
         t.set_td_net(td_code[args.td_net])
     # the same loop with the full fp32 column-max product in place of the exact screen (bracketed the same way)
     qmax_info, full_variant = None, None
@@ -333,11 +404,11 @@ def main():
                              "rigorous error bound (DESIGN.md section 4)",
                      "candidate_groups_per_sample": (st[2] - qstat0[2]) / max(st[1] - qstat0[1], 1),
                      "whole_groups_per_sample": (st[3] - qstat0[3]) / max(st[1] - qstat0[1], 1)}
-        if screened_live and world == 1:
+        if screened_live and world == 1 and not args.no_variants:
             t.dqn.set_qmax_mode(_capi.QMAX_FULL)
             one_step()
             t.dqn.kernel_stats(enable=3 if args.bracket_all else 4)
-            el_full, _ = timed(args.steps)
+            el_full, _, samples_full = timed(args.steps)
             full_variant = (el_full, {s["name"]: s for s in t.dqn.kernel_stats(enable=0)})
             t.dqn.set_qmax_mode(_capi.QMAX_SCREENED)
     else:
@@ -380,6 +451,9 @@ def main():
             "transitions_trained_per_s": world * minibatch * args.steps / elapsed,
             "metric_config": "BASELINE.json configs[%d]%s" % (args.config - 1, "" if args.config == 2 else " (NOT the headline configuration)"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_samples": [1e3 * x / args.steps for x in samples],
+            "timing": "the timed region (exactly `steps` steps between barrier + synchronize) run %d times back to back; value, "
+                      "updates_per_s and ms_per_step are the median repetition" % len(samples),
             "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": CFG["dtype"], "data": "synthetic",
             "dtype_note": ("weights, activations, Q-values, TD targets and gradients fp32; with config.qmax.mode = screened the candidates for "
@@ -392,12 +466,13 @@ def main():
                        "q_net_precision": "bf16 forward (fp32 master weights, fp32 backward)" if CFG["bf16"] else "fp32",
                        "target_sync_interval": args.target_sync_interval,
                        "target_syncs_in_timed_region": (c1["updates"] // max(args.target_sync_interval, 1)
-                                                        - c0["updates"] // max(args.target_sync_interval, 1)) if args.target_sync_interval else 0,
+                                                        - c0["updates"] // max(args.target_sync_interval, 1)) / len(samples)
+                                                       if args.target_sync_interval else 0,
                        "steady_state": {"prefill_random_plies": args.prefill_plies, "fill_collects": fill_collects,
                                         "replay_fill": rp_size / rp_cap, "replay_total_pushed": rp_total,
                                         "mean_ply": float(np.mean(meta[:, 0])), "max_ply": int(np.max(meta[:, 0])),
                                         "mean_legal_moves": float(np.mean(legal_counts)), "max_legal_moves": int(np.max(legal_counts)),
-                                        "episodes_finished_in_timed_region": c1["episodes"] - c0["episodes"]},
+                                        "episodes_finished_in_timed_region": (c1["episodes"] - c0["episodes"]) / len(samples)},
                        "schedule": "collect -> learn -> apply on one stream" if args.no_overlap else
                                    "collect(t) on its own stream beside learn_grads(t), both on theta_t; minibatch from the ring minus "
                                    "the slots collect(t) writes; apply joins both",
@@ -441,7 +516,8 @@ def main():
         if full_variant is not None:
             el_full, st_full = full_variant
             line["variant_qmax_full_fp32_product"] = {"value": world * n_games * plies * args.steps / el_full, "unit": "env steps/s",
-                                                      "updates_per_s": args.steps / el_full, "ms_per_step": 1e3 * el_full / args.steps}
+                                                      "updates_per_s": args.steps / el_full, "ms_per_step": 1e3 * el_full / args.steps,
+                                                      "ms_per_step_samples": [1e3 * x / args.steps for x in samples_full]}
             gf = st_full.get("gemm_qmax_rowmax")
             if gf and gf["launches"]:
                 line["variant_qmax_full_fp32_product"]["roofline"] = gemm_roofline(gf, None, False)
@@ -454,11 +530,29 @@ def main():
                                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("env_kernel<2>")[0] if args.config == 2 else None, "avg_launch_ms": ms,
                                     "bytes_per_launch": by, "launches": e["launches"]}
+            mix = env_instruction_mix() if args.config == 2 else None
+            if mix:
+                # the bound that actually applies: instruction issue.  Floor = the larger of the VALU issue time (a wave64 VALU
+                # instruction occupies its SIMD-32 for 2 cycles; 4 SIMDs per CU) and the scalar issue time (one scalar unit per
+                # CU, one instruction per cycle) at the 2.4 GHz peak clock, every CU busy, nothing else stalling.
+                valu_us = mix["valu"] * n_games * 2.0 / (4 * 256) / 2400.0
+                salu_us = (mix["salu"] + mix["smem"]) * n_games / 256.0 / 2400.0
+                floor_us = max(valu_us, salu_us)
+                line["roofline_env"]["issue"] = {
+                    "bound": "issue", "wave_instructions_per_board": mix["total"], "valu": mix["valu"], "salu": mix["salu"],
+                    "lds": mix["lds"], "smem": mix["smem"], "vmem": mix["vmem"], "source": mix["source"],
+                    "floor_us": floor_us, "valu_issue_us": valu_us, "scalar_issue_us": salu_us,
+                    "frac": floor_us / (ms * 1e3),
+                    "note": "one wavefront per board: ~%d wave-instructions per board-ply (move generation alone ~400); BASELINE's "
+                            ">= 40 %% of HBM peak would need ~100 — the HBM figure above is reported, but it is not the bound of this kernel"
+                            % round(mix["total"])}
             ei = iso.get("env_selfplay_step")
             if ei and ei["launches"]:
                 line["roofline_env"]["co_scheduled"] = "runs on its own stream beside the TD step; avg_launch_ms is its stretched live duration"
                 line["roofline_env"]["isolated_avg_launch_ms"] = ei["ms"] / ei["launches"]
                 line["roofline_env"]["isolated_achieved"] = by / (ei["ms"] / ei["launches"] * 1e-3) / 1e9
+                if "issue" in line["roofline_env"]:
+                    line["roofline_env"]["issue"]["isolated_frac"] = line["roofline_env"]["issue"]["floor_us"] / (ei["ms"] / ei["launches"] * 1e3)
         if args.profile_all:
             line["kernels"] = {k: {"ms_per_launch": v["ms"] / max(v["launches"], 1), "launches": v["launches"]}
                                for k, v in stats.items()}

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libxqhip.so")
+# XQ_LIBXQHIP: another build of the same library (same-box A/B of two builds, tools/); never a different implementation
+LIB_PATH = os.environ.get("XQ_LIBXQHIP") or os.path.join(HERE, "libxqhip.so")
 
 XQ_OK = 0
 MAX_MOVES = 128

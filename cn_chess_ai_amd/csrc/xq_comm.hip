@@ -8,8 +8,12 @@
 //
 // Bucketing (xq_dqn_set_comm): the gradient chains of a TD step end on two streams — the side stream finishes the
 // output-layer / hidden-layer / bias segments (0.36 MB, one contiguous range behind the layer-0 segment) while the handle's
-// stream is still inside the layer-0 segmented sum (1.29 MB, the last and largest piece).  Each range is all-reduced on the
-// communicator's own stream as soon as its producer is done; only the layer-0 bucket is exposed.
+// stream is still inside the layer-0 segmented sum (1.29 MB, the last and largest piece).  Each range is all-reduced ON THE
+// STREAM OF ITS PRODUCER, right behind it (the small bucket is issued first, so RCCL's per-communicator ordering never holds
+// it behind the late one); only the layer-0 bucket is exposed.  There is no communicator stream in the TD step: a process
+// with a fifth busy stream shares hardware queues between streams that wait for each other.  The
+// communicator's own stream exists only for the stand-alone calls (xq_comm_sum_u64, xq_comm_allreduce without a stream) and
+// is created on their first use.
 #include "xq_internal.h"
 
 #include <dlfcn.h>
@@ -55,8 +59,7 @@ RcclApi& rccl() {
 struct xq_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
-    hipStream_t stream = nullptr;          // collectives run here, ordered against the producers / consumers by events
-    hipEvent_t ev_done = nullptr;
+    hipStream_t stream = nullptr;          // stand-alone collectives only (created on first use); the TD step uses its producers' streams
     uint64_t collectives = 0, floats = 0;  // issued so far (tests, bench)
     unsigned long long* scalar = nullptr;  // device scratch of xq_comm_sum_u64
 };
@@ -77,9 +80,11 @@ int comm_allreduce_on(xq_comm* c, float* buf, size_t n_floats, hipStream_t strea
     c->floats += n_floats;
     return XQ_OK;
 }
-hipStream_t comm_stream(xq_comm* c) { return c->stream; }
-hipEvent_t comm_done_event(xq_comm* c) { return c->ev_done; }
 int comm_world(const xq_comm* c) { return c->world; }
+static int comm_own_stream(xq_comm* c) {
+    if (!c->stream) XQ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    return XQ_OK;
+}
 
 }  // namespace xq
 
@@ -112,9 +117,7 @@ int xq_comm_create(int rank, int world, const uint8_t* id128, xq_comm** out) {
         delete c;
         return fail(XQ_ERR_RUNTIME, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl().GetErrorString(r));
     }
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc(&c->scalar, sizeof(unsigned long long));
+    hipError_t e = hipMalloc(&c->scalar, sizeof(unsigned long long));
     if (e != hipSuccess) { xq_comm_destroy(c); return fail(XQ_ERR_RUNTIME, "HIP error: %s (xq_comm_create)", hipGetErrorString(e)); }
     *out = c;
     return XQ_OK;
@@ -149,14 +152,17 @@ int xq_comm_create_from_file(int rank, int world, const char* path, double timeo
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
     }
-    return xq_comm_create(rank, world, id, out);
+    const int rc = xq_comm_create(rank, world, id, out);
+    // ncclCommInitRank returns once every rank has joined, i.e. after every rank has read the id: rank 0 takes the file away
+    // again, so the same path serves the next run (a leftover from a crashed run is still refused above — never a dead id)
+    if (rank == 0) remove(path);
+    return rc;
 }
 
 int xq_comm_destroy(xq_comm* c) {
     if (!c) return XQ_OK;
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) rccl().CommDestroy(c->comm);
-    if (c->ev_done) hipEventDestroy(c->ev_done);
     if (c->scalar) hipFree(c->scalar);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -175,6 +181,7 @@ int xq_comm_info(const xq_comm* c, int* rank, int* world, uint64_t* collectives,
 int xq_comm_sum_u64(xq_comm* c, uint64_t* inout_host) {
     if (!c || !inout_host) return fail(XQ_ERR_INVALID_ARGUMENT, "null pointer");
     unsigned long long v = *inout_host;
+    XQ_TRY(comm_own_stream(c));
     XQ_HIP(hipMemcpyAsync(c->scalar, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
     XQ_RCCL(rccl().AllReduce(c->scalar, c->scalar, 1, ncclUint64, ncclSum, c->comm, c->stream));
     XQ_HIP(hipMemcpyAsync(&v, c->scalar, sizeof v, hipMemcpyDeviceToHost, c->stream));
@@ -185,6 +192,7 @@ int xq_comm_sum_u64(xq_comm* c, uint64_t* inout_host) {
 
 int xq_comm_allreduce(xq_comm* c, float* buf_dev, size_t n_floats, void* hip_stream) {
     if (!c || !buf_dev) return fail(XQ_ERR_INVALID_ARGUMENT, "null pointer");
+    if (!hip_stream) XQ_TRY(comm_own_stream(c));
     return comm_allreduce_on(c, buf_dev, n_floats, hip_stream ? (hipStream_t)hip_stream : c->stream);
 }
 

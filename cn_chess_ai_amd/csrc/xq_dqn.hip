@@ -16,6 +16,7 @@
 // as the same GEMM with a different base/leading dimension.
 #include "xq_internal.h"
 #include "xq_gemm.hip.h"
+#include "xq_screen.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -67,9 +68,14 @@ struct xq_dqn {
     // the last hidden activations of s', the two screening partial arrays, the largest row norm of the weights, counters
     int qmax_mode = XQ_QMAX_FULL;
     uint16_t* scr_wb = nullptr;                 // [round_up(nout,128)][hlast] (rows >= nout zero)
-    uint16_t* scr_ab = nullptr;  int scr_cap = 0;   // [round_up(cap,128)][hlast]
-    float* scr_p1 = nullptr; float* scr_p2 = nullptr;   // [4*tiles_m][cap]
-    unsigned* scr_wmax = nullptr;               // bits of max_j ||W_out[j]||_2 (non-negative floats order like unsigned)
+    uint16_t* scr_ab = nullptr;  int scr_cap = 0;   // [round_up(cap,512)][hlast]: row-major, or B-fragment order for screen_top2_kernel
+    float* scr_p1 = nullptr; float* scr_p2 = nullptr;   // [4*tiles_m][round_up(cap,512)]
+    // bits of the largest row norm / largest |bias| of the output layer (non-negative floats order like unsigned): [0..1] rows 0..95 by
+    // step parity, [2..3] their biases by step parity, [4] rows >= 96, [5] their biases.  Only rows 0..95 change under the TD rule
+    // (xq_dqn_td_grads never touches the others), so the shadow of rows >= 96 and slots [4], [5] are kept from step to step:
+    unsigned* scr_wmax = nullptr;
+    int scr_static_net = -1;                    // net whose rows >= 96 the shadow holds (-1: none — the next step converts everything)
+    bool scr_new_kernel_ready = false;          // dynamic-LDS attribute of screen_top2_kernel set
     unsigned long long* scr_stats = nullptr;    // [4] TD steps, samples, candidate (sample, group) pairs, pairs recomputed as whole groups
     unsigned long long scr_host_steps = 0, scr_host_samples = 0;
     // guard: every kScreenCheckEvery screened steps the candidate counters come back asynchronously; a net that leaves the screen too
@@ -95,7 +101,6 @@ struct xq_dqn {
     float* slabs = nullptr;  size_t slabs_cap = 0;
     float* slabs_l0 = nullptr;  size_t slabs_l0_cap = 0;     // layer-0 gradient partials
     xq_comm* comm = nullptr;                    // xq_dqn_set_comm: bucketed RCCL all-reduce of the gradient buffer inside td_grads
-    hipEvent_t ev_l0 = nullptr;                 // handle stream: the layer-0 gradient segment is final
     bool fused_apply = false;                   // xq_dqn_set_fused_apply: apply_grads may sum the layer-0 partials itself
     int l0_pending = 0;                         // > 0: that many layer-0 slabs wait in slabs_l0, not yet reduced into grads_td
     struct PendingSlab { const float* src = nullptr; int nslabs = 0; long long stride = 0; };
@@ -160,12 +165,18 @@ enum { kMaxChains = 3 };
 // bf16 copy of a weight matrix [NO][K] (K % 64 == 0) + the largest row norm (exact screening of max_a' Q(s',a'), see
 // qmax_refine_kernel).  A quarter-wave per row, 2 rows per quarter, all of a quarter's loads in flight together (pure latency:
 // 8 MB in, 4 MB out); block `blk` of 256 threads takes rows [32 blk, 32 blk + 32); rows >= NO of the padded copy stay zero.
-struct ShadowJob { const float* W; int NO, K; uint16_t* Wb; unsigned* wmax_bits; };
-enum { kShadowRows = 32 };
-__device__ __forceinline__ void screen_shadow_block(const ShadowJob& S, int blk, float* nrm /* LDS [4] */) {
+struct ShadowJob {
+    const float* W; const float* bias; int NO, K; uint16_t* Wb;
+    unsigned* w_dyn; unsigned* b_dyn;         // rows 0..95 (kShadowDynBlocks blocks): this step's parity slots
+    unsigned* w_stat; unsigned* b_stat;       // rows >= 96
+    int nblocks;                              // blocks to run: all of them, or kShadowDynBlocks when rows >= 96 are still valid
+};
+enum { kShadowRows = 32, kShadowDynBlocks = 3 };
+__device__ __forceinline__ void screen_shadow_block(const ShadowJob& S, int blk, float* nrm /* LDS [8] */) {
     const int ql = (int)(threadIdx.x & 15), quarter = (int)(threadIdx.x >> 4);
     const int row0 = blk * kShadowRows + quarter * 2;
     float mx = 0.f;
+    float bm = fmaxf(row0 < S.NO ? fabsf(S.bias[row0]) : 0.f, row0 + 1 < S.NO ? fabsf(S.bias[row0 + 1]) : 0.f);
     if (S.K == 256) {
         float4 x[2][4];
 #pragma unroll
@@ -205,17 +216,21 @@ __device__ __forceinline__ void screen_shadow_block(const ShadowJob& S, int blk,
         }
     }
 #pragma unroll
-    for (int off = 32; off >= 16; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    if ((threadIdx.x & 63) == 0) nrm[threadIdx.x >> 6] = mx;
+    for (int off = 32; off >= 16; off >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, off, 64)); bm = fmaxf(bm, __shfl_xor(bm, off, 64)); }
+    if ((threadIdx.x & 63) == 0) { nrm[threadIdx.x >> 6] = mx; nrm[4 + (threadIdx.x >> 6)] = bm; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const float m = sqrtf(fmaxf(fmaxf(nrm[0], nrm[1]), fmaxf(nrm[2], nrm[3])));
-        const unsigned mb = __builtin_bit_cast(unsigned, m);
-        if (mb > *reinterpret_cast<volatile unsigned*>(S.wmax_bits)) atomicMax(S.wmax_bits, mb);
+        const float b = fmaxf(fmaxf(nrm[4], nrm[5]), fmaxf(nrm[6], nrm[7]));
+        unsigned* wslot = blk < kShadowDynBlocks ? S.w_dyn : S.w_stat;
+        unsigned* bslot = blk < kShadowDynBlocks ? S.b_dyn : S.b_stat;
+        const unsigned mb = __builtin_bit_cast(unsigned, m), bb = __builtin_bit_cast(unsigned, b);
+        if (mb > *reinterpret_cast<volatile unsigned*>(wslot)) atomicMax(wslot, mb);
+        if (bb > *reinterpret_cast<volatile unsigned*>(bslot)) atomicMax(bslot, bb);
     }
 }
 __global__ __launch_bounds__(256) void screen_shadow_kernel(ShadowJob S) {
-    __shared__ float nrm[4];
+    __shared__ float nrm[8];
     screen_shadow_block(S, (int)blockIdx.x, nrm);
 }
 
@@ -230,6 +245,7 @@ struct L0Jobs {
     int njobs;
     int derive_next;                         // 1: job 0's waves also produce job 1 (s' = s after one move, SAME net) from their own layer-0 sums:
                                              // z1(s') = z1(s) - rows of the squares that changed + rows of what stands there now
+    int out_bf_frag;                         // fp32 net: the bf16 copy out_bf is written in MFMA B-fragment order (scr_afrag_index)
     ShadowJob shadow;                        // W != nullptr: the blocks of grid row y == njobs convert the screening shadow (no extra launch)
 };
 
@@ -240,7 +256,7 @@ template <bool BF16>
 __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, int n, int H) {
     __shared__ int rows[4][96];
     if ((int)blockIdx.y == J.njobs) {                   // block-uniform: the screening shadow rides in the same grid
-        if ((int)blockIdx.x * kShadowRows < J.shadow.NO) screen_shadow_block(J.shadow, (int)blockIdx.x, reinterpret_cast<float*>(&rows[0][0]));
+        if ((int)blockIdx.x < J.shadow.nblocks) screen_shadow_block(J.shadow, (int)blockIdx.x, reinterpret_cast<float*>(&rows[0][0]));
         return;
     }
     const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
                 t = make_float4(bf16_to_float(q0), bf16_to_float(q1), bf16_to_float(q2), bf16_to_float(q3));
             } else if (out_bf) {            // fp32 net: a bf16 COPY beside the exact activations (screening operand, one hidden layer)
                 const uint16_t q0 = bf16_bits(t.x), q1 = bf16_bits(t.y), q2 = bf16_bits(t.z), q3 = bf16_bits(t.w);
-                *reinterpret_cast<uint2*>(out_bf + (long long)b * H + col) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
+                *reinterpret_cast<uint2*>(out_bf + (J.out_bf_frag ? scr_afrag_index(b, col, H) : (long long)b * H + col)) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
             }
             if (out) *reinterpret_cast<float4*>(out + (long long)b * H + col) = t;
             if (!BF16 && nd >= 0) {                       // the s' chain of the same sample, same net
@@ -386,7 +402,8 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
                 const float4 t2 = make_float4(tanhf(a2.x), tanhf(a2.y), tanhf(a2.z), tanhf(a2.w));
                 if (J.out_bf[1]) {
                     const uint16_t q0 = bf16_bits(t2.x), q1 = bf16_bits(t2.y), q2 = bf16_bits(t2.z), q3 = bf16_bits(t2.w);
-                    *reinterpret_cast<uint2*>(J.out_bf[1] + (long long)b * H + col) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
+                    *reinterpret_cast<uint2*>(J.out_bf[1] + (J.out_bf_frag ? scr_afrag_index(b, col, H) : (long long)b * H + col)) =
+                        make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
                 }
                 if (J.out[1]) *reinterpret_cast<float4*>(J.out[1] + (long long)b * H + col) = t2;
             }
@@ -929,6 +946,10 @@ struct SegTable {
 // value (tagged with its row) and the second largest.  Pass 2 (qmax_refine_kernel): threshold per sample, then one fp32 dot per
 // candidate group whose second value is below the threshold (the usual case), 32 dots for a group with two values above it.
 constexpr float kScreenEps = 0.0078125f * 1.0625f;
+// the bias travels inside the accumulation chain (C operand of a tile's first MFMA, xq_screen.hip.h) or is added behind it (the
+// older kernel): either way it adds at most (K + 1) 2^-24 |b_j| of rounding to the screened value and the same to the fp32
+// re-evaluation; 2^-9 max_j |b_j| covers both for K <= 1024, including the 2^-5 share of B the threshold reserves for the latter
+constexpr float kScreenBiasEps = 0.001953125f;
 enum { kScreenCheckEvery = 32, kScreenHoldSteps = 512 };
 constexpr double kScreenMaxPairs = 24.0, kScreenMaxWhole = 1.0;     // candidate groups / whole groups per sample above which the
                                                                     // fp32 re-evaluation costs more than the product it replaces
@@ -989,11 +1010,10 @@ __device__ __forceinline__ int screen_row(int g, int code) {       // inverse of
 }
 
 template <int KFIX, int NPT>                 // NPT = screened values per thread = ceil(G / 8), unrolled (32 for 8100 outputs)
-__global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restrict__ P1, const float* __restrict__ P2, int G, int n,
+__global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restrict__ P1, const float* __restrict__ P2, int G, int n, long long ldp,
                                                           const float* __restrict__ a_last, int K, const float* __restrict__ W,
-                                                          const float* __restrict__ bias, int NO, const unsigned* __restrict__ wmax_bits,
-                                                          unsigned* __restrict__ wmax_next, float* __restrict__ zmax,
-                                                          unsigned long long* __restrict__ stats) {
+                                                          const float* __restrict__ bias, int NO, unsigned* __restrict__ wm, int parity,
+                                                          float* __restrict__ zmax, unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cand[];            // [G * 32]: sample | row << 5
     uint16_t* wlist = reinterpret_cast<uint16_t*>(cand + (size_t)G * kRefineSamples);    // [G * 32]: sample | group << 5
     __shared__ float sv[8][32];
@@ -1006,7 +1026,7 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
     const int b0 = (int)blockIdx.x * kRefineSamples;
     const int b = b0 + sl;
     const bool ok = b < n;
-    if (tid == 0) { cnt = 0; nexp = 0; if (blockIdx.x == 0) *wmax_next = 0u; }
+    if (tid == 0) { cnt = 0; nexp = 0; if (blockIdx.x == 0) { wm[parity ^ 1] = 0u; wm[2 + (parity ^ 1)] = 0u; } }   // next step's slots
     if (tid < 32) best[tid] = (int)0x80000000;
     // this thread's screened values: groups phase, phase + 8, ...
     // (unconditional, clamped loads: a predicate per load compiles to a branch per load)
@@ -1015,8 +1035,8 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
 #pragma unroll
     for (int u = 0; u < NPT; ++u) {
         const int g = min(phase + 8 * u, G - 1);
-        v[u] = P1[(long long)g * n + bc];
-        v2[u] = P2[(long long)g * n + bc];
+        v[u] = P1[(long long)g * ldp + bc];
+        v2[u] = P2[(long long)g * ldp + bc];
     }
 #pragma unroll
     for (int u = 0; u < NPT; ++u)
@@ -1038,7 +1058,9 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
         m = sv[0][sl];
 #pragma unroll
         for (int p = 1; p < 8; ++p) m = fmaxf(m, sv[p][sl]);
-        const float B = kScreenEps * sqrtf(na[sl]) * __builtin_bit_cast(float, *wmax_bits);
+        const float wmx = fmaxf(__builtin_bit_cast(float, wm[parity]), __builtin_bit_cast(float, wm[4]));
+        const float bmx = fmaxf(__builtin_bit_cast(float, wm[2 + parity]), __builtin_bit_cast(float, wm[5]));
+        const float B = kScreenEps * sqrtf(na[sl]) * wmx + kScreenBiasEps * bmx;
         thr[sl] = b0 + sl < n ? m - 2.f * B * 1.03125f - 1.52587890625e-05f * (fabsf(m) + 2.f * B) : __builtin_inff();   // no candidates past n
     }
     __syncthreads();
@@ -1281,24 +1303,26 @@ static int ensure_screen_capacity(xq_dqn* d, int n) {
     if (!d->scr_wb) {
         XQ_HIP(hipMalloc(&d->scr_wb, wrows * Hl * sizeof(uint16_t)));
         XQ_HIP(hipMemset(d->scr_wb, 0, wrows * Hl * sizeof(uint16_t)));
-        XQ_HIP(hipMalloc(&d->scr_wmax, 2 * sizeof(unsigned)));
-        XQ_HIP(hipMemset(d->scr_wmax, 0, 2 * sizeof(unsigned)));
+        XQ_HIP(hipMalloc(&d->scr_wmax, 6 * sizeof(unsigned)));
+        XQ_HIP(hipMemset(d->scr_wmax, 0, 6 * sizeof(unsigned)));
         XQ_HIP(hipMalloc(&d->scr_stats, 4 * sizeof(unsigned long long)));
         XQ_HIP(hipMemset(d->scr_stats, 0, 4 * sizeof(unsigned long long)));
         XQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->scr_guard_host), 4 * sizeof(unsigned long long), hipHostMallocDefault));
         memset(d->scr_guard_host, 0, 4 * sizeof(unsigned long long));
         XQ_HIP(hipEventCreateWithFlags(&d->scr_guard_ev, hipEventDisableTiming));
+        d->scr_static_net = -1;
     }
     if (n > d->scr_cap) {
         XQ_HIP(hipDeviceSynchronize());
-        const size_t rows = (size_t)round_up(n, 128), G = (size_t)4 * ((NO + 127) / 128);
+        // sample dimension padded to whole blocks of screen_top2_kernel (512): it stores every column of its panels unconditionally
+        const size_t rows = (size_t)round_up(n, 512), G = (size_t)4 * ((NO + 127) / 128);
         if (d->scr_ab) XQ_HIP(hipFree(d->scr_ab));
         if (d->scr_p1) XQ_HIP(hipFree(d->scr_p1));
         if (d->scr_p2) XQ_HIP(hipFree(d->scr_p2));
         XQ_HIP(hipMalloc(&d->scr_ab, rows * Hl * sizeof(uint16_t)));
         XQ_HIP(hipMemset(d->scr_ab, 0, rows * Hl * sizeof(uint16_t)));
-        XQ_HIP(hipMalloc(&d->scr_p1, G * (size_t)n * sizeof(float)));
-        XQ_HIP(hipMalloc(&d->scr_p2, G * (size_t)n * sizeof(float)));
+        XQ_HIP(hipMalloc(&d->scr_p1, G * rows * sizeof(float)));
+        XQ_HIP(hipMalloc(&d->scr_p2, G * rows * sizeof(float)));
         d->scr_cap = n;
     }
     return XQ_OK;
@@ -1311,6 +1335,7 @@ struct ChainJob {
     uint16_t* const* outs_bf;
     uint32_t* gathered;
     uint16_t* last_bf;          // fp32 net: != nullptr => bf16 copy of the chain's LAST hidden activations (screening operand)
+    bool last_bf_frag;          //   ... written in MFMA B-fragment order (scr_afrag_index) for screen_top2_kernel
 };
 // Up to three chains run in the same launches: one gather grid with blockIdx.y = chain, grouped GEMMs with blockIdx.z = chain.
 static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src, int n, const ShadowJob* shadow = nullptr) {
@@ -1325,7 +1350,7 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
             J.boards[k] = jobs[k].boards; J.W0T[k] = d->w0t(jobs[k].net); J.b0[k] = d->bl(jobs[k].net, 0);
             J.out[k] = jobs[k].outs ? jobs[k].outs[0] : nullptr; J.gathered[k] = jobs[k].gathered;
             if (bf) { J.W0T_bf[k] = d->wl_bf(jobs[k].net, 0); J.out_bf[k] = jobs[k].outs_bf[0]; }
-            else if (d->nl == 2) J.out_bf[k] = jobs[k].last_bf;
+            else if (d->nl == 2) { J.out_bf[k] = jobs[k].last_bf; if (jobs[k].last_bf && jobs[k].last_bf_frag) J.out_bf_frag = 1; }
         }
         // the screening shadow of the output-layer weights rides in the same grid (one more row of blocks) when the grid is wide
         // enough for it; a launch of its own otherwise
@@ -1336,7 +1361,7 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
         J.derive_next = derive ? 1 : 0;
         bool ride = false;
         if (shadow) {
-            const int sblocks = (shadow->NO + kShadowRows - 1) / kShadowRows;
+            const int sblocks = shadow->nblocks;
             ride = sblocks <= (n + 3) / 4;
             if (ride) J.shadow = *shadow;
             else {
@@ -1373,6 +1398,7 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
             g.K = d->L[l]; g.lda = g.ldb = d->L[l]; g.ldc = d->L[l + 1]; g.ldcb = d->L[l + 1];
             for (int k = 0; k < njobs; ++k) {
                 uint16_t* cb = (l == d->nl - 2) ? jobs[k].last_bf : nullptr;
+                if (cb && jobs[k].last_bf_frag) g.cb_frag = 1;
                 if (k == 0) { g.A = jobs[k].outs[l - 1]; g.B = d->wl(jobs[k].net, l); g.C = jobs[k].outs[l]; g.bias = d->bl(jobs[k].net, l); g.Cb = cb; }
                 else { g.Ax[k - 1] = jobs[k].outs[l - 1]; g.Bx[k - 1] = d->wl(jobs[k].net, l); g.Cx[k - 1] = jobs[k].outs[l]; g.biasx[k - 1] = d->bl(jobs[k].net, l); g.Cbx[k - 1] = cb; }
             }
@@ -1677,7 +1703,6 @@ static int dqn_init(xq_dqn* d, const int* layer_sizes, int n_sizes, double learn
     XQ_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
     XQ_HIP(hipEventCreateWithFlags(&d->ev_delta, hipEventDisableTiming));
     XQ_HIP(hipEventCreateWithFlags(&d->ev_qmax, hipEventDisableTiming));
-    XQ_HIP(hipEventCreateWithFlags(&d->ev_l0, hipEventDisableTiming));
     // + 128 rows of the widest layer: the persistent column-max GEMM reads whole 128-row tiles of W_out (rows beyond the
     // last output are masked in its epilogue, but must be readable)
     int widest = 0;
@@ -1717,7 +1742,6 @@ int xq_dqn_destroy(xq_dqn* d) {
     if (d->ev_join) hipEventDestroy(d->ev_join);
     if (d->ev_delta) hipEventDestroy(d->ev_delta);
     if (d->ev_qmax) hipEventDestroy(d->ev_qmax);
-    if (d->ev_l0) hipEventDestroy(d->ev_l0);
     for (void* q : {(void*)d->scr_wb, (void*)d->scr_ab, (void*)d->scr_p1, (void*)d->scr_p2, (void*)d->scr_wmax, (void*)d->scr_stats})
         if (q) hipFree(q);
     if (d->scr_guard_host) hipHostFree(d->scr_guard_host);
@@ -1744,6 +1768,7 @@ int xq_dqn_set_params(xq_dqn* d, int net, const double* w, const double* b) {
     for (size_t i = 0; i < d->nb; ++i) p[d->nw + i] = (float)b[i];
     XQ_HIP(hipStreamSynchronize(d->stream));
     XQ_HIP(hipMemcpy(d->params[net], p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (d->scr_static_net == net) d->scr_static_net = -1;       // screening shadow: rows >= 96 are no longer what it holds
     return refresh_shadow(d, net);
 }
 
@@ -1766,6 +1791,7 @@ int xq_dqn_update_target(xq_dqn* d) {
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
     ProfScope ps(d, "target_sync_copy", 0, 8.0 * (d->nw + d->nb));
     XQ_HIP(hipMemcpyAsync(d->params[1], d->params[0], (d->nw + d->nb) * sizeof(float), hipMemcpyDeviceToDevice, d->stream));
+    if (d->scr_static_net == XQ_NET_TARGET) d->scr_static_net = -1;     // screening shadow: every row of the target net changed
     if (d->bf16())
         XQ_HIP(hipMemcpyAsync(d->params_bf[1], d->params_bf[0], d->nw * sizeof(uint16_t), hipMemcpyDeviceToDevice, d->stream));
     return XQ_OK;
@@ -1925,6 +1951,8 @@ int xq_dqn_backpropagate(xq_dqn* d, const double* states, const double* targets,
     SegTable t; memset(&t, 0, sizeof t);
     t.nseg = 1; t.dst[0] = d->params[0]; t.src[0] = d->grads_full; t.len[0] = (long long)(d->nw + d->nb);
     XQ_TRY(sgd_apply(d, t, lr * grad_scale));
+    XQ_TRY(refresh_shadow(d, XQ_NET_ONLINE));          // bf16 Q-net: every later bf16 forward must see the updated weights
+    if (d->scr_static_net == XQ_NET_ONLINE) d->scr_static_net = -1;    // dense update: every output row changed (screening shadow)
     XQ_HIP(hipStreamSynchronize(d->stream));
     return XQ_OK;
 }
@@ -2058,31 +2086,67 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         }
         if (d->scr_hold > 0) { --d->scr_hold; screened = false; }
     }
-    // bf16 copy + largest row norm of the selecting net's output-layer weights (they change with every SGD step); the norm lands
-    // in slot `screened steps & 1`, which the refine kernel of the previous screened step zeroed
-    ShadowJob shadow{d->wl(sel_net, nl - 1), NO, Hl, d->scr_wb, d->scr_wmax ? d->scr_wmax + (d->scr_host_steps & 1) : nullptr};
-    ChainJob jobs[3] = {{XQ_NET_ONLINE, boards, outs, outs_bf, d->gboards, nullptr}, {sel_net, next_boards, touts, touts_bf, nullptr, screened ? d->scr_ab : nullptr},
-                        {XQ_NET_TARGET, next_boards, t2outs, t2outs_bf, nullptr, nullptr}};
+    // bf16 copy + largest row norm / |bias| of the selecting net's output-layer weights.  Only rows 0..95 change under the TD rule:
+    // while `scr_static_net` says that rows >= 96 of the shadow (and their maxima, slots [4], [5]) still belong to this net, the
+    // shadow pass converts three blocks of 32 rows instead of 254; everything is converted again after set_params / load_model /
+    // update_target / a dense backpropagate / a change of the selecting net.  The maxima of rows 0..95 land in the slots of this
+    // step's parity, which the refine kernel of the previous screened step zeroed.
+    const int parity = (int)(d->scr_host_steps & 1);
+    // screen_top2_kernel (xq_screen.hip.h) for the widths it is built for; the persistent tile kernel's CM_TOP2 mode otherwise
+    const bool scr_new = screened && (Hl == 256 || Hl == 512);
+    ShadowJob shadow; memset(&shadow, 0, sizeof shadow);
+    if (screened) {
+        const bool full = d->scr_static_net != sel_net;
+        if (full) XQ_HIP(hipMemsetAsync(d->scr_wmax + 4, 0, 2 * sizeof(unsigned), d->cur));
+        shadow.W = d->wl(sel_net, nl - 1); shadow.bias = d->bl(sel_net, nl - 1); shadow.NO = NO; shadow.K = Hl; shadow.Wb = d->scr_wb;
+        shadow.w_dyn = d->scr_wmax + parity; shadow.b_dyn = d->scr_wmax + 2 + parity;
+        shadow.w_stat = d->scr_wmax + 4; shadow.b_stat = d->scr_wmax + 5;
+        shadow.nblocks = full ? (NO + kShadowRows - 1) / kShadowRows : std::min((int)kShadowDynBlocks, (NO + kShadowRows - 1) / kShadowRows);
+        d->scr_static_net = sel_net;
+    }
+    ChainJob jobs[3] = {{XQ_NET_ONLINE, boards, outs, outs_bf, d->gboards, nullptr, false},
+                        {sel_net, next_boards, touts, touts_bf, nullptr, screened ? d->scr_ab : nullptr, scr_new},
+                        {XQ_NET_TARGET, next_boards, t2outs, t2outs_bf, nullptr, nullptr, false}};
     XQ_TRY(chain_boards(d, jobs, dbl ? 3 : 2, slots, n, screened ? &shadow : nullptr));
     int zparts = kReduceParts;
     if (screened) {
-        const int tiles_m = (NO + 127) / 128, total = tiles_m * ((n + 127) / 128), G = 4 * tiles_m;
-        GemmArgs g; memset(&g, 0, sizeof g);
-        g.M = NO; g.N = n;
-        g.K = Hl / 2; g.lda = g.ldb = Hl / 2;
-        g.A = reinterpret_cast<const float*>(d->scr_wb);
-        g.B = reinterpret_cast<const float*>(d->scr_ab);
-        g.bias = d->bl(sel_net, nl - 1);
-        g.partial = d->scr_p1; g.partial2 = d->scr_p2;
-        g.a_vec = g.b_vec = 1; g.k_chunk = g.K;
-        g.bias_padded = ((((uintptr_t)g.bias) % 16 == 0) && (NO % 4) == 0) ? 1 : 0;
-        const int grid = std::min(total, 2 * d->ncu);
-        if (grid >= 2 && (grid & 1) == 0 && total >= 4 * grid) {
-            g.prio_split = grid / 2;
-            g.prio_tiles = (total / 2) / tiles_m * tiles_m;
-            if (g.prio_tiles <= 0 || g.prio_tiles >= total) { g.prio_split = 0; g.prio_tiles = 0; }
-        }
-        {
+        const int tiles_m = (NO + 127) / 128, total = tiles_m * ((n + 127) / 128);
+        // 32-row lane groups: the tile kernel writes all 4 per 128-row tile, screen_top2_kernel only those of 64-row chunks with real rows
+        const int G = scr_new ? 2 * ((NO + 63) / 64) : 4 * tiles_m;
+        long long ldp = n;
+        if (scr_new) {
+            ScreenArgs a; memset(&a, 0, sizeof a);
+            a.W = d->scr_wb; a.A = d->scr_ab; a.a_frag = 1; a.bias = d->bl(sel_net, nl - 1);
+            a.P1 = d->scr_p1; a.P2 = d->scr_p2;
+            screen_geometry(NO, n, Hl, d->ncu, a);
+            a.ldp = screen_padded_samples(n, Hl);
+            ldp = a.ldp;
+            const size_t lds = screen_lds_bytes(a);
+            if (!d->scr_new_kernel_ready) {
+                XQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(screen_top2_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                XQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(screen_top2_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                d->scr_new_kernel_ready = true;
+            }
+            ProfScope ps(d, "gemm_qmax_screen", 2.0 * NO * (double)n * Hl, 2.0 * ((double)NO * Hl + (double)n * Hl) + 8.0 * G * n);
+            if (Hl == 256) hipLaunchKernelGGL((screen_top2_kernel<1, 2>), dim3(a.panels * a.ranges), dim3(512), lds, d->cur, a);
+            else hipLaunchKernelGGL((screen_top2_kernel<2, 1>), dim3(a.panels * a.ranges), dim3(512), lds, d->cur, a);
+            XQ_HIP(hipGetLastError());
+        } else {
+            GemmArgs g; memset(&g, 0, sizeof g);
+            g.M = NO; g.N = n;
+            g.K = Hl / 2; g.lda = g.ldb = Hl / 2;
+            g.A = reinterpret_cast<const float*>(d->scr_wb);
+            g.B = reinterpret_cast<const float*>(d->scr_ab);
+            g.bias = d->bl(sel_net, nl - 1);
+            g.partial = d->scr_p1; g.partial2 = d->scr_p2;
+            g.a_vec = g.b_vec = 1; g.k_chunk = g.K;
+            g.bias_padded = ((((uintptr_t)g.bias) % 16 == 0) && (NO % 4) == 0) ? 1 : 0;
+            const int grid = std::min(total, 2 * d->ncu);
+            if (grid >= 2 && (grid & 1) == 0 && total >= 4 * grid) {
+                g.prio_split = grid / 2;
+                g.prio_tiles = (total / 2) / tiles_m * tiles_m;
+                if (g.prio_tiles <= 0 || g.prio_tiles >= total) { g.prio_split = 0; g.prio_tiles = 0; }
+            }
             ProfScope ps(d, "gemm_qmax_screen", 2.0 * g.M * g.N * Hl, 2.0 * ((double)g.M * Hl + (double)g.N * Hl) + 8.0 * G * g.N);
             hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_BF16, CM_TOP2>), dim3(grid), dim3(256), bias_lds_all, d->cur, g, tiles_m, total);
             XQ_HIP(hipGetLastError());
@@ -2092,11 +2156,9 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             ProfScope ps(d, "qmax_refine", 2.0 * n * Hl * 3, 12.0 * G * n + 4.0 * n * Hl);
             const size_t lds = (size_t)G * kRefineSamples * (sizeof(uint32_t) + sizeof(uint16_t));
             const dim3 grid((n + kRefineSamples - 1) / kRefineSamples);
-            unsigned* w_now = d->scr_wmax + (d->scr_host_steps & 1);
-            unsigned* w_next = d->scr_wmax + ((d->scr_host_steps & 1) ^ 1);
             auto launch = [&](auto kern) {
-                hipLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, d->scr_p1, d->scr_p2, G, n, touts[nl - 2], Hl, d->wl(sel_net, nl - 1),
-                                   d->bl(sel_net, nl - 1), NO, w_now, w_next, d->zmax, d->scr_stats);
+                hipLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, d->scr_p1, d->scr_p2, G, n, ldp, touts[nl - 2], Hl, d->wl(sel_net, nl - 1),
+                                   d->bl(sel_net, nl - 1), NO, d->scr_wmax, parity, d->zmax, d->scr_stats);
             };
             const bool small = G <= 8 * 32;
             if (Hl == 256) { if (small) launch(qmax_refine_kernel<256, 32>); else launch(qmax_refine_kernel<256, 64>); }
@@ -2199,25 +2261,29 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     XQ_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
     if (nl >= 3) XQ_TRY(hidden_deltas(d, n, d->deltas[nl - 2], d->L[nl - 1], d->L[nl - 1], mode, nl - 3));
     XQ_HIP(hipEventRecord(d->ev_delta, d->stream));
+    const size_t n0 = (size_t)d->L[0] * d->L[1];
+    if (d->comm) {
+        // data-parallel step: the gradient buffer is all-reduced in two buckets, each ON THE STREAM OF ITS PRODUCER right behind
+        // it — no communicator stream, no event of its own.  RCCL runs the collectives of one communicator in issue order, so
+        // the side bucket (hidden + output-layer weights, all biases: ready first) is issued first and the layer-0 bucket
+        // (the last thing computed, the only exposed one) second; every rank issues in this order.
+        d->cur = d->side;
+        int rc = side_gradients(d, n, outs, G);
+        d->cur = d->stream;
+        if (rc != XQ_OK) return rc;
+        XQ_TRY(comm_allreduce_on(d->comm, G + n0, d->n_grads_td - n0, d->side));
+        XQ_HIP(hipEventRecord(d->ev_join, d->side));
+        XQ_TRY(l0_gradient(d, n, G + d->g_w0));
+        XQ_TRY(comm_allreduce_on(d->comm, G, n0, d->stream));
+        XQ_HIP(hipStreamWaitEvent(d->stream, d->ev_join, 0));
+        return XQ_OK;
+    }
     XQ_TRY(l0_gradient(d, n, G + d->g_w0));
-    if (d->comm) XQ_HIP(hipEventRecord(d->ev_l0, d->stream));
     d->cur = d->side;
     const int rc = side_gradients(d, n, outs, G);
     d->cur = d->stream;
     if (rc != XQ_OK) return rc;
     XQ_HIP(hipEventRecord(d->ev_join, d->side));
-    if (d->comm) {
-        // two buckets on the communicator's stream, each released by its producer: everything behind the layer-0 segment
-        // (hidden + output-layer weights, all biases) as soon as the side stream is done, the layer-0 segment last
-        hipStream_t cs = comm_stream(d->comm);
-        const size_t n0 = (size_t)d->L[0] * d->L[1];
-        XQ_HIP(hipStreamWaitEvent(cs, d->ev_join, 0));
-        XQ_TRY(comm_allreduce_on(d->comm, G + n0, d->n_grads_td - n0, cs));
-        XQ_HIP(hipStreamWaitEvent(cs, d->ev_l0, 0));
-        XQ_TRY(comm_allreduce_on(d->comm, G, n0, cs));
-        XQ_HIP(hipEventRecord(comm_done_event(d->comm), cs));
-        XQ_HIP(hipStreamWaitEvent(d->stream, comm_done_event(d->comm), 0));
-    }
     XQ_HIP(hipStreamWaitEvent(d->stream, d->ev_join, 0));
     return XQ_OK;
 }

@@ -39,6 +39,13 @@ __device__ __forceinline__ float bf16_to_float(uint16_t b) { return __builtin_bi
 // ~40 instructions per value, which the bf16 MFMA no longer hides (the fp32 epilogues keep tanhf)
 __device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 
+// element index (in bf16 units) of activation (sample, k) in B-fragment order: 32-sample group, k-step of 16, lane half, then the
+// 32 samples x 8 consecutive k of one MFMA operand wave-instruction (1 KB).  The screening pass (xq_screen.hip.h) loads its
+// register-resident operand with fully coalesced 1-KB loads from this layout; the producers of the operand write through it.
+__host__ __device__ __forceinline__ long long scr_afrag_index(int sample, int k, int K) {
+    return ((long long)((sample >> 5) * (K >> 4) + (k >> 4)) * 2 + ((k >> 3) & 1)) * 256 + (sample & 31) * 8 + (k & 7);
+}
+
 enum { L_KCONTIG = 0, L_MCONTIG = 1 };
 // EPI_COLMAX: per column n, max over the rows m of (acc + bias[m]) — the GEMM is launched "transposed" (rows = output
 // neurons, columns = samples) so that the reduction runs over accumulator REGISTERS of one lane, not across lanes.
@@ -66,6 +73,7 @@ struct GemmArgs {
     // DT_BF16: A, B point at bf16 data, K / lda / ldb / k_chunk count PAIRS of bf16 (float units).  EPI_BIAS_TANH then rounds
     // its result to bf16 and writes it to Cb (bf16 bits, row stride ldcb) — and, when C != nullptr, the rounded value to C too.
     uint16_t* Cb; long long ldcb; uint16_t* Cbx[2];
+    int cb_frag;                  // fp32 EPI_BIAS_TANH: the bf16 copy Cb is written in MFMA B-fragment order (scr_afrag_index, K = N)
     int* partial_idx;             // EPI_COLMAX: != nullptr => also the row index of each partial maximum (first maximum wins)
     float* partial2;              // persistent kernel, CM_TOP2: second-largest value of every 32-row lane group (see below)
     int bias_padded;              // EPI_COLMAX: bias[] is 16-byte aligned and readable up to the last tile's edge
@@ -435,7 +443,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     if (EPI == EPI_DELTA) v = v * (1.f - hv[q] * hv[q]);
                     Cz[(long long)(mb + (q & 3) + 8 * (q >> 2)) * g.ldc + n] = v;
                     // fp32 net: a bf16 COPY of the exact activation beside it (operand of the screening pass)
-                    if (EPI == EPI_BIAS_TANH && g.Cb) g.Cb[(long long)(mb + (q & 3) + 8 * (q >> 2)) * g.ldcb + n] = bf16_bits(v);
+                    if (EPI == EPI_BIAS_TANH && g.Cb) {
+                        const int row = mb + (q & 3) + 8 * (q >> 2);
+                        g.Cb[g.cb_frag ? scr_afrag_index(row, n, g.N) : (long long)row * g.ldcb + n] = bf16_bits(v);
+                    }
                 }
             }
         return;
@@ -459,7 +470,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     v = v * (1.f - a * a);
                 }
                 Cz[(long long)m * g.ldc + n] = v;
-                if (EPI == EPI_BIAS_TANH && g.Cb) g.Cb[(long long)m * g.ldcb + n] = bf16_bits(v);
+                if (EPI == EPI_BIAS_TANH && g.Cb) g.Cb[g.cb_frag ? scr_afrag_index(m, n, g.N) : (long long)m * g.ldcb + n] = bf16_bits(v);
             }
         }
 }

@@ -135,8 +135,6 @@ struct Profiler {
 
 // communicator internals (xq_comm.hip)
 int comm_allreduce_on(xq_comm* c, float* buf, size_t n_floats, hipStream_t stream);   // in-place sum over all ranks
-hipStream_t comm_stream(xq_comm* c);
-hipEvent_t comm_done_event(xq_comm* c);
 int comm_world(const xq_comm* c);
 
 // dqn-side entry points used by the trainer (defined in xq_dqn.hip)

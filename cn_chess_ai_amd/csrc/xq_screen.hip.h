@@ -1,0 +1,278 @@
+// xq_screen.hip.h — the bf16 screening pass of max_a' Q(s',a') as a kernel of its own for gfx950.
+//
+// Reference: chessai.cpp:126 takes max over the 8100 outputs of DQN::getQValues(nextState) (dqn.cpp:65-68, dqn.cu:184-195).
+// What this pass computes: for every sample b and every 32-row lane group g of the output layer, the largest and the
+// second-largest of  z~_j(b) = b_j + sum_k bf16(W_jk) bf16(a_bk)  (fp32 accumulation on v_mfma_f32_32x32x16_bf16), the largest
+// carrying its position in its low five mantissa bits — the same [G][n] partial arrays, group numbering and position code as
+// gemm_colmax_persistent_kernel<2,2,DT_BF16,CM_TOP2> (xq_gemm.hip.h), which it replaces.
+//
+// Why a kernel of its own (the fp32 kernel's skeleton reached 0.26–0.28 of the bf16 peak: register -> LDS restaging of BOTH
+// operands, two barriers per 64-deep k-tile, four `v_mov` per staged fragment, one epilogue per 16 MFMAs):
+//   * the product is  [8100 outputs] x [n samples] x [K = 256 or 512]  — K is so short that a wave can keep its samples' WHOLE
+//     k-range in registers: 32 NS samples x K bf16 = NS * K / 4 VGPRs (128 for NS * K = 512).  The activation operand is loaded
+//     ONCE per block, straight from global memory in MFMA fragment order, and never touches LDS;
+//   * only the weight operand streams: 64-row x 256-k "units" (32 KB) go global -> LDS by `global_load_lds_dwordx4` (no VGPR
+//     round trip, no ds_write), three units deep, ONE barrier per unit, counted vmcnt so that two units stay in flight across
+//     the barrier; the LDS image is the plain row-major unit with the 16-byte chunks of row r XOR-ed by (r & 15) — applied to
+//     the per-lane SOURCE address (the LDS side of an LDS-DMA is lane-linear) and again on the read — so every ds_read_b128 of
+//     a fragment (16 lanes, 16 different rows, same k) is conflict-free, and what it returns IS the MFMA operand: no moves;
+//   * all 8 waves of a block read the same unit (different samples): 32 ds_read_b128 feed 32 NS MFMAs per wave;
+//   * the bias enters as the C operand of a tile's first MFMA (one ds_read_b128 per 4 rows), so the fold is tag + top-2 only:
+//     two values per step, v_max3 / v_med3 / v_max + two v_and_or = 2.5 VALU per value;
+//   * grid = sample panels x row ranges, one 512-thread block per CU, blocks that share a row range on one XCD (same weight
+//     stream from that L2).
+// Error bound: the bias sits inside the accumulation chain, so the screen's bound uses the augmented vectors —
+//   |z~_j - z_j| <= eps * sqrt(||a||^2 + 1) * max_j sqrt(||W_j||^2 + b_j^2)   (qmax_refine_kernel, screen_shadow_block).
+#pragma once
+
+#include "xq_gemm.hip.h"
+
+#include <type_traits>
+
+namespace xq {
+
+struct ScreenArgs {
+    const uint16_t* W;      // bf16 [rows_padded][K], rows >= NO zero, readable up to ranges * cpr * 64 rows
+    const uint16_t* A;      // bf16 [panels * samples-per-block][K] (rows >= n: any finite values)
+    const float* bias;      // fp32 [NO]
+    float* P1; float* P2;   // [G][ldp], G = 2 * number of 64-row chunks; EVERY column < panels * samples-per-block is written
+    int ldp;                //   (ldp >= that: the stores are unconditional, so that the counted vmcnt below never depends on data)
+    int NO, n, K;
+    int nchunks;            // 64-row chunks that hold real rows: ceil(NO / 64)
+    int cpr;                // chunks per row range
+    int panels, ranges;     // grid = panels * ranges
+    int a_frag;             // 1: A is stored in B-fragment order (scr_afrag_index) instead of row-major [sample][K]
+    int xcd_rows;           // 1: the blocks of one XCD share ROW RANGES (weight stream from that L2); 0: they share SAMPLE PANELS
+    unsigned long long* dbg;  // DBG & 8 (probe only): [grid][8] stamps
+};
+
+constexpr int kScrUnitBytes = 64 * 512;      // 64 rows x 256 bf16
+constexpr int kScrBufs = 3;
+
+template <int N> __device__ __forceinline__ void scr_wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Four 1-KB LDS-DMA pieces of one wave (consecutive LDS kilobytes from lds_dst, per-lane 32-bit source offsets off[0..3] from the
+// wave-uniform base).  Inline asm on purpose: hipcc drains vmcnt(0) in front of the next ds_read when it sees the LDS-DMA builtin
+// (it cannot prove that the read and the DMA touch different buffers), which serialises the whole pipeline; an asm statement is
+// invisible to its bookkeeping and the kernel counts vmcnt itself.  M0 (the DMA's LDS base) is compiler-reserved: saved/restored.
+__device__ __forceinline__ void scr_dma4(const void* base, unsigned o0, unsigned o1, unsigned o2, unsigned o3, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+        "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+        "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+        "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base), "s"(lds_dst), "s"(lds_dst + 1024u), "s"(lds_dst + 2048u), "s"(lds_dst + 3072u)
+        : "memory");
+}
+
+// KU = K / 256 (units per chunk), NS = 32-sample column tiles per wave; KU * NS == 2 keeps the register-resident operand at 128 VGPRs
+// ---- pieces of the main loop (all indices that select registers are template arguments: static indexing, no scratch) ----
+// k-steps [SBEG, SBEG + SCNT) of one unit: per step 2 ds_read_b128 (row tiles) and 2 NS MFMAs; the reads of step s + 1 are issued
+// before the MFMAs of step s.  fr = this lane's fragment offset inside a unit (see the kernel), buf = the unit's LDS buffer.
+template <int KU, int NS, int KUI, int SBEG, int SCNT>
+__device__ __forceinline__ void scr_mma(const unsigned char* buf, unsigned fr, const bf16x8 (&bfrag)[NS][16 * KU], f32x16 (&acc)[2][NS]) {
+    bf16x8 af[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[SBEG & 1][i] = *reinterpret_cast<const bf16x8*>(buf + (fr ^ (unsigned)(SBEG << 5)) + 16384 * i);
+#pragma unroll
+    for (int s = SBEG; s < SBEG + SCNT; ++s) {
+        if (s + 1 < SBEG + SCNT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(buf + (fr ^ (unsigned)((s + 1) << 5)) + 16384 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bfrag[j][KUI * 16 + s], acc[i][j], 0, 0, 0);
+    }
+}
+// accumulators of a chunk = its rows' biases (the first MFMA of every tile adds onto them): one ds_read_b128 per 4 rows
+template <int NS>
+__device__ __forceinline__ void scr_bias_init(const float* bt, f32x16 (&acc)[2][NS]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        f32x16 bv;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 x = *reinterpret_cast<const float4*>(bt + 32 * i + 8 * gq);
+            bv[4 * gq] = x.x; bv[4 * gq + 1] = x.y; bv[4 * gq + 2] = x.z; bv[4 * gq + 3] = x.w;
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) acc[i][j] = bv;
+    }
+}
+// fold of a finished chunk: top-2 of the 32 rows a lane holds of each column (code = 16 i + q), two values per step —
+// 2 v_and_or (tags), v_med3, v_max3, and one v_max3 per two steps for the running second value: 2.25 VALU per value
+template <int NS, int DBG>
+__device__ __forceinline__ void scr_fold(const f32x16 (&acc)[2][NS], float* __restrict__ P1, float* __restrict__ P2, long long o) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        float m1 = kColmaxPadBias, m2 = kColmaxPadBias;
+        if (DBG & 1) { m1 = acc[0][j][0] + acc[1][j][5]; m2 = acc[0][j][9]; }
+        else
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                const float vx = acc[i][j][q], vy = acc[i][j][q + 1];      // (a bit_cast of the vector ELEMENT itself reads element 0)
+                const float x = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, vx) & ~31u) | (unsigned)(16 * i + q));
+                const float y = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, vy) & ~31u) | (unsigned)(16 * i + q + 1));
+                const float t = __builtin_amdgcn_fmed3f(m1, x, y);
+                m1 = fmaxf(fmaxf(m1, x), y);          // v_max3_f32
+                m2 = fmaxf(m2, t);
+            }
+        P1[o + 32 * j] = m1;
+        P2[o + 32 * j] = m2;
+    }
+}
+// unit u + 1 has landed once everything older than this iteration's own traffic is complete: the (up to) 4 LDS-DMA pieces of
+// unit u + 2 and the 2 NS partial stores of a finished chunk are the only younger operations of this wave
+template <int NS>
+__device__ __forceinline__ void scr_wait_landed(bool more, bool stored) {
+    if (more) { if (stored) scr_wait_vm<4 + 2 * NS>(); else scr_wait_vm<4>(); }
+    else scr_wait_vm<0>();
+}
+
+// DBG (tools/screen_probe.hip only; 0 in the library): 1 = no fold (stores one accumulator element), 2 = no activation loads,
+// 4 = no LDS-DMA in the loop, 8 = s_memtime / s_memrealtime stamps into a.dbg
+// SPLIT: the two waves of a SIMD (waves w and w + 4 of the block) share its matrix pipe, and the older one wins the arbitration: in
+// every iteration waves 0-3 issue their MFMAs first and waves 4-7 behind them.  With the fold in front of the barrier in all waves,
+// the fold of waves 4-7 would run with the pipe idle (everybody else waits at the barrier).  So waves 4-7 fold BEHIND the barrier,
+// at the top of the next iteration, under the MFMAs of waves 0-3 (their own MFMAs could not issue then anyway); waves 0-3 fold in
+// front of the barrier, under the MFMAs of waves 4-7.  Waves 0-3 also get s_setprio 1 so that this order does not hang on age.
+template <int KU, int NS, int SPLIT = 1, int DBG = 0>
+__global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
+    static_assert(KU * NS == 2, "register budget: NS * K / 4 = 128 VGPRs of activations");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // [kScrBufs][32 KB] units, then cpr * 64 bias floats
+    constexpr int K = 256 * KU;
+    constexpr int SB = 8 * 32 * NS;                  // samples per block
+    constexpr int NBUF = kScrBufs;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);                  // provably wave-uniform (scalar registers)
+    const int r5 = lane & 31, h = lane >> 5;
+    // block -> (row range, sample panel); blocks b and b + 8 share an XCD (observed round-robin placement; speed only)
+    const int nb = (int)gridDim.x;
+    int lin = (int)blockIdx.x;
+    if ((nb & 7) == 0) lin = ((int)blockIdx.x & 7) * (nb >> 3) + ((int)blockIdx.x >> 3);
+    const int range = a.xcd_rows ? lin / a.panels : lin % a.ranges;
+    const int panel = a.xcd_rows ? lin - range * a.panels : lin / a.ranges;
+    const int c_first = range * a.cpr;
+    const int nch = min(a.cpr, a.nchunks - c_first);             // chunks of this block (>= 1 by construction of the grid)
+    const int U = nch * KU;                                      // units to stream
+    unsigned long long st0 = 0, sr0 = 0;
+    if (DBG & 8) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+    float* bias_s = reinterpret_cast<float*>(lds + NBUF * kScrUnitBytes);
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)lds);   // LDS byte address of the ring
+    const bool late = SPLIT && wid >= 4;
+    if (SPLIT && wid < 4) __builtin_amdgcn_s_setprio(1);
+
+    // ---- weight stream: unit u = (chunk u / KU, k-half u % KU) -> buffer u % NBUF, four 1-KB LDS-DMA pieces per wave ----
+    // piece p = 4 wid + j holds rows 2p, 2p + 1; the lane at linear LDS position (row, c) fetches 16-byte chunk c ^ (row & 15)
+    unsigned srcoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wid * 4 + j) * 2 + (lane >> 5);
+        srcoff[j] = (unsigned)(row * K * 2 + (((lane & 31) ^ (row & 15)) << 4));
+    }
+    auto issue_unit = [&](int u) {
+        const int c = c_first + u / KU, ku = u % KU;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.W) + ((long long)c * 64 * K + ku * 256) * 2;
+        scr_dma4(base, srcoff[0], srcoff[1], srcoff[2], srcoff[3], lds0 + (unsigned)((u % NBUF) * kScrUnitBytes + wid * 4096));
+    };
+    issue_unit(0);
+    if (U > 1) issue_unit(1);
+    // ---- bias of this block's rows -> LDS (rows >= NO: a finite very negative value; tagging -inf would make a NaN) ----
+    for (int i = tid; i < nch * 64; i += 512) {
+        const int row = c_first * 64 + i;
+        bias_s[i] = row < a.NO ? a.bias[row] : kColmaxPadBias;
+    }
+    // ---- this wave's samples, whole k-range, in MFMA B-fragment order: lane (r5, h) holds k = 16 s + 8 h .. + 7 of sample r5.
+    //      a_frag: the producer wrote the operand in exactly this order (scr_afrag_index) => every load is 1 KB contiguous ----
+    const int s0 = panel * SB + wid * 32 * NS;
+    bf16x8 bfrag[NS][K / 16];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const uint16_t* ap = a.a_frag ? a.A + ((long long)((s0 >> 5) + j) * (K / 16) * 2 + h) * 256 + r5 * 8
+                                      : a.A + (long long)(s0 + 32 * j + r5) * K + 8 * h;
+        const int sstride = a.a_frag ? 512 : 16;
+#pragma unroll
+        for (int s = 0; s < K / 16; ++s) {
+            if (DBG & 2) { const short v = (short)(0x3c00 + lane + s); bfrag[j][s] = __builtin_bit_cast(bf16x8, (short __attribute__((ext_vector_type(8)))){v, v, v, v, v, v, v, v}); }
+            else bfrag[j][s] = *reinterpret_cast<const bf16x8*>(ap + (long long)sstride * s);
+        }
+    }
+    scr_wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the bias ds_writes (a raw s_barrier waits for no counter)
+    __builtin_amdgcn_s_barrier();
+
+    // fragment of k-step s, row tile i: chunk (2 s + h) ^ (r5 & 15) of row 32 i + r5.  2 s + h = 2 s ^ h, so the byte offset inside
+    // the unit is  (r5 * 512 | ((h ^ (r5 & 15)) << 4)) ^ (s << 5)  + 16384 i : ONE register, one v_xor per k-step, immediates for i
+    const unsigned frag0 = (unsigned)(r5 * 512) | (unsigned)((h ^ (r5 & 15)) << 4);
+    unsigned long long st1 = 0, sr1 = 0;
+    if (DBG & 8) { st1 = __builtin_amdgcn_s_memtime(); sr1 = __builtin_amdgcn_s_memrealtime(); }
+    f32x16 acc[2][NS];
+    const long long ocol = (long long)s0 + r5;
+    int cl = 0;
+    // one iteration = one unit; the k-half arrives as a type so that everything that selects registers stays a constant expression
+    auto iteration = [&](auto kuc) {
+        constexpr int ku = decltype(kuc)::value;
+        const int u = cl * KU + ku;
+        const bool more = u + 2 < U;
+        if (more && !(DBG & 4)) issue_unit(u + 2);
+        bool stored = false;
+        if (late && ku == 0 && cl > 0) {                         // waves 4-7: the fold of the previous chunk, behind its barrier
+            scr_fold<NS, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + cl - 1) + h) * a.ldp + ocol);
+            stored = true;
+        }
+        unsigned fr = frag0;
+        asm volatile("" : "+v"(fr));                             // opaque: keeps the 16 per-step offsets out of 16 loop-invariant registers
+        const unsigned char* buf = lds + (u % NBUF) * kScrUnitBytes;
+        if (ku == 0) scr_bias_init<NS>(bias_s + cl * 64 + 4 * h, acc);
+        scr_mma<KU, NS, ku, 0, 16>(buf, fr, bfrag, acc);
+        if (!late && ku == KU - 1) {                             // waves 0-3: fold in front of the barrier
+            scr_fold<NS, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + cl) + h) * a.ldp + ocol);
+            stored = true;
+        }
+        if (DBG & 4) scr_wait_vm<0>(); else scr_wait_landed<NS>(more, stored);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment read of this unit has returned: its buffer may be refilled
+        __builtin_amdgcn_s_barrier();
+    };
+    for (; cl < nch; ++cl) {
+        iteration(std::integral_constant<int, 0>{});
+        if constexpr (KU > 1) iteration(std::integral_constant<int, KU - 1>{});
+    }
+    if (late) scr_fold<NS, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + nch - 1) + h) * a.ldp + ocol);
+    if (DBG & 8) {
+        const unsigned long long st2 = __builtin_amdgcn_s_memtime(), sr2 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long* o = a.dbg + (size_t)blockIdx.x * 8;
+            o[0] = st1 - st0; o[1] = sr1 - sr0; o[2] = st2 - st1; o[3] = sr2 - sr1; o[4] = (unsigned long long)U; o[5] = sr0;
+        }
+    }
+}
+
+// grid geometry for (NO outputs, n samples, K): one block per CU when the problem allows
+inline void screen_geometry(int NO, int n, int K, int ncu, ScreenArgs& a) {
+    const int SB = K == 256 ? 512 : 256;
+    a.NO = NO; a.n = n; a.K = K;
+    a.nchunks = (NO + 63) / 64;
+    a.panels = (n + SB - 1) / SB;
+    int ranges = ncu / a.panels;
+    if (ranges < 1) ranges = 1;
+    if (ranges > a.nchunks) ranges = a.nchunks;
+    a.cpr = (a.nchunks + ranges - 1) / ranges;
+    a.ranges = (a.nchunks + a.cpr - 1) / a.cpr;
+}
+inline size_t screen_lds_bytes(const ScreenArgs& a) { return (size_t)kScrBufs * kScrUnitBytes + (size_t)a.cpr * 64 * sizeof(float); }
+inline int screen_padded_samples(int n, int K) { const int SB = K == 256 ? 512 : 256; return (n + SB - 1) / SB * SB; }
+
+}  // namespace xq

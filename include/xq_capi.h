@@ -288,7 +288,8 @@ int xq_comm_unique_id(uint8_t* id128);
 /* ncclCommInitRank on the calling process's current device (xq_set_device).  Collective: every rank calls it. */
 int xq_comm_create(int rank, int world, const uint8_t* id128, xq_comm** out);
 /* Same, with the id exchanged through a file every rank can see (rank 0 writes, the others poll up to timeout_s).  `path` must
- * not exist beforehand (a fresh path per run: rank 0 refuses to reuse one, XQ_ERR_IO). */
+ * not exist beforehand (rank 0 refuses a leftover, XQ_ERR_IO: it would hand the other ranks a dead id); rank 0 removes the file
+ * again once every rank has joined, so one path serves run after run. */
 int xq_comm_create_from_file(int rank, int world, const char* path, double timeout_s, xq_comm** out);
 int xq_comm_destroy(xq_comm* c);
 int xq_comm_info(const xq_comm* c, int* rank, int* world, uint64_t* collectives_issued, uint64_t* floats_reduced);
@@ -297,9 +298,10 @@ int xq_comm_sum_u64(xq_comm* c, uint64_t* inout_host);
 /* In-place sum of n_floats fp32 over all ranks on hip_stream (NULL = the communicator's own stream). */
 int xq_comm_allreduce(xq_comm* c, float* buf_dev, size_t n_floats, void* hip_stream);
 /* Attach (or detach with NULL) a communicator: every xq_dqn_td_grads* then all-reduces the gradient buffer itself, in two
- * buckets on the communicator's stream — [hidden + output-layer weights, biases] as soon as the side stream has produced
- * them, the layer-0 segment (the largest and last) behind the layer-0 kernel — and returns with the handle's stream
- * ordered behind both.  xq_dqn_apply_grads therefore sees the global sum.  world = 1 is bit-identical to no communicator. */
+ * buckets, each on the stream of its producer right behind it (no communicator stream, no extra events) — [hidden +
+ * output-layer weights, biases] on the library's side stream, issued first, the layer-0 segment (the largest and last) on
+ * the handle's stream behind the layer-0 kernel — and returns with the handle's stream ordered behind both.
+ * xq_dqn_apply_grads therefore sees the global sum.  world = 1 is bit-identical to no communicator. */
 int xq_dqn_set_comm(xq_dqn* d, xq_comm* comm);
 /* One all-reduce of the whole gradient buffer on the handle's stream, for callers that do not attach a communicator. */
 int xq_allreduce_grads(xq_dqn* d, xq_comm* comm);

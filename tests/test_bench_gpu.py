@@ -39,11 +39,12 @@ def test_bench_line_contract(config, games, dtype):
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     screened = cfg["qmax"]["mode"] == "screened"                 # the exact screen runs on the bf16 pipe whatever the net's dtype
     assert screened == (config in (2, 4))                        # config 5 (Double DQN on a bf16 net) keeps its arg-max GEMM
-    assert r["launches"] == 1 and r["peak"] == (2500.0 if dtype == "bf16" or screened else 157.3)      # every 4th of 4 timed steps
+    assert r["launches"] == 5 and r["peak"] == (2500.0 if dtype == "bf16" or screened else 157.3)      # every 4th of 5 x 4 timed steps
+    assert len(d["ms_per_step_samples"]) == 5 and min(d["ms_per_step_samples"]) <= d["ms_per_step"] <= max(d["ms_per_step_samples"])
     if screened:
         assert cfg["qmax"]["candidate_groups_per_sample"] >= 1.0
         v = d["variant_qmax_full_fp32_product"]
-        assert v["value"] > 0 and v["roofline"]["peak"] == 157.3 and v["roofline"]["launches"] == 1
+        assert v["value"] > 0 and v["roofline"]["peak"] == 157.3 and v["roofline"]["launches"] == 5
     if config == 5:
         assert cfg["prioritized_replay"] is True and "double" in cfg["td_net"] and "bf16" in cfg["q_net_precision"]
     if config == 2:

@@ -338,3 +338,31 @@ def test_config5_full_size_properties(xq):
     c2, w2, b2, prio2, st2, boards2, meta2, loss2 = run()
     assert c2 == c and np.array_equal(w, w2) and np.array_equal(b, b2) and np.array_equal(prio, prio2) and st == st2
     assert np.array_equal(boards, boards2) and np.array_equal(meta, meta2) and loss == loss2
+
+
+def test_bf16_dense_backpropagate_refreshes_the_shadow(xq, trace):
+    """ADVICE r2 (medium): DQN::backpropagate (dense path, dqn.cu:323-467) updates the fp32 master weights; every later bf16 forward
+    must read the UPDATED bf16 shadow — the same numbers a fresh set_params of the new weights gives — and so must a target sync."""
+    sizes = [1260, 128, 8100]
+    d, w, b = make_net(xq, sizes, seed=5)
+    d.set_precision(xq._capi.PRECISION_BF16)
+    n = 32
+    boards = trace["board"][np.random.default_rng(3).choice(len(trace["board"]), n, replace=False)]
+    env = xq.VecEnv(n)
+    env.set_state(boards)
+    q_before = d.q_boards(env, 8100).cpu().numpy()
+    x = xo.state_repr(xo.board_from(boards[0]))
+    target = np.tanh(np.random.default_rng(4).uniform(-1, 1, size=8100))
+    d.backpropagate(x, target, learning_rate=0.5)
+    q_after = d.q_boards(env, 8100).cpu().numpy()
+    assert np.abs(q_after - q_before).max() > 1e-3              # the update is visible to the bf16 forward at all
+    w1, b1 = d.get_params()
+    d.updateTargetNetwork()
+    q_target = d.q_boards(env, 8100, net=1).cpu().numpy()
+    d2 = xq.DQN(sizes, 0.001, 0.99, seed=1)
+    d2.set_params(w1, b1)
+    d2.set_precision(xq._capi.PRECISION_BF16)
+    q_fresh = d2.q_boards(env, 8100).cpu().numpy()
+    assert np.array_equal(q_after, q_fresh)
+    assert np.array_equal(q_target, q_fresh)
+    env.close(); d.close(); d2.close()

@@ -93,9 +93,13 @@ def test_rccl_path_behind_the_c_abi_world_size_one(tmp_path):
         comm.close()
     # file rendezvous (what the C++ facade uses)
     c2 = xd.Comm(rank=0, world=1, path=str(tmp_path / "xq_comm_id"))
-    assert c2.info()["world"] == 1 and (tmp_path / "xq_comm_id").stat().st_size == 128
+    assert c2.info()["world"] == 1
+    assert not (tmp_path / "xq_comm_id").exists()        # rank 0 takes the file away once every rank has joined ...
     c2.close()
-    with pytest.raises(xq.XqError) as e:                 # a stale file would hand out a dead id: rank 0 refuses to reuse the path
+    c3 = xd.Comm(rank=0, world=1, path=str(tmp_path / "xq_comm_id"))     # ... so the same path serves the next run
+    c3.close()
+    (tmp_path / "xq_comm_id").write_bytes(b"\0" * 128)
+    with pytest.raises(xq.XqError) as e:                 # a leftover of a crashed run would hand out a dead id: refused
         xd.Comm(rank=0, world=1, path=str(tmp_path / "xq_comm_id"))
     assert e.value.code == 4
 
@@ -126,21 +130,39 @@ def test_two_rank_independent_shards_on_one_gpu():
 def test_two_rank_rehearsal_on_one_gpu():
     """The whole N > 1 path of bench.py (game sharding, zero-copy gradient view, all-reduce per update, barriers, max-over-
     ranks timing) with two ranks pinned to the one GPU of the box and gloo standing in for RCCL; the replicas must end
-    with bit-identical parameters."""
+    with bit-identical parameters.  Started exactly as the driver starts the N = 1 bench — `python bench.py --gpus 2 ...`, NO
+    external launcher: bench.py spawns its own fresh rank processes before anything touches the GPU."""
     import json
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, XQ_FORCE_DEVICE="0", XQ_DIST_BACKEND="gloo")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--check-replicas"],
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                          "--check-replicas", "--no-cpu-baseline"],
                          capture_output=True, text=True, env=env, cwd=root, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "replicas identical on 2 ranks" in out.stderr
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0's line only
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["parallelism"].startswith("dp2")
+    assert len(line["ms_per_step_samples"]) == 5
+
+
+def test_self_launch_reports_a_failed_rank():
+    """A rank that fails takes the whole self-launched job down with a non-zero exit code (no JSON line, no hang)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XQ_FORCE_DEVICE="99", XQ_DIST_BACKEND="gloo")           # no such device: every rank fails at set_device
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -567,3 +567,67 @@ def test_online_td_next_state_chain_derived_and_direct(xq):
             want = float(R[i]) + 0.99 * xo.nn_forward(sizes, w, b, xo.state_repr(xo.board_from(nxt[i]))).max()
             assert abs(y[i] - want) < 2e-6, (name, i, y[i], want)
     env.close(); d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [CFG2_NET, (1260, 512, 512, 512, 8100)])
+def test_screen_shadow_follows_every_parameter_change(xq, sizes):
+    """The screening pass keeps the bf16 copy (and the row-norm / bias maxima) of output rows >= 96 from step to step — the TD rule
+    only ever writes rows 0..95 — and converts everything again after set_params / updateTargetNetwork / a dense backpropagate.
+    Each of those routes changes a row >= 96 so that it becomes the maximum; a stale shadow would miss it."""
+    from cn_chess_ai_amd import _capi
+    n = 1100
+    env = xq.VecEnv(n, seed=17)
+    for _ in range(12):
+        env.selfplay_step(None)
+    S, _ = env.get_state()
+    res = env.selfplay_step(None)
+    S2, _ = env.get_state()
+    A = (res["action"] % 90).astype(np.int32)
+    R = np.zeros(n, np.float32)
+    D = np.zeros(n, np.uint8)
+    d, w, b = make_net(xq, sizes, seed=21)
+    H = sizes[-2]
+    nb_out0 = len(b) - 8100
+
+    def both(td_net):
+        d.set_qmax_mode(_capi.QMAX_FULL)
+        _, yf = d.td_update(S, S2, A, R, D, td_net=td_net, mode=0, learning_rate=0.0, grad_scale=1.0)
+        d.set_qmax_mode(_capi.QMAX_SCREENED)
+        _, ys = d.td_update(S, S2, A, R, D, td_net=td_net, mode=0, learning_rate=0.0, grad_scale=1.0)
+        assert np.abs(yf - ys).max() < 2e-6
+        return ys
+
+    for td_net in (0, 1):
+        y0 = both(td_net)
+        both(td_net)                                            # a second screened step runs on the kept shadow
+        # (a) set_params: bias of row 5000 up => that output wins everywhere
+        b2 = b.copy(); b2[nb_out0 + 5000] = 3.0
+        d.set_params(w, b2, net=td_net)
+        y1 = both(td_net)
+        assert y1.min() > 0.99 * np.tanh(2.0) and np.abs(y1 - y0).max() > 0.1
+        # (b) weights of row 7001 scaled up (the row NORM maximum changes, and with it the bound)
+        w2 = w.copy(); w2[-8100 * H + 7001 * H:-8100 * H + 7002 * H] *= 40.0
+        d.set_params(w2, b, net=td_net)
+        y2 = both(td_net)
+        for i in range(0, n, 97):
+            q2 = xo.nn_forward(sizes, w2, b, xo.state_repr(xo.board_from(S2[i])))
+            assert abs(y2[i] - 0.99 * q2.max()) < QTOL
+        d.set_params(w, b, net=td_net)
+    # (c) updateTargetNetwork copies a changed online net into the target net the screen had cached
+    both(1)
+    b3 = b.copy(); b3[nb_out0 + 6500] = 2.5
+    d.set_params(w, b3, net=0)
+    d.updateTargetNetwork()
+    y3 = both(1)
+    assert y3.min() > 0.99 * np.tanh(1.5)
+    # (d) a TD step with a learning rate really leaves rows >= 96 alone (what the kept shadow relies on)
+    d.set_params(w, b, net=0)
+    both(0)
+    d.set_qmax_mode(_capi.QMAX_SCREENED)
+    d.td_update(S, S2, A, R, D, td_net=0, mode=0, learning_rate=0.05, grad_scale=1.0 / n)
+    w4, b4 = d.get_params()
+    assert np.array_equal(w4[-8100 * H + 96 * H:], w[-8100 * H + 96 * H:].astype(np.float32).astype(np.float64))
+    assert not np.array_equal(w4[-8100 * H:-8100 * H + 96 * H], w[-8100 * H:-8100 * H + 96 * H].astype(np.float32).astype(np.float64))
+    both(0)
+    env.close(); d.close()
