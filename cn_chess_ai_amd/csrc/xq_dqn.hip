@@ -554,12 +554,13 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
 // zmax / zidx are [kReduceParts][n], td_delta_kernel folds the last kReduceParts values of its sample itself.
 enum { kReduceParts = 4 };
 __global__ __launch_bounds__(256) void colmax_reduce_kernel(const float* __restrict__ partial_all, const int* __restrict__ partial_idx_all,
-                                                            int n_partial_all, int n, float* __restrict__ zmax_all, int* __restrict__ zidx_all) {
+                                                            int n_partial_all, int n, long long ld, float* __restrict__ zmax_all,
+                                                            int* __restrict__ zidx_all) {
     const int per = (n_partial_all + kReduceParts - 1) / kReduceParts;
     const int t0 = (int)blockIdx.y * per;
     const int n_partial = max(0, min(per, n_partial_all - t0));
-    const float* partial = partial_all + (long long)t0 * n;
-    const int* partial_idx = partial_idx_all ? partial_idx_all + (long long)t0 * n : nullptr;
+    const float* partial = partial_all + (long long)t0 * ld;          // rows of the partial arrays are `ld` apart (>= n)
+    const int* partial_idx = partial_idx_all ? partial_idx_all + (long long)t0 * ld : nullptr;
     float* zmax = zmax_all + (long long)blockIdx.y * n;
     int* zidx = zidx_all + (long long)blockIdx.y * n;
     __shared__ float sv[4][64];
@@ -576,8 +577,8 @@ __global__ __launch_bounds__(256) void colmax_reduce_kernel(const float* __restr
         int vi[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            v[u] = ok ? partial[(long long)(t + 4 * u) * n + b] : -__builtin_inff();
-            vi[u] = (ok && arg) ? partial_idx[(long long)(t + 4 * u) * n + b] : 0x7fffffff;
+            v[u] = ok ? partial[(long long)(t + 4 * u) * ld + b] : -__builtin_inff();
+            vi[u] = (ok && arg) ? partial_idx[(long long)(t + 4 * u) * ld + b] : 0x7fffffff;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -586,8 +587,8 @@ __global__ __launch_bounds__(256) void colmax_reduce_kernel(const float* __restr
         }
     }
     for (; t < n_partial; t += 4) {
-        const float v = ok ? partial[(long long)t * n + b] : -__builtin_inff();
-        const int vi = (ok && arg) ? partial_idx[(long long)t * n + b] : 0x7fffffff;
+        const float v = ok ? partial[(long long)t * ld + b] : -__builtin_inff();
+        const int vi = (ok && arg) ? partial_idx[(long long)t * ld + b] : 0x7fffffff;
         if (arg) { if (v > m || (v == m && vi < mi)) { m = v; mi = vi; } }
         else m = fmaxf(m, v);
     }
@@ -1238,7 +1239,8 @@ static int ensure_capacity(xq_dqn* d, int n) {
     const int ntn = (d->nout() + 63) / 64;             // column-max partials: 2 per 64- or 128-row tile
     float** bufs[] = {&d->q90, &d->partial, &d->qsa, &d->yv, &d->lossv, &d->dsc, reinterpret_cast<float**>(&d->act_mb), &d->zmax,
                       reinterpret_cast<float**>(&d->zidx)};
-    const size_t sizes[] = {cap * 96, cap * (size_t)ntn * 2, cap, cap, cap, cap, cap, cap * kReduceParts, cap * kReduceParts};
+    // (partials: the sample dimension padded to whole blocks of screen_top2_kernel, which stores every column of its panels)
+    const size_t sizes[] = {cap * 96, (size_t)round_up(n, 512) * (size_t)ntn * 2, cap, cap, cap, cap, cap, cap * kReduceParts, cap * kReduceParts};
     for (int i = 0; i < 9; ++i) {
         if (*bufs[i]) XQ_HIP(hipFree(*bufs[i]));
         XQ_HIP(hipMalloc(bufs[i], sizes[i] * sizeof(float)));
@@ -1254,7 +1256,7 @@ static int ensure_capacity(xq_dqn* d, int n) {
 static int ensure_ext_capacity(xq_dqn* d, int n, bool want_double) {
     int maxh = 0;
     for (int l = 0; l + 1 < d->nl; ++l) maxh = std::max(maxh, d->L[l + 1]);
-    const size_t rows = (size_t)round_up(n, 128);
+    const size_t rows = (size_t)round_up(n, 512);      // whole-tile reads of the persistent GEMM (128) / whole panels of screen_top2_kernel (512)
     if (d->bf16() && n > d->cap_bf) {
         XQ_HIP(hipDeviceSynchronize());
         for (int l = 0; l + 1 < d->nl; ++l) {
@@ -1284,7 +1286,7 @@ static int ensure_ext_capacity(xq_dqn* d, int n, bool want_double) {
         XQ_HIP(hipDeviceSynchronize());
         if (d->partial_idx) XQ_HIP(hipFree(d->partial_idx));
         const int ntn = (d->nout() + 63) / 64;
-        XQ_HIP(hipMalloc(&d->partial_idx, (size_t)n * (size_t)ntn * 2 * sizeof(int)));
+        XQ_HIP(hipMalloc(&d->partial_idx, (size_t)round_up(n, 512) * (size_t)ntn * 2 * sizeof(int)));
         d->cap_idx = n;
     }
     return XQ_OK;
@@ -2175,7 +2177,28 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         }
         zparts = 1;
     } else {
-    {
+    long long part_ld = n;              // row stride of the partial arrays
+    int n_part = n_partial;
+    if (bf && (Hl == 256 || Hl == 512) && n >= 1024) {
+        // bf16 Q-net: the same kernel as the screening pass (xq_screen.hip.h) in its exact max / arg-max mode — here the bf16 product
+        // IS the net's output layer, not a screen: per 32-row lane group the largest value (+ its row, first maximum: Double DQN)
+        ScreenArgs a; memset(&a, 0, sizeof a);
+        a.W = d->wl_bf(sel_net, nl - 1); a.A = touts_bf[nl - 2]; a.a_frag = 0; a.bias = d->bl(sel_net, nl - 1);
+        a.P1 = d->partial; a.P2 = reinterpret_cast<float*>(d->partial_idx);
+        screen_geometry(NO, n, Hl, d->ncu, a);
+        a.ldp = screen_padded_samples(n, Hl);
+        part_ld = a.ldp; n_part = 2 * a.nchunks;
+        const size_t lds = screen_lds_bytes(a);
+        auto launch = [&](auto kern) {
+            static bool ready = false;       // per instantiation
+            if (!ready) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); ready = true; }
+            hipLaunchKernelGGL(kern, dim3(a.panels * a.ranges), dim3(512), lds, d->cur, a);
+        };
+        ProfScope ps(d, "gemm_qmax_rowmax", 2.0 * NO * (double)n * Hl, 2.0 * ((double)NO * Hl + (double)n * Hl) + 8.0 * n_part * n);
+        if (Hl == 256) { if (dbl) launch(screen_top2_kernel<1, 2, SCR_ARG>); else launch(screen_top2_kernel<1, 2, SCR_MAX>); }
+        else { if (dbl) launch(screen_top2_kernel<2, 1, SCR_ARG>); else launch(screen_top2_kernel<2, 1, SCR_MAX>); }
+        XQ_HIP(hipGetLastError());
+    } else {
         GemmArgs g; memset(&g, 0, sizeof g);
         g.M = NO; g.N = n;
         if (bf) {
@@ -2220,9 +2243,9 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     }
     XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
     {   // the partial maxima of every sample folded into kReduceParts values (+ row indices): coalesced, block-cooperative
-        ProfScope ps(d, "colmax_reduce", (double)n * n_partial, (dbl ? 8.0 : 4.0) * n * (n_partial + kReduceParts));
+        ProfScope ps(d, "colmax_reduce", (double)n * n_part, (dbl ? 8.0 : 4.0) * n * (n_part + kReduceParts));
         hipLaunchKernelGGL(colmax_reduce_kernel, dim3((n + 63) / 64, kReduceParts), dim3(256), 0, d->cur, d->partial,
-                           dbl ? d->partial_idx : nullptr, n_partial, n, d->zmax, d->zidx);
+                           dbl ? d->partial_idx : nullptr, n_part, n, part_ld, d->zmax, d->zidx);
         XQ_HIP(hipGetLastError());
     }
     }   // !screened

@@ -36,6 +36,7 @@ struct ScreenArgs {
     const uint16_t* A;      // bf16 [panels * samples-per-block][K] (rows >= n: any finite values)
     const float* bias;      // fp32 [NO]
     float* P1; float* P2;   // [G][ldp], G = 2 * number of 64-row chunks; EVERY column < panels * samples-per-block is written
+                            //   (P2: second values for SCR_TOP2, int row indices for SCR_ARG, unused for SCR_MAX)
     int ldp;                //   (ldp >= that: the stores are unconditional, so that the counted vmcnt below never depends on data)
     int NO, n, K;
     int nchunks;            // 64-row chunks that hold real rows: ceil(NO / 64)
@@ -109,13 +110,19 @@ __device__ __forceinline__ void scr_bias_init(const float* bt, f32x16 (&acc)[2][
         for (int j = 0; j < NS; ++j) acc[i][j] = bv;
     }
 }
-// fold of a finished chunk: top-2 of the 32 rows a lane holds of each column (code = 16 i + q), two values per step —
-// 2 v_and_or (tags), v_med3, v_max3, and one v_max3 per two steps for the running second value: 2.25 VALU per value
-template <int NS, int DBG>
-__device__ __forceinline__ void scr_fold(const f32x16 (&acc)[2][NS], float* __restrict__ P1, float* __restrict__ P2, long long o) {
+// What the fold keeps per (sample, 32-row lane group): SCR_TOP2 the largest value tagged with its position + the second largest
+// (exact screening of an fp32 net); SCR_ARG the exact largest value and its row, first maximum (Double DQN on a bf16 net: P2 holds
+// int row indices); SCR_MAX the exact largest value only (bf16 net, plain maximum).
+enum { SCR_TOP2 = 0, SCR_ARG = 1, SCR_MAX = 2 };
+// fold of a finished chunk over the 32 rows a lane holds of each column (code = 16 i + q; row = rowbase + 32 i + (q & 3) + 8 (q >> 2)).
+// SCR_TOP2, two values per step: 2 v_and_or (tags), v_med3, v_max3, and one v_max3 per two steps for the running second value =
+// 2.25 VALU per value.  SCR_ARG: rows ascending with a strict > (the lane's first maximum): compare + two selects per value.
+template <int NS, int MODE, int DBG>
+__device__ __forceinline__ void scr_fold(const f32x16 (&acc)[2][NS], float* __restrict__ P1, float* __restrict__ P2, long long o, int rowbase) {
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         float m1 = kColmaxPadBias, m2 = kColmaxPadBias;
+        int mi = 0x7fffffff;
         if (DBG & 1) { m1 = acc[0][j][0] + acc[1][j][5]; m2 = acc[0][j][9]; }
         else
 #pragma unroll
@@ -123,21 +130,30 @@ __device__ __forceinline__ void scr_fold(const f32x16 (&acc)[2][NS], float* __re
 #pragma unroll
             for (int q = 0; q < 16; q += 2) {
                 const float vx = acc[i][j][q], vy = acc[i][j][q + 1];      // (a bit_cast of the vector ELEMENT itself reads element 0)
-                const float x = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, vx) & ~31u) | (unsigned)(16 * i + q));
-                const float y = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, vy) & ~31u) | (unsigned)(16 * i + q + 1));
-                const float t = __builtin_amdgcn_fmed3f(m1, x, y);
-                m1 = fmaxf(fmaxf(m1, x), y);          // v_max3_f32
-                m2 = fmaxf(m2, t);
+                if (MODE == SCR_TOP2) {
+                    const float x = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, vx) & ~31u) | (unsigned)(16 * i + q));
+                    const float y = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, vy) & ~31u) | (unsigned)(16 * i + q + 1));
+                    const float t = __builtin_amdgcn_fmed3f(m1, x, y);
+                    m1 = fmaxf(fmaxf(m1, x), y);          // v_max3_f32
+                    m2 = fmaxf(m2, t);
+                } else if (MODE == SCR_ARG) {
+                    const int rx = rowbase + 32 * i + (q & 3) + 8 * (q >> 2);
+                    if (vx > m1) { m1 = vx; mi = rx; }
+                    if (vy > m1) { m1 = vy; mi = rx + 1; }
+                } else {
+                    m1 = fmaxf(fmaxf(m1, vx), vy);
+                }
             }
         P1[o + 32 * j] = m1;
-        P2[o + 32 * j] = m2;
+        if (MODE == SCR_TOP2) P2[o + 32 * j] = m2;
+        if (MODE == SCR_ARG) reinterpret_cast<int*>(P2)[o + 32 * j] = mi;
     }
 }
 // unit u + 1 has landed once everything older than this iteration's own traffic is complete: the (up to) 4 LDS-DMA pieces of
 // unit u + 2 and the 2 NS partial stores of a finished chunk are the only younger operations of this wave
-template <int NS>
+template <int NSTORES>
 __device__ __forceinline__ void scr_wait_landed(bool more, bool stored) {
-    if (more) { if (stored) scr_wait_vm<4 + 2 * NS>(); else scr_wait_vm<4>(); }
+    if (more) { if (stored) scr_wait_vm<4 + NSTORES>(); else scr_wait_vm<4>(); }
     else scr_wait_vm<0>();
 }
 
@@ -148,8 +164,9 @@ __device__ __forceinline__ void scr_wait_landed(bool more, bool stored) {
 // the fold of waves 4-7 would run with the pipe idle (everybody else waits at the barrier).  So waves 4-7 fold BEHIND the barrier,
 // at the top of the next iteration, under the MFMAs of waves 0-3 (their own MFMAs could not issue then anyway); waves 0-3 fold in
 // front of the barrier, under the MFMAs of waves 4-7.  Waves 0-3 also get s_setprio 1 so that this order does not hang on age.
-template <int KU, int NS, int SPLIT = 1, int DBG = 0>
+template <int KU, int NS, int MODE = SCR_TOP2, int SPLIT = 1, int DBG = 0>
 __global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
+    constexpr int NSTORES = (MODE == SCR_MAX ? 1 : 2) * NS;     // partial stores of one wave per finished chunk
     static_assert(KU * NS == 2, "register budget: NS * K / 4 = 128 VGPRs of activations");
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // [kScrBufs][32 KB] units, then cpr * 64 bias floats
     constexpr int K = 256 * KU;
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
         if (more && !(DBG & 4)) issue_unit(u + 2);
         bool stored = false;
         if (late && ku == 0 && cl > 0) {                         // waves 4-7: the fold of the previous chunk, behind its barrier
-            scr_fold<NS, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + cl - 1) + h) * a.ldp + ocol);
+            scr_fold<NS, MODE, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + cl - 1) + h) * a.ldp + ocol, 64 * (c_first + cl - 1) + 4 * h);
             stored = true;
         }
         unsigned fr = frag0;
@@ -239,10 +256,10 @@ __global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
         if (ku == 0) scr_bias_init<NS>(bias_s + cl * 64 + 4 * h, acc);
         scr_mma<KU, NS, ku, 0, 16>(buf, fr, bfrag, acc);
         if (!late && ku == KU - 1) {                             // waves 0-3: fold in front of the barrier
-            scr_fold<NS, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + cl) + h) * a.ldp + ocol);
+            scr_fold<NS, MODE, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + cl) + h) * a.ldp + ocol, 64 * (c_first + cl) + 4 * h);
             stored = true;
         }
-        if (DBG & 4) scr_wait_vm<0>(); else scr_wait_landed<NS>(more, stored);
+        if (DBG & 4) scr_wait_vm<0>(); else scr_wait_landed<NSTORES>(more, stored);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment read of this unit has returned: its buffer may be refilled
         __builtin_amdgcn_s_barrier();
     };
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
         iteration(std::integral_constant<int, 0>{});
         if constexpr (KU > 1) iteration(std::integral_constant<int, KU - 1>{});
     }
-    if (late) scr_fold<NS, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + nch - 1) + h) * a.ldp + ocol);
+    if (late) scr_fold<NS, MODE, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + nch - 1) + h) * a.ldp + ocol, 64 * (c_first + nch - 1) + 4 * h);
     if (DBG & 8) {
         const unsigned long long st2 = __builtin_amdgcn_s_memtime(), sr2 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {

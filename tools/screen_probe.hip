@@ -21,8 +21,8 @@ static int screen_row_host(int g, int code) { const int q = code & 15; return (g
 template <int KU, int NS, int DBG = 0, int SPLIT = 1> static void launch_new(const ScreenArgs& a, hipStream_t s) {
     static bool once = false;
     const size_t lds = screen_lds_bytes(a);
-    if (!once) { CK(hipFuncSetAttribute((const void*)screen_top2_kernel<KU, NS, SPLIT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
-    hipLaunchKernelGGL((screen_top2_kernel<KU, NS, SPLIT, DBG>), dim3(a.panels * a.ranges), dim3(512), lds, s, a);
+    if (!once) { CK(hipFuncSetAttribute((const void*)screen_top2_kernel<KU, NS, SCR_TOP2, SPLIT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+    hipLaunchKernelGGL((screen_top2_kernel<KU, NS, SCR_TOP2, SPLIT, DBG>), dim3(a.panels * a.ranges), dim3(512), lds, s, a);
 }
 
 int main(int argc, char** argv) {
