@@ -46,7 +46,8 @@ CONFIGS = {
             games=8192, layers=(1260, 512, 512, 512, 8100), replay=1 << 20, minibatch=8192, plies=4, td="online", dtype="f32",
             prioritized=0, bf16=False),
     5: dict(workload="BASELINE configs[4], per-GPU share (131072 games / 8): 16384 games, Double-DQN + proportional prioritized replay "
-                     "(alpha 0.6, beta 0.4), bf16 MFMA Q-net 1260-512-512-512-8100 (fp32 master weights and backward), replay 1M, "
+                     "(alpha 0.6, beta 0.4), bf16 MFMA Q-net 1260-512-512-512-8100 (bf16 operands in the forward AND backward products, "
+                     "fp32 accumulation, fp32 master weights), replay 1M, "
                      "minibatch 16384, one update per ply",
             games=16384, layers=(1260, 512, 512, 512, 8100), replay=1 << 20, minibatch=16384, plies=1, td="double", dtype="bf16",
             prioritized=1, bf16=True),
@@ -243,6 +244,8 @@ def main():
     ap.add_argument("--qmax", choices=("screened", "full"), default="screened",
                     help="max_a' Q(s',a') of the TD target: exact bf16 screening + fp32 re-evaluation (default) or the full fp32 product")
     ap.add_argument("--bracket-all", action="store_true", help="HIP-event bracket around EVERY launch of the dominant GEMM (default: every 4th)")
+    ap.add_argument("--bf16-fp32-backward", action="store_true",
+                    help="--config 5: XQ_PRECISION_BF16 (bf16 forward, fp32 backward products) instead of XQ_PRECISION_BF16_FULL")
     ap.add_argument("--no-variants", action="store_true", help="skip the variant legs (other TD net, full fp32 product): A/B runs")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps, barrier + synchronize on both sides) is run this many times back to "
@@ -297,7 +300,8 @@ def main():
                            backprop_mode=_capi.BACKPROP_REFERENCE, target_sync_interval=args.target_sync_interval, mean_gradient=1,
                            seed=0x5EED, first_game_id=first, overlap_collect=0 if args.no_overlap else 1,
                            collects_per_update=CFG["plies"], prioritized=CFG["prioritized"],
-                           precision=_capi.PRECISION_BF16 if CFG["bf16"] else _capi.PRECISION_F32)
+                           precision=(_capi.PRECISION_BF16 if args.bf16_fp32_backward else _capi.PRECISION_BF16_FULL) if CFG["bf16"]
+                           else _capi.PRECISION_F32)
     plies = CFG["plies"]
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
     t.dqn.set_qmax_mode(_capi.QMAX_SCREENED if args.qmax == "screened" else _capi.QMAX_FULL)
@@ -458,12 +462,15 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": CFG["dtype"], "data": "synthetic",
             "dtype_note": ("weights, activations, Q-values, TD targets and gradients fp32; with config.qmax.mode = screened the candidates for "
                            "max_a' Q(s',a') are found on bf16 MFMA under a rigorous bound and re-evaluated in fp32 (same maximum)"
-                           if CFG["dtype"] == "f32" else "bf16 forward passes, fp32 accumulation, fp32 master weights and backward"),
+                           if CFG["dtype"] == "f32" else "bf16 operands on the matrix pipe (forward and backward products), fp32 accumulation, "
+                           "fp32 master weights, fp32 layer-0 / output-layer / bias gradients"),
             "config": {"workload": CFG["workload"], "baseline_config": args.config,
                        "games_per_gpu": n_games, "layer_sizes": list(LAYERS), "replay_capacity": max(REPLAY, n_games),
                        "minibatch": minibatch, "plies_per_update": plies, "epsilon": 0.1, "backprop": "reference-compatible",
                        "td_net": td_text, "prioritized_replay": bool(CFG["prioritized"]),
-                       "q_net_precision": "bf16 forward (fp32 master weights, fp32 backward)" if CFG["bf16"] else "fp32",
+                       "q_net_precision": ("bf16 forward (fp32 master weights, fp32 backward)" if args.bf16_fp32_backward else
+                                           "bf16 forward and bf16 operands in the backward products (fp32 accumulation, fp32 master weights)")
+                                          if CFG["bf16"] else "fp32",
                        "target_sync_interval": args.target_sync_interval,
                        "target_syncs_in_timed_region": (c1["updates"] // max(args.target_sync_interval, 1)
                                                         - c0["updates"] // max(args.target_sync_interval, 1)) / len(samples)

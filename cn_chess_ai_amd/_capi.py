@@ -17,7 +17,7 @@ MAX_LAYERS = 8
 NET_ONLINE, NET_TARGET = 0, 1
 BACKPROP_REFERENCE, BACKPROP_TEXTBOOK = 0, 1
 TD_ONLINE_NET, TD_TARGET_NET, TD_DOUBLE = 0, 1, 2
-PRECISION_F32, PRECISION_BF16 = 0, 1
+PRECISION_F32, PRECISION_BF16, PRECISION_BF16_FULL = 0, 1, 2
 QMAX_FULL, QMAX_SCREENED = 0, 1
 
 STATUS_NAMES = {1: "XQ_ERR_INVALID_ARGUMENT", 2: "XQ_ERR_RUNTIME", 3: "XQ_ERR_NO_DEVICE", 4: "XQ_ERR_IO",

@@ -17,6 +17,7 @@
 #include "xq_internal.h"
 #include "xq_gemm.hip.h"
 #include "xq_screen.hip.h"
+#include "xq_gemm_bf16.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -47,7 +48,9 @@ struct xq_dqn {
     uint16_t* tacts_bf[2] = {nullptr, nullptr};
     uint16_t* t2acts_bf[2] = {nullptr, nullptr};
     uint16_t* sel_acts_bf[XQ_MAX_LAYERS] = {nullptr};
-    int cap_bf = 0, sel_cap_bf = 0;
+    uint16_t* deltas_bf[XQ_MAX_LAYERS] = {nullptr};    // XQ_PRECISION_BF16_FULL: the hidden deltas rounded to bf16 (operands of the backward products)
+    int cap_bf = 0, sel_cap_bf = 0, cap_dbf = 0;
+    bool bg_ready = false;                             // dynamic-LDS attribute of the gemm_bf16_kernel instances set
     float* t2acts[2] = {nullptr, nullptr};             // third forward chain of a Double-DQN step (s' on the target net)
     int cap_t2 = 0;
     int* partial_idx = nullptr;  int cap_idx = 0;      // row index of each column-max partial (Double DQN)
@@ -116,7 +119,8 @@ struct xq_dqn {
 
     // partial-sum slabs may stay unreduced until the SGD kernel only when nothing (an all-reduce) reads the buffer in between
     bool fused() const { return fused_apply && comm == nullptr; }
-    bool bf16() const { return precision == XQ_PRECISION_BF16; }
+    bool bf16() const { return precision != XQ_PRECISION_F32; }               // bf16 forward passes
+    bool bf16_bwd() const { return precision == XQ_PRECISION_BF16_FULL; }     // ... and bf16 operands in the backward products
     uint16_t* wl_bf(int net, int l) const { return params_bf[net] + (l == 0 ? 0 : (size_t)L[0] * L[1] + (wo[l] - wo[1])); }
     float* w0t(int net) const { return params[net]; }
     float* wrest(int net) const { return params[net] + (size_t)L[0] * L[1]; }     // layers 1.. in reference flat order
@@ -432,9 +436,15 @@ __constant__ unsigned char kL0SquareOrder[90] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 19, 
 // zeros; here block (sq, chunk) compacts the samples of its chunk that occupy `sq` (ascending sample order, so the sums
 // are bitwise reproducible), then streams their delta rows (1 KB each, L2-resident) into 14 LDS accumulator rows.
 // partial[chunk][sq*14 + piece-1][H]; the ordered chunk reduction is the usual reduce_slabs_kernel.
-__global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict__ gboards, const float* __restrict__ delta0,
-                                                      int n, int H, int chunk, int nsets, float* __restrict__ partial) {
+// Wide layers: blockIdx.z picks a slab of HS columns (grid z = H / HS) — at H = 512 one block per (square, chunk) could keep only two
+// accumulator sets in LDS (two of its four waves streaming, 265 us at 16384 x 512); two 256-column slabs are two blocks of the
+// H = 256 shape each (four sets, 2 blocks per CU).  Every slab compacts the chunk for itself (cheap) and streams its own columns.
+__global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict__ gboards, const float* __restrict__ delta0_all,
+                                                      int n, int Hfull, int HS, int chunk, int nsets, float* __restrict__ partial_all) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = HS;                                   // width this block works on; rows of delta0 / partial are Hfull apart
+    const float* __restrict__ delta0 = delta0_all + (long long)blockIdx.z * HS;
+    float* __restrict__ partial = partial_all + (long long)blockIdx.z * HS;
     float* acc = smem;                                  // [nsets][14][H]
     uint16_t* list = reinterpret_cast<uint16_t*>(smem + (long long)nsets * 14 * H);   // [chunk] (b_local | piece << 11)
     // workgroups go to the 8 XCDs round-robin in linear order: chunk = linear id mod nchunks keeps all 90 square-blocks of a chunk
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     e[u] = list[i + u * nsets];
-                    const float4 x = *reinterpret_cast<const float4*>(delta0 + (long long)(c0 + (e[u] & 2047)) * H + col);
+                    const float4 x = *reinterpret_cast<const float4*>(delta0 + (long long)(c0 + (e[u] & 2047)) * Hfull + col);
                     v[u].x = x.x; v[u].y = x.y; v[u].z = x.z; v[u].w = x.w;
                 }
 #pragma unroll
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
             }
             for (; i < cnt; i += nsets) {
                 const int e1 = list[i];
-                const float4 x = *reinterpret_cast<const float4*>(delta0 + (long long)(c0 + (e1 & 2047)) * H + col);
+                const float4 x = *reinterpret_cast<const float4*>(delta0 + (long long)(c0 + (e1 & 2047)) * Hfull + col);
                 const int p = __builtin_amdgcn_readfirstlane(e1 >> 11);
                 if (p != cur) { flush(); cur = p; rx = x.x; ry = x.y; rz = x.z; rw = x.w; }
                 else { rx += x.x; ry += x.y; rz += x.z; rw += x.w; }
@@ -533,16 +543,16 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
         for (int col = lane; col < H; col += 64)
             for (int i = 0; i < cnt; ++i) {
                 const int e1 = list[i];
-                acc[((e1 >> 11) - 1) * H + col] += delta0[(long long)(c0 + (e1 & 2047)) * H + col];
+                acc[((e1 >> 11) - 1) * H + col] += delta0[(long long)(c0 + (e1 & 2047)) * Hfull + col];
             }
     }
     __syncthreads();
-    float* out = partial + ((long long)(lin % nch) * kStateSize + (long long)s * 14) * H;
+    float* out = partial + ((long long)(lin % nch) * kStateSize + (long long)s * 14) * Hfull;
     const int used = (H & 3) == 0 ? nsets : 1;
     for (int i = tid; i < 14 * H; i += 256) {
         float t = acc[i];
         for (int w = 1; w < used; ++w) t += acc[(long long)w * 14 * H + i];
-        out[i] = t;
+        out[(long long)(i / H) * Hfull + (i % H)] = t;
     }
 }
 
@@ -617,6 +627,7 @@ struct TdExtra {
     float* prio; unsigned* pmax_live;            // prioritized replay: priority table (by ring slot) and the running maximum (float bits)
     float per_eps, per_alpha;
     int double_dqn, nout;
+    uint16_t* dtop_bf;             // XQ_PRECISION_BF16_FULL: the top hidden delta rounded to bf16 beside the fp32 one
 };
 
 // TD target, output delta and the TOP hidden delta for one sample per wave (chessai.cpp:122-128 +
@@ -713,10 +724,12 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
         const float* vr = view + (long long)a * view_ld;
         for (int i = lane; i < H; i += 64) {
             const float h = ar[i];
-            drow[i] = delta * vr[i] * (1.f - h * h);
+            const float v = delta * vr[i] * (1.f - h * h);
+            drow[i] = v;
+            if (X.dtop_bf) X.dtop_bf[(long long)b * H + i] = bf16_bits(v);
         }
     } else {
-        for (int i = lane; i < H; i += 64) drow[i] = 0.f;
+        for (int i = lane; i < H; i += 64) { drow[i] = 0.f; if (X.dtop_bf) X.dtop_bf[(long long)b * H + i] = 0; }
     }
     }
     if (lane == 0) {
@@ -1202,6 +1215,21 @@ static int launch_gemm(xq_dqn* d, GemmArgs g, int splits, const char* name, int*
 }
 #define XQ_GEMM(expr) XQ_TRY(expr)
 
+// gemm_bf16_kernel (xq_gemm_bf16.hip.h): 256 x 128 tiles, 144 KB of dynamic LDS (attribute set once per instance)
+template <int AL, int BL, int EPI>
+static int launch_bf16_gemm(xq_dqn* d, const Bf16GemmArgs& g, int gz, const char* name) {
+    static bool ready = false;
+    if (!ready) {
+        XQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<AL, BL, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, kBgLdsBytes));
+        ready = true;
+    }
+    const int groups = g.groups > 1 ? g.groups : 1;
+    ProfScope ps(d, name, 2.0 * g.M * g.N * (double)g.K * groups, 2.0 * groups * ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N));
+    hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, EPI>), dim3(g.M / kBgBM, g.N / kBgBN, gz), dim3(512), kBgLdsBytes, d->cur, g);
+    XQ_HIP(hipGetLastError());
+    return XQ_OK;
+}
+
 static int ensure_slabs(xq_dqn* d, size_t floats) {
     if (floats <= d->slabs_cap) return XQ_OK;
     if (d->slabs) { XQ_HIP(hipStreamSynchronize(d->stream)); XQ_HIP(hipFree(d->slabs)); }
@@ -1272,6 +1300,14 @@ static int ensure_ext_capacity(xq_dqn* d, int n, bool want_double) {
             XQ_HIP(hipMemsetAsync(d->t2acts_bf[i], 0, rows * (size_t)maxh * sizeof(uint16_t), d->stream));
         }
         d->cap_bf = n;
+    }
+    if (d->bf16_bwd() && n > d->cap_dbf) {
+        XQ_HIP(hipDeviceSynchronize());
+        for (int l = 0; l + 1 < d->nl; ++l) {
+            if (d->deltas_bf[l]) XQ_HIP(hipFree(d->deltas_bf[l]));
+            XQ_HIP(hipMalloc(&d->deltas_bf[l], rows * d->L[l + 1] * sizeof(uint16_t)));
+        }
+        d->cap_dbf = n;
     }
     if (want_double && n > d->cap_t2) {
         XQ_HIP(hipDeviceSynchronize());
@@ -1384,7 +1420,21 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
         GemmArgs g; memset(&g, 0, sizeof g);
         g.M = n; g.N = d->L[l + 1];
         g.grouped = njobs > 1 ? njobs : 0;
-        if (bf) {
+        if (bf && (n % kBgBM) == 0 && (d->L[l + 1] % kBgBN) == 0 && (d->L[l] % kBgBK) == 0 && !d->small_tiles) {
+            // the bf16 loop of its own (xq_gemm_bf16.hip.h): whole 256 x 128 tiles only, the chains as groups of one launch
+            Bf16GemmArgs b; memset(&b, 0, sizeof b);
+            b.M = n; b.N = d->L[l + 1]; b.K = d->L[l]; b.lda = b.ldb = d->L[l]; b.k_chunk = b.K;
+            b.ldc = d->L[l + 1]; b.ldcb = d->L[l + 1];
+            b.groups = njobs;
+            for (int k = 0; k < njobs; ++k) {
+                const uint16_t* A = jobs[k].outs_bf[l - 1];
+                const uint16_t* B = d->wl_bf(jobs[k].net, l);
+                float* C = jobs[k].outs ? jobs[k].outs[l] : nullptr;
+                if (k == 0) { b.A = A; b.B = B; b.C = C; b.bias = d->bl(jobs[k].net, l); b.Cb = jobs[k].outs_bf[l]; }
+                else { b.Ax[k - 1] = A; b.Bx[k - 1] = B; b.Cx[k - 1] = C; b.biasx[k - 1] = d->bl(jobs[k].net, l); b.Cbx[k - 1] = jobs[k].outs_bf[l]; }
+            }
+            XQ_TRY((launch_bf16_gemm<L_KCONTIG, L_KCONTIG, BG_TANH>(d, b, njobs, "gemm_hidden_fwd")));
+        } else if (bf) {
             if (d->L[l] & 1) return fail(XQ_ERR_INVALID_ARGUMENT, "bf16 Q-net needs even layer widths (layer %d has %d)", l, d->L[l]);
             g.K = d->L[l] / 2; g.lda = g.ldb = d->L[l] / 2;
             g.ldc = d->L[l + 1]; g.ldcb = d->L[l + 1];
@@ -1512,6 +1562,20 @@ static int hidden_deltas(xq_dqn* d, int n, const float* dnext, int ld_next, int 
         g.M = n; g.N = d->L[l + 1];
         const int kfull = (mode == XQ_BACKPROP_REFERENCE) ? d->L[l + 1] : d->L[l + 2];
         g.K = std::min(kfull, nz);
+        if (d->bf16_bwd() && up == d->deltas[l + 1] && (n % kBgBM) == 0 && (g.N % kBgBN) == 0 && (g.K % kBgBK) == 0) {
+            // XQ_PRECISION_BF16_FULL: delta_l = (bf16(delta_{l+1}) . bf16 weight VIEW) (1 - a_l^2) on the bf16 loop — the view is the
+            // same (base, leading dimension) trick as below, applied to the bf16 shadow, which keeps the element order of the master
+            Bf16GemmArgs b; memset(&b, 0, sizeof b);
+            b.M = n; b.N = g.N; b.K = g.K; b.k_chunk = b.K;
+            b.A = d->deltas_bf[l + 1]; b.lda = ld_up;
+            b.B = d->wl_bf(XQ_NET_ONLINE, l + 1); b.ldb = (mode == XQ_BACKPROP_REFERENCE) ? d->L[l] : d->L[l + 1];
+            b.C = d->deltas[l]; b.ldc = d->L[l + 1];
+            b.Cb = d->deltas_bf[l]; b.ldcb = d->L[l + 1];
+            b.Hb = d->acts_bf[l]; b.ldh = d->L[l + 1];
+            XQ_TRY((launch_bf16_gemm<L_KCONTIG, L_MCONTIG, BG_DELTA>(d, b, 1, "gemm_hidden_delta")));
+            up = d->deltas[l]; ld_up = d->L[l + 1]; nz = d->L[l + 1];
+            continue;
+        }
         g.A = up; g.lda = ld_up;
         g.B = d->wrest(XQ_NET_ONLINE) + (d->wo[l + 1] - d->wo[1]);
         g.ldb = (mode == XQ_BACKPROP_REFERENCE) ? d->L[l] : d->L[l + 1];
@@ -1531,12 +1595,47 @@ static int pick_splits(int M, int N, int K) {
     return std::max(1, std::min(s, 32));
 }
 
-// dst[M][N] = sum over the batch: A(m,k) B(k,n), split-K slabs + ordered reduction
+// XQ_PRECISION_BF16_FULL: the hidden weight gradient on the bf16 loop when the shape allows (whole 256 x 128 tiles, whole 64-deep
+// k-tiles per slab); the slab count then comes from the 256 x 128 tiling: one block per CU
+static bool grad_bf16_ok(const xq_dqn* d, int M, int N, int K) {
+    return d->bf16_bwd() && (M % kBgBM) == 0 && (N % kBgBN) == 0 && K >= kBgBK && (K % kBgBK) == 0;
+}
+static int grad_splits(const xq_dqn* d, int M, int N, int K) {
+    if (!grad_bf16_ok(d, M, N, K)) return pick_splits(M, N, K);
+    const int tiles = (M / kBgBM) * (N / kBgBN);
+    int s = std::max(1, d->ncu / tiles);
+    s = std::min(s, 32);
+    while (s > 1 && (K % (s * kBgBK)) != 0) --s;           // whole k-tiles per slab
+    return s;
+}
+
+// dst[M][N] = sum over the batch: A(m,k) B(k,n), split-K slabs + ordered reduction.  a_bf / b_bf: the bf16 copies of the operands
+// ([batch][M] / [batch][N]) for the bf16 loop.
 template <int AL>
 static int grad_gemm(xq_dqn* d, GemmArgs g, float* dst, const char* name, float* slab_base = nullptr,
-                     xq_dqn::PendingSlab* defer = nullptr) {
+                     xq_dqn::PendingSlab* defer = nullptr, const uint16_t* a_bf = nullptr, const uint16_t* b_bf = nullptr) {
     const bool big = false;    // 64-tiles: more tiles, fewer k-splits, cheaper ordered reduction
-    int splits = pick_splits(g.M, g.N, g.K);
+    const bool use_bf = AL == L_MCONTIG && a_bf && b_bf && grad_bf16_ok(d, g.M, g.N, g.K);
+    int splits = use_bf ? grad_splits(d, g.M, g.N, g.K) : pick_splits(g.M, g.N, g.K);
+    if (use_bf) {
+        const long long len = (long long)g.M * g.N;
+        float* slabs = slab_base;
+        Bf16GemmArgs b; memset(&b, 0, sizeof b);
+        b.M = g.M; b.N = g.N; b.K = g.K; b.A = a_bf; b.lda = g.lda; b.B = b_bf; b.ldb = g.ldb; b.k_chunk = g.K / splits;
+        if (splits > 1) {
+            if (!slabs) { XQ_TRY(ensure_slabs(d, (size_t)splits * (size_t)len)); slabs = d->slabs; }
+            b.C = slabs; b.ldc = g.N; b.slab_stride = len;
+        } else { b.C = dst; b.ldc = g.N; }
+        XQ_TRY((launch_bf16_gemm<L_MCONTIG, L_MCONTIG, BG_STORE>(d, b, splits, name)));
+        if (splits > 1 && defer) { defer->src = slabs; defer->nslabs = splits; defer->stride = len; return XQ_OK; }
+        if (splits > 1) {
+            ProfScope ps(d, "reduce_slabs", (double)splits * len, 4.0 * (splits + 1) * len);
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)std::min<long long>((len + 255) / 256, 2048)), dim3(256), 0,
+                               d->cur, slabs, splits, len, len, dst);
+            XQ_HIP(hipGetLastError());
+        }
+        return XQ_OK;
+    }
     const long long len = (long long)g.M * g.N;
     float* slabs = slab_base;
     if (splits > 1) {
@@ -1611,11 +1710,12 @@ static int l0_gradient(xq_dqn* d, int n, float* dst) {
     }
     {
         ProfScope ps(d, "l0_grad_segsum", 2.0 * n * 32 * H, (double)n * (32.0 * H * 4 + 48) + 4.0 * nchunks * len);
+        const int HS = (H > 256 && H % 256 == 0) ? 256 : H;     // column slab per block (grid z): wide layers keep the H = 256 shape
         int nsets = 4;                               // one accumulator set per wave while they fit in 60 KB of LDS
-        while (nsets > 1 && (size_t)nsets * 14 * H * sizeof(float) > 60 * 1024) nsets >>= 1;
-        const size_t shmem = (size_t)nsets * 14 * H * sizeof(float) + (size_t)chunk * sizeof(uint16_t);
+        while (nsets > 1 && (size_t)nsets * 14 * HS * sizeof(float) > 60 * 1024) nsets >>= 1;
+        const size_t shmem = (size_t)nsets * 14 * HS * sizeof(float) + (size_t)chunk * sizeof(uint16_t);
         if (shmem > 64 * 1024) return fail(XQ_ERR_INVALID_ARGUMENT, "first hidden layer too wide for the layer-0 gradient kernel (%d)", H);
-        hipLaunchKernelGGL(l0_grad_kernel, dim3(kSquares, nchunks), dim3(256), shmem, d->cur, d->gboards, d->deltas[0], n, H,
+        hipLaunchKernelGGL(l0_grad_kernel, dim3(kSquares, nchunks, H / HS), dim3(256), shmem, d->cur, d->gboards, d->deltas[0], n, H, HS,
                            chunk, nsets, out);
         XQ_HIP(hipGetLastError());
     }
@@ -1739,6 +1839,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     for (int i = 0; i < 2; ++i) { hipFree(d->params_bf[i]); hipFree(d->tacts_bf[i]); hipFree(d->t2acts_bf[i]); hipFree(d->t2acts[i]); }
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts_bf[l]); hipFree(d->sel_acts_bf[l]); }
     hipFree(d->partial_idx);
+    for (int l = 0; l < XQ_MAX_LAYERS; ++l) hipFree(d->deltas_bf[l]);
     if (d->side) { hipStreamSynchronize(d->side); hipStreamDestroy(d->side); }
     if (d->ev_fork) hipEventDestroy(d->ev_fork);
     if (d->ev_join) hipEventDestroy(d->ev_join);
@@ -1825,10 +1926,11 @@ int xq_dqn_qmax_stats(xq_dqn* d, uint64_t stats[4]) {
 }
 
 int xq_dqn_set_precision(xq_dqn* d, int precision) {
-    if (!d || (precision != XQ_PRECISION_F32 && precision != XQ_PRECISION_BF16)) return fail(XQ_ERR_INVALID_ARGUMENT, "bad precision");
+    if (!d || (precision != XQ_PRECISION_F32 && precision != XQ_PRECISION_BF16 && precision != XQ_PRECISION_BF16_FULL))
+        return fail(XQ_ERR_INVALID_ARGUMENT, "bad precision");
     if (d->l0_pending > 0 || d->pend_wout.nslabs > 0)
         return fail(XQ_ERR_RUNTIME, "xq_dqn_set_precision: a TD step is waiting for its apply_grads");
-    if (precision == XQ_PRECISION_BF16) {
+    if (precision != XQ_PRECISION_F32) {
         for (int l = 1; l <= d->nl - 1; ++l)
             if (d->L[l] & 1) return fail(XQ_ERR_INVALID_ARGUMENT, "bf16 Q-net needs even hidden widths (layer %d has %d)", l, d->L[l]);
         if (!d->params_bf[0]) {
@@ -1988,7 +2090,7 @@ static int side_gradients(xq_dqn* d, int n, float* const* outs, float* G) {
         if (nchunks > 1) need += (size_t)nchunks * (size_t)len_out;
         for (int l = nl - 2; l >= 1; --l) {
             off_h[l] = need;
-            const int sp = pick_splits(d->L[l + 1], d->L[l], n);
+            const int sp = grad_splits(d, d->L[l + 1], d->L[l], n);
             if (sp > 1) need += (size_t)sp * (size_t)d->L[l + 1] * (size_t)d->L[l];
         }
         XQ_TRY(ensure_slabs(d, need));
@@ -2028,7 +2130,8 @@ static int side_gradients(xq_dqn* d, int n, float* const* outs, float* G) {
         g.A = d->deltas[l]; g.lda = d->L[l + 1];
         g.B = outs[l - 1]; g.ldb = d->L[l];
         XQ_TRY((grad_gemm<L_MCONTIG>(d, g, G + d->g_wh[l], "gemm_grad_hidden", fused ? d->slabs + off_h[l] : nullptr,
-                                     fused ? &d->pend_hidden[l] : nullptr)));
+                                     fused ? &d->pend_hidden[l] : nullptr, d->bf16_bwd() ? d->deltas_bf[l] : nullptr,
+                                     d->bf16_bwd() ? d->acts_bf[l - 1] : nullptr)));
         bj.add(d->deltas[l], d->L[l + 1], d->L[l + 1], G + d->g_bh[l]);
     }
     bj.add(d->deltas[0], d->L[1], d->L[1], G + d->g_bh[0]);
@@ -2265,6 +2368,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             else { X.wout_t = d->wl(XQ_NET_TARGET, nl - 1); X.alast_t = t2outs[nl - 2]; }
         }
         if (bf) X.wout_bf = d->wl_bf(XQ_NET_ONLINE, nl - 1);
+        if (d->bf16_bwd()) X.dtop_bf = d->deltas_bf[lt];
         if (per) {
             X.is_w = per->is_w; X.is_wmax = per->is_wmax; X.prio = per->prio; X.pmax_live = per->pmax_live;
             X.per_eps = per->eps; X.per_alpha = per->alpha;

@@ -186,9 +186,13 @@ enum { XQ_TD_ONLINE_NET = 0,       /* max Q(s') from the ONLINE net — what Che
        XQ_TD_DOUBLE = 2 };         /* Double DQN (build-defined, BASELINE configs[4]): a* = argmax_k Q_online(s')[k] over all outputs
                                     * (first maximum), y = r + gamma * Q_target(s')[a*] */
 enum { XQ_PRECISION_F32 = 0,       /* fp32 MFMA everywhere (the reference computes in fp64; north_star: fp32, Q within 1e-4) */
-       XQ_PRECISION_BF16 = 1 };    /* bf16 Q-net (build-defined, BASELINE configs[4]): forward passes on bf16 MFMA — weights and hidden
+       XQ_PRECISION_BF16 = 1,      /* bf16 Q-net (build-defined, BASELINE configs[4]): forward passes on bf16 MFMA — weights and hidden
                                     * activations rounded to bf16 (RNE), fp32 accumulation, biases and outputs fp32; backward and SGD
                                     * in fp32 on the master weights */
+       XQ_PRECISION_BF16_FULL = 2 };/* the same forward, and the dense products of the backward pass on bf16 MFMA too: the lower hidden deltas
+                                    * take the bf16 weights and the upstream delta rounded to bf16, the hidden weight gradients the delta
+                                    * rounded to bf16 and the (already bf16) activations; fp32 accumulation, fp32 deltas for the bias /
+                                    * layer-0 / output-layer gradients, fp32 master weights and SGD (oracle: xqo_ext_td_accum, bf16 = 2) */
 
 enum { XQ_QMAX_FULL = 0,           /* max_a' Q(s',a') of the TD target (chessai.cpp:126-127, dqn.cpp:166-167): every output in fp32 */
        XQ_QMAX_SCREENED = 1 };     /* the same fp32 maximum, found by exact screening: all outputs once on the bf16 matrix pipe with a

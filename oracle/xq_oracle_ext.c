@@ -19,6 +19,12 @@
  *   bf16 Q-net: forward in bf16 — weights rounded to bf16 (RNE, from the fp32 master copy), hidden activations rounded to
  *       bf16 after tanh, products accumulated in >= fp32, biases and the output pre-activation z kept in fp32; backward in
  *       fp32 on the master weights with the rounded activations (1 - a^2 from the stored a).
+ *   bf16 = 2 (XQ_PRECISION_BF16_FULL): the same forward, and bf16 operands in the dense products of the backward pass too
+ *       (mixed precision as in Micikevicius et al., ICLR 2018, without loss scaling: the deltas of this loss are O(1e-3..1)):
+ *       the hidden deltas BELOW the top one multiply the bf16-rounded weights with the upstream delta rounded to bf16, the hidden
+ *       weight gradients (layers 1 .. nl-2) multiply the layer's delta rounded to bf16 with the (already bf16) activations;
+ *       products are exact, sums >= fp32.  Unrounded: the top hidden delta (one scaled row of the master weights), every
+ *       bias gradient, the layer-0 and the output-layer gradients, the master weights and the SGD step.
  */
 #include "xq_oracle.h"
 
@@ -138,10 +144,16 @@ int xqo_ext_td_accum(const int* L, int ns, const double* w, const double* b, con
                 if (L[l + 2] < inputSize || outputSize < L[l + 1] ||
                     wo[l + 1] + (size_t)(inputSize - 1) * outputSize + (size_t)(L[l + 1] - 1) >= nw) { rc = -1; break; }
                 if (l == nl - 2) { if (action_to < inputSize) sum = w[wo[l + 1] + (size_t)action_to * outputSize + idx] * delta; }
-                else for (int i = 0; i < inputSize; ++i) sum += w[wo[l + 1] + (size_t)i * outputSize + idx] * d[l + 1][i];
+                else for (int i = 0; i < inputSize; ++i) {
+                    const double wv = w[wo[l + 1] + (size_t)i * outputSize + idx], dv = d[l + 1][i];
+                    sum += bf16 == 2 ? (double)xqo_bf16_round((float)wv) * (double)xqo_bf16_round((float)dv) : wv * dv;
+                }
             } else {
                 if (l == nl - 2) sum = w[wo[l + 1] + (size_t)action_to * L[l + 1] + idx] * delta;
-                else for (int k = 0; k < up_n; ++k) sum += w[wo[l + 1] + (size_t)k * L[l + 1] + idx] * d[l + 1][k];
+                else for (int k = 0; k < up_n; ++k) {
+                    const double wv = w[wo[l + 1] + (size_t)k * L[l + 1] + idx], dv = d[l + 1][k];
+                    sum += bf16 == 2 ? (double)xqo_bf16_round((float)wv) * (double)xqo_bf16_round((float)dv) : wv * dv;
+                }
             }
             d[l][idx] = sum * (1.0 - a[l + 1][idx] * a[l + 1][idx]);
         }
@@ -154,9 +166,10 @@ int xqo_ext_td_accum(const int* L, int ns, const double* w, const double* b, con
             for (int j = 0; j < L[l + 1]; ++j) {
                 const double dj = d[l][j];
                 gb[bo[l] + j] += dj;
-                if (dj != 0.0)
+                const double dw = (bf16 == 2 && l >= 1) ? (double)xqo_bf16_round((float)dj) : dj;     /* layer 0 sums fp32 delta rows */
+                if (dw != 0.0)
                     for (int i = 0; i < L[l]; ++i)
-                        if (a[l][i] != 0.0) gw[wo[l] + (size_t)j * L[l] + i] += dj * a[l][i];
+                        if (a[l][i] != 0.0) gw[wo[l] + (size_t)j * L[l] + i] += dw * a[l][i];
             }
     }
     if (q_sa) *q_sa = q;

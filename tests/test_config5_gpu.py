@@ -250,11 +250,11 @@ def test_new_transitions_enter_with_the_maximum_priority(xq):
 
 
 # ------------------------------------------------------------------------------------------------ the whole configs[4] loop
-def _cfg5(xq, n, cap, minibatch, sizes, overlap, plies=1, seed=31):
+def _cfg5(xq, n, cap, minibatch, sizes, overlap, plies=1, seed=31, precision=1):
     return xq.TrainerConfig(n_games=n, layer_sizes=sizes, learning_rate=0.01, gamma=0.99, epsilon=0.2, replay_capacity=cap,
                             minibatch=minibatch, td_net=xq._capi.TD_DOUBLE, backprop_mode=0, target_sync_interval=3,
                             mean_gradient=1, seed=seed, first_game_id=11, collects_per_update=plies, overlap_collect=overlap,
-                            prioritized=1, per_alpha=0.6, per_beta=0.4, per_eps=1e-3, precision=xq._capi.PRECISION_BF16)
+                            prioritized=1, per_alpha=0.6, per_beta=0.4, per_eps=1e-3, precision=precision)
 
 
 @pytest.mark.parametrize("overlap,n,cap,minibatch,plies,iters", [(0, 64, 256, 48, 1, 9), (1, 64, 256, 48, 1, 9), (1, 32, 200, 64, 2, 8)])
@@ -311,12 +311,13 @@ def test_config5_trainer_equals_its_composition(xq, overlap, n, cap, minibatch, 
     t.close(); env.close(); d.close(); rp.close()
 
 
-def test_config5_full_size_properties(xq):
+@pytest.mark.parametrize("precision", [1, 2])       # XQ_PRECISION_BF16 (fp32 backward products) / XQ_PRECISION_BF16_FULL (what bench.py --config 5 runs)
+def test_config5_full_size_properties(xq, precision):
     """BASELINE configs[4] per GPU: 16384 games (131072 / 8), (512,512,512) bf16 Q-net, Double DQN, prioritized replay from a 1 M
     ring, minibatch 16384.  Size-independent properties: counters, finite parameters, priorities of sampled slots positive, the
     tree total equals the sequential sums of the priority table, and a bit-identical rerun."""
     def run():
-        cfg = _cfg5(xq, 16384, 1 << 20, 16384, CFG4_NET, 1, seed=0x5EED)
+        cfg = _cfg5(xq, 16384, 1 << 20, 16384, CFG4_NET, 1, seed=0x5EED, precision=precision)
         t = xq.Trainer(cfg)
         t.random_plies(60)
         t.step(4)
@@ -366,3 +367,45 @@ def test_bf16_dense_backpropagate_refreshes_the_shadow(xq, trace):
     assert np.array_equal(q_after, q_fresh)
     assert np.array_equal(q_target, q_fresh)
     env.close(); d.close(); d2.close()
+
+
+@pytest.mark.parametrize("td_rule,mode", [(2, 0), (0, 1)])
+def test_bf16_full_td_update_matches_oracle(xq, trace, td_rule, mode):
+    """XQ_PRECISION_BF16_FULL at a batch the bf16 GEMM loop of its own takes (n = 256 = one 256-row tile; widths 512): forward chains,
+    hidden deltas and hidden weight gradients on gemm_bf16_kernel (xq_gemm_bf16.hip.h), against the oracle's bf16 = 2 definition."""
+    sizes = CFG4_NET
+    n = 256
+    S, A, R, D, S2 = transitions(trace, valid_indices(trace, n, seed=6))
+    d, w, b = make_net(xq, sizes, seed=9)
+    wt, bt = xo.init_weights(sizes, 78)
+    d.set_params(wt, bt, net=1)
+    d.set_precision(xq._capi.PRECISION_BF16_FULL)
+    R = R / 1000.0
+    lr, scale = 0.5, 1.0 / n
+    want_w, want_b, want_q, want_y, _ = oracle_update(sizes, w, b, wt, bt, S, A, R, D, S2, 0.99, lr, scale, mode, td_rule, bf16=2)
+    qsa, y = d.td_update(S, S2, A, R, D, td_net=td_rule, mode=mode, learning_rate=lr, grad_scale=scale)
+    assert np.abs(qsa - want_q).max() < BF16_QTOL
+    same_action = np.abs(y - want_y) < 2 * BF16_QTOL
+    assert same_action.mean() > (0.7 if td_rule == 2 else 0.999)
+    got_w, got_b = d.get_params()
+    # per layer: the update agrees with the oracle's within 5 % of its largest entry (bf16 noise of the forward moves the deltas a
+    # little; samples whose arg-max flipped move them more — their share is bounded above)
+    off = 0
+    for l in range(len(sizes) - 1):
+        cnt = sizes[l] * sizes[l + 1]
+        dw = (want_w - w)[off:off + cnt]
+        err = np.abs((got_w - want_w)[off:off + cnt]).max()
+        assert np.abs(dw).max() > 0
+        tol = 0.05 if same_action.all() else 0.25
+        assert err <= tol * np.abs(dw).max() + 1e-7, (l, err, np.abs(dw).max())
+        off += cnt
+    assert np.abs(got_b - want_b).max() <= (0.05 if same_action.all() else 0.25) * np.abs(want_b - b).max() + 1e-7
+    # and the plain bf16 mode (fp32 backward) gives a DIFFERENT update on the same data: the mode is really in effect
+    d2, _, _ = make_net(xq, sizes, seed=9)
+    d2.set_params(wt, bt, net=1)
+    d2.set_precision(xq._capi.PRECISION_BF16)
+    d2.td_update(S, S2, A, R, D, td_net=td_rule, mode=mode, learning_rate=lr, grad_scale=scale)
+    w2, _ = d2.get_params()
+    h1 = slice(sizes[0] * sizes[1], sizes[0] * sizes[1] + sizes[1] * sizes[2])
+    assert np.abs(w2[h1] - got_w[h1]).max() > 0
+    d.close(); d2.close()

@@ -65,3 +65,34 @@ def test_sum_tree_sampler_is_proportional():
         assert (prio[slots] > 0).all() and wmax == w.max()
     big = prio > 0.5
     assert abs(counts[big].sum() / counts.sum() - prio[big].sum() / prio.sum()) < 0.01
+
+
+def test_bf16_backward_definition_stays_close_to_the_fp32_backward(golden_dir):
+    """XQ_PRECISION_BF16_FULL (oracle bf16 = 2): bf16 operands in the lower hidden deltas and the hidden weight gradients.  Same forward
+    as bf16 = 1 (bit-identical Q and y); the update differs from the fp32-backward one by a few bf16 roundings per product — stated
+    tolerance: 2 % of the update's largest entry per parameter block — and it is not the same function (the rounding is applied)."""
+    trace = np.load(os.path.join(golden_dir, "ref_trace.npz"))
+    sizes = [1260, 64, 64, 64, 8100]
+    n = 24
+    S, A, R, D, S2 = transitions(trace, valid_indices(trace, n, seed=5))
+    R = R / 1000.0
+    w, b = xo.init_weights(sizes, 5)
+    b = np.random.default_rng(2).uniform(-0.05, 0.05, size=len(b))
+    wt, bt = xo.init_weights(sizes, 6)
+    for mode in (0, 1):
+        u1 = oracle_update(sizes, w, b, wt, bt, S, A, R, D, S2, 0.99, 1.0, 1.0 / n, mode, 2, bf16=1)
+        u2 = oracle_update(sizes, w, b, wt, bt, S, A, R, D, S2, 0.99, 1.0, 1.0 / n, mode, 2, bf16=2)
+        assert np.array_equal(u1[2], u2[2]) and np.array_equal(u1[3], u2[3]) and np.array_equal(u1[4], u2[4])
+        dw1, dw2 = u1[0] - w, u2[0] - w
+        off = 0
+        for l in range(len(sizes) - 1):
+            cnt = sizes[l] * sizes[l + 1]
+            a, c = dw1[off:off + cnt], dw2[off:off + cnt]
+            assert np.abs(a).max() > 0
+            assert np.abs(a - c).max() <= 0.02 * np.abs(a).max(), (mode, l)
+            if l == len(sizes) - 2:
+                assert np.array_equal(a, c)                 # output layer: untouched by the mode
+            elif l >= 1:
+                assert np.abs(a - c).max() > 0              # hidden layers: really rounded
+            off += cnt
+        assert np.abs((u1[1] - b) - (u2[1] - b)).max() <= 0.02 * np.abs(u1[1] - b).max()
