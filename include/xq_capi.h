@@ -192,7 +192,7 @@ enum { XQ_PRECISION_F32 = 0,       /* fp32 MFMA everywhere (the reference comput
        XQ_PRECISION_BF16_FULL = 2 };/* the same forward, and the dense products of the backward pass on bf16 MFMA too: the lower hidden deltas
                                     * take the bf16 weights and the upstream delta rounded to bf16, the hidden weight gradients the delta
                                     * rounded to bf16 and the (already bf16) activations; fp32 accumulation, fp32 deltas for the bias /
-                                    * layer-0 / output-layer gradients, fp32 master weights and SGD (oracle: xqo_ext_td_accum, bf16 = 2) */
+                                    * layer-0 / output-layer gradients, fp32 master weights and SGD (defined in DESIGN.md section 4) */
 
 enum { XQ_QMAX_FULL = 0,           /* max_a' Q(s',a') of the TD target (chessai.cpp:126-127, dqn.cpp:166-167): every output in fp32 */
        XQ_QMAX_SCREENED = 1 };     /* the same fp32 maximum, found by exact screening: all outputs once on the bf16 matrix pipe with a
