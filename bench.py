@@ -117,22 +117,25 @@ def cpu_baseline(seconds=15.0):
     return out
 
 
-def pmc_traffic(kernel_substring):
-    """HBM bytes per launch of a kernel from the newest committed rocprofv3 --pmc summary (profiles/*_pmc_hbm_traffic.json,
-    made by tools/collect_profiles.sh + tools/summarize_profiles.py on this same bench command: separate FETCH_SIZE /
-    WRITE_SIZE passes, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction).  None if absent: PMC counters
-    cannot be read from inside the timed run."""
+def pmc_traffic(kernel_substring, config=2):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 --pmc summary of this configuration
+    (profiles/*_pmc_hbm_traffic.json for configs[1], profiles/*_config<K>_pmc_hbm_traffic.json for the others; made by
+    tools/collect_profiles*.sh + tools/summarize_profiles.py on this same bench command: separate FETCH_SIZE / WRITE_SIZE passes,
+    bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction).  None if absent: PMC counters cannot be read from inside
+    the timed run."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        data = json.load(open(files[-1]))
-    except Exception:
-        return None, None
-    for k, v in data.items():
-        if kernel_substring in k:
-            return v.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+    if config == 2:
+        files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")) if "_config" not in os.path.basename(f))
+    else:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_config%d_pmc_hbm_traffic.json" % config)))
+    for path in reversed(files):
+        try:
+            data = json.load(open(path))
+        except Exception:
+            continue
+        for k, v in data.items():
+            if kernel_substring in k:
+                return v.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -498,10 +501,15 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             bf16_pipe = screened_kernel or CFG["bf16"]
             peak = PEAK_BF16_MFMA_TFLOPS if bf16_pipe else PEAK_F32_MFMA_TFLOPS
-            # template arguments as rocprofv3 prints them: <TM, TN, DT (0 f32 / 1 bf16), MODE (0 max / 1 arg-max / 2 top-2 screen)>
-            inst = "gemm_colmax_persistent_kernel<2, 2, %d, %d>" % (1 if bf16_pipe else 0,
-                                                                     2 if screened_kernel else 1 if args.td_net == "double" else 0)
-            tr, src = pmc_traffic(inst) if args.config == 2 else (None, None)
+            # kernel instance as rocprofv3 prints it.  bf16 pipe, last hidden width 256 / 512: screen_top2_kernel<KU, NS, MODE, 0>
+            # (xq_screen.hip.h; MODE 0 = top-2 screen, 1 = arg-max, 2 = max); fp32: gemm_colmax_persistent_kernel<2, 2, 0, MODE>
+            if bf16_pipe and LAYERS[-2] in (256, 512):
+                ku = LAYERS[-2] // 256
+                inst = "screen_top2_kernel<%d, %d, %d, 0>" % (ku, 2 // ku, 0 if screened_kernel else 1 if args.td_net == "double" else 2)
+            else:
+                inst = "gemm_colmax_persistent_kernel<2, 2, %d, %d>" % (1 if bf16_pipe else 0,
+                                                                         2 if screened_kernel else 1 if args.td_net == "double" else 0)
+            tr, src = pmc_traffic(inst, args.config)
             what = ("exact screen of max_a' Q(s'): all outputs once on bf16 MFMA, top-2 per 32-output group" if screened_kernel else
                     "%s_a' Q(s')" % ("argmax" if args.td_net == "double" else "max"))
             r = {"kernel": "%s (%s: 8100 x %d x %d, %s MFMA)" % (inst, what, minibatch, LAYERS[-2], "bf16" if bf16_pipe else "f32"),
@@ -535,7 +543,7 @@ def main():
             ach = by / (ms * 1e-3) / 1e9
             line["roofline_env"] = {"kernel": "env_kernel<SELFPLAY> (movegen+select+move+reward+reset, %d boards)" % n_games,
                                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                    "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("env_kernel<2>")[0] if args.config == 2 else None, "avg_launch_ms": ms,
+                                    "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("env_kernel<2>", args.config)[0], "avg_launch_ms": ms,
                                     "bytes_per_launch": by, "launches": e["launches"]}
             mix = env_instruction_mix() if args.config == 2 else None
             if mix:

@@ -17,7 +17,7 @@
 #include "xq_internal.h"
 #include "xq_gemm.hip.h"
 #include "xq_screen.hip.h"
-#include "xq_gemm_bf16.hip.h"
+#include "xq_gemm_dma.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -73,6 +73,7 @@ struct xq_dqn {
     uint16_t* scr_wb = nullptr;                 // [round_up(nout,128)][hlast] (rows >= nout zero)
     uint16_t* scr_ab = nullptr;  int scr_cap = 0;   // [round_up(cap,512)][hlast]: row-major, or B-fragment order for screen_top2_kernel
     float* scr_p1 = nullptr; float* scr_p2 = nullptr;   // [4*tiles_m][round_up(cap,512)]
+    float* scr_R = nullptr; float* scr_na = nullptr;    // [chunks][round_up(cap,512)] per-range maxima, [round_up(cap,512)] ||bf16(a)||^2
     // bits of the largest row norm / largest |bias| of the output layer (non-negative floats order like unsigned): [0..1] rows 0..95 by
     // step parity, [2..3] their biases by step parity, [4] rows >= 96, [5] their biases.  Only rows 0..95 change under the TD rule
     // (xq_dqn_td_grads never touches the others), so the shadow of rows >= 96 and slots [4], [5] are kept from step to step:
@@ -1132,6 +1133,110 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
     }
 }
 
+// Pass 2 behind screen_top2_kernel (xq_screen.hip.h), which also leaves R[range][sample] = the largest P1 of the sample over the groups
+// of one row range and na[sample] = ||bf16(a)||^2: the threshold needs 16 values per sample instead of 254, and only the groups of the
+// ranges that reach it are looked at (usually one: the kernel reads ~1/10 of the partial arrays, and no activation rows for the norm).
+// ||a|| <= ||bf16(a)|| (1 + 2^-7): inside the slack of kScreenEps (2^-7 * 0.0625 - 2^-12 - 2^-16 = 2.3e-4 against 6.1e-5 + the fp32
+// rounding of the sum of squares).  Same block shape, candidate lists and fp32 re-evaluation as qmax_refine_kernel.
+template <int KFIX>
+__global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restrict__ R, int ranges, int gpr /* groups per range */,
+                                                           const float* __restrict__ P1, const float* __restrict__ P2, int G, int n, long long ldp,
+                                                           const float* __restrict__ na_all, const float* __restrict__ a_last, int K,
+                                                           const float* __restrict__ W, const float* __restrict__ bias, int NO,
+                                                           unsigned* __restrict__ wm, int parity, float* __restrict__ zmax,
+                                                           unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cand[];            // [G * 32]: sample | row << 5
+    uint16_t* wlist = reinterpret_cast<uint16_t*>(cand + (size_t)G * kRefineSamples);    // [G * 32]: sample | group << 5
+    __shared__ float sv[8][32];
+    __shared__ float thr[32];
+    __shared__ int best[32];
+    __shared__ int cnt, nexp;
+    const int tid = (int)threadIdx.x;
+    const int sl = tid & 31, phase = tid >> 5;
+    const int ql = tid & 15, quarter = tid >> 4;
+    const int b0 = (int)blockIdx.x * kRefineSamples;
+    const int b = b0 + sl;
+    const bool ok = b < n;
+    const int bc = min(b, n - 1);
+    if (tid == 0) { cnt = 0; nexp = 0; if (blockIdx.x == 0) { wm[parity ^ 1] = 0u; wm[2 + (parity ^ 1)] = 0u; } }   // next step's slots
+    if (tid < 32) best[tid] = (int)0x80000000;
+    float m = kColmaxPadBias;
+    for (int r = phase; r < ranges; r += 8) m = fmaxf(m, R[(long long)r * ldp + bc]);
+    sv[phase][sl] = m;
+    __syncthreads();
+    if (tid < 32) {
+        m = sv[0][sl];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) m = fmaxf(m, sv[p][sl]);
+        const float wmx = fmaxf(__builtin_bit_cast(float, wm[parity]), __builtin_bit_cast(float, wm[4]));
+        const float bmx = fmaxf(__builtin_bit_cast(float, wm[2 + parity]), __builtin_bit_cast(float, wm[5]));
+        const float B = kScreenEps * sqrtf(na_all[bc]) * wmx + kScreenBiasEps * bmx;
+        thr[sl] = ok ? m - 2.f * B * 1.03125f - 1.52587890625e-05f * (fabsf(m) + 2.f * B) : __builtin_inff();   // no candidates past n
+    }
+    __syncthreads();
+    {
+        const float t = thr[sl];
+        for (int r = phase; r < ranges; r += 8) {
+            if (R[(long long)r * ldp + bc] < t) continue;        // no group of this range reaches the threshold
+            const int g0 = r * gpr, g1 = min(G, g0 + gpr);
+            for (int g = g0; g < g1; g += 4) {                   // four independent loads in flight
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = P1[(long long)min(g + u, g1 - 1) * ldp + bc];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (g + u < g1 && v[u] >= t) {
+                        const float v2 = P2[(long long)(g + u) * ldp + bc];
+                        if (v2 >= t) wlist[atomicAdd(&nexp, 1)] = (uint16_t)(sl | ((g + u) << 5));
+                        else cand[atomicAdd(&cnt, 1)] = (uint32_t)sl | ((uint32_t)screen_row(g + u, (int)(__builtin_bit_cast(uint32_t, v[u]) & 31u)) << 5);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // fp32 dots of the candidates (the maximum does not depend on the order they are visited in)
+    const int singles = cnt, wholes = nexp;
+    for (int e0 = 0; e0 < singles; e0 += 64) {                   // 16 quarters x 4 rows per round, all loads of a round in flight
+        float z[4];
+        int s2[4], row[4];
+        bool live[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = e0 + quarter + 16 * r;
+            live[r] = e < singles;
+            const uint32_t ent = cand[live[r] ? e : 0];
+            s2[r] = (int)(ent & 31u);
+            row[r] = min((int)(ent >> 5), NO - 1);
+            z[r] = quarter_dot<KFIX>(a_last + (long long)(b0 + s2[r]) * K, W + (long long)row[r] * K, K, ql);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            z[r] = quarter_sum(z[r]) + bias[row[r]];
+            if (live[r] && ql == 0) atomicMax(&best[s2[r]], float_order_key(z[r]));
+        }
+    }
+    for (int e = 0; e < wholes; ++e) {                           // a whole group: its 32 rows over the 16 quarters, one round
+        const int ent = wlist[e];
+        const int s2 = ent & 31, g = ent >> 5;
+        float zb = kColmaxPadBias;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = screen_row(g, quarter + 16 * r);
+            const int rc = min(row, NO - 1);
+            const float z = quarter_sum(quarter_dot<KFIX>(a_last + (long long)(b0 + s2) * K, W + (long long)rc * K, K, ql)) + bias[rc];
+            if (row < NO) zb = fmaxf(zb, z);
+        }
+        if (ql == 0) atomicMax(&best[s2], float_order_key(zb));
+    }
+    __syncthreads();
+    if (tid < 32 && ok) zmax[b] = float_from_key(best[sl]);
+    if (tid == 0) {
+        atomicAdd(&stats[2], (unsigned long long)(singles + wholes));
+        atomicAdd(&stats[3], (unsigned long long)wholes);
+    }
+}
+
 // bf16 shadow of a weight range (set_params / load_model / set_precision)
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -1215,19 +1320,25 @@ static int launch_gemm(xq_dqn* d, GemmArgs g, int splits, const char* name, int*
 }
 #define XQ_GEMM(expr) XQ_TRY(expr)
 
-// gemm_bf16_kernel (xq_gemm_bf16.hip.h): 256 x 128 tiles, 144 KB of dynamic LDS (attribute set once per instance)
-template <int AL, int BL, int EPI>
-static int launch_bf16_gemm(xq_dqn* d, const Bf16GemmArgs& g, int gz, const char* name) {
+// gemm_dma_kernel (xq_gemm_dma.hip.h): (128 TI) x (64 TJ) tiles, up to 144 KB of dynamic LDS (attribute set once per instance)
+template <int DT, int AL, int BL, int EPI, int TI, int TJ>
+static int launch_dma_gemm(xq_dqn* d, const Bf16GemmArgs& g, int gz, const char* name) {
     static bool ready = false;
+    constexpr int lds = bg_lds_bytes(TI, TJ);
     if (!ready) {
-        XQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<AL, BL, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, kBgLdsBytes));
+        XQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<DT, AL, BL, EPI, TI, TJ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ready = true;
     }
     const int groups = g.groups > 1 ? g.groups : 1;
-    ProfScope ps(d, name, 2.0 * g.M * g.N * (double)g.K * groups, 2.0 * groups * ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N));
-    hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, EPI>), dim3(g.M / kBgBM, g.N / kBgBN, gz), dim3(512), kBgLdsBytes, d->cur, g);
+    const double es = DT == DT_F32 ? 4.0 : 2.0;
+    ProfScope ps(d, name, 2.0 * g.M * g.N * (double)g.K * groups, es * groups * ((double)g.M * g.K + (double)g.N * g.K + 2.0 * g.M * g.N));
+    hipLaunchKernelGGL((gemm_dma_kernel<DT, AL, BL, EPI, TI, TJ>), dim3(g.M / (128 * TI), g.N / (64 * TJ), gz), dim3(512), lds, d->cur, g);
     XQ_HIP(hipGetLastError());
     return XQ_OK;
+}
+template <int AL, int BL, int EPI>
+static int launch_bf16_gemm(xq_dqn* d, const Bf16GemmArgs& g, int gz, const char* name) {
+    return launch_dma_gemm<DT_BF16, AL, BL, EPI, 2, 2>(d, g, gz, name);
 }
 
 static int ensure_slabs(xq_dqn* d, size_t floats) {
@@ -1361,6 +1472,10 @@ static int ensure_screen_capacity(xq_dqn* d, int n) {
         XQ_HIP(hipMemset(d->scr_ab, 0, rows * Hl * sizeof(uint16_t)));
         XQ_HIP(hipMalloc(&d->scr_p1, G * rows * sizeof(float)));
         XQ_HIP(hipMalloc(&d->scr_p2, G * rows * sizeof(float)));
+        if (d->scr_R) XQ_HIP(hipFree(d->scr_R));
+        if (d->scr_na) XQ_HIP(hipFree(d->scr_na));
+        XQ_HIP(hipMalloc(&d->scr_R, (size_t)((NO + 63) / 64) * rows * sizeof(float)));       // at most one range per 64-row chunk
+        XQ_HIP(hipMalloc(&d->scr_na, rows * sizeof(float)));
         d->scr_cap = n;
     }
     return XQ_OK;
@@ -1845,7 +1960,8 @@ int xq_dqn_destroy(xq_dqn* d) {
     if (d->ev_join) hipEventDestroy(d->ev_join);
     if (d->ev_delta) hipEventDestroy(d->ev_delta);
     if (d->ev_qmax) hipEventDestroy(d->ev_qmax);
-    for (void* q : {(void*)d->scr_wb, (void*)d->scr_ab, (void*)d->scr_p1, (void*)d->scr_p2, (void*)d->scr_wmax, (void*)d->scr_stats})
+    for (void* q : {(void*)d->scr_wb, (void*)d->scr_ab, (void*)d->scr_p1, (void*)d->scr_p2, (void*)d->scr_wmax, (void*)d->scr_stats, (void*)d->scr_R,
+                    (void*)d->scr_na})
         if (q) hipFree(q);
     if (d->scr_guard_host) hipHostFree(d->scr_guard_host);
     if (d->scr_guard_ev) hipEventDestroy(d->scr_guard_ev);
@@ -2219,13 +2335,15 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         // 32-row lane groups: the tile kernel writes all 4 per 128-row tile, screen_top2_kernel only those of 64-row chunks with real rows
         const int G = scr_new ? 2 * ((NO + 63) / 64) : 4 * tiles_m;
         long long ldp = n;
+        int scr_ranges = 0, scr_gpr = 0;
         if (scr_new) {
             ScreenArgs a; memset(&a, 0, sizeof a);
             a.W = d->scr_wb; a.A = d->scr_ab; a.a_frag = 1; a.bias = d->bl(sel_net, nl - 1);
-            a.P1 = d->scr_p1; a.P2 = d->scr_p2;
+            a.P1 = d->scr_p1; a.P2 = d->scr_p2; a.R = d->scr_R; a.na = d->scr_na;
             screen_geometry(NO, n, Hl, d->ncu, a);
             a.ldp = screen_padded_samples(n, Hl);
             ldp = a.ldp;
+            scr_ranges = a.ranges; scr_gpr = 2 * a.cpr;
             const size_t lds = screen_lds_bytes(a);
             if (!d->scr_new_kernel_ready) {
                 XQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(screen_top2_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2266,6 +2384,13 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
                                    d->bl(sel_net, nl - 1), NO, d->scr_wmax, parity, d->zmax, d->scr_stats);
             };
             const bool small = G <= 8 * 32;
+            if (scr_new) {
+                auto launch2 = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, d->scr_R, scr_ranges, scr_gpr, d->scr_p1, d->scr_p2, G, n, ldp, d->scr_na,
+                                       touts[nl - 2], Hl, d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, d->scr_wmax, parity, d->zmax, d->scr_stats);
+                };
+                if (Hl == 256) launch2(qmax_refine2_kernel<256>); else launch2(qmax_refine2_kernel<512>);
+            } else
             if (Hl == 256) { if (small) launch(qmax_refine_kernel<256, 32>); else launch(qmax_refine_kernel<256, 64>); }
             else if (Hl == 512) { if (small) launch(qmax_refine_kernel<512, 32>); else launch(qmax_refine_kernel<512, 64>); }
             else { if (small) launch(qmax_refine_kernel<0, 32>); else launch(qmax_refine_kernel<0, 64>); }

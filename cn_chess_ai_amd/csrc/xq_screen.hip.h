@@ -38,6 +38,9 @@ struct ScreenArgs {
     float* P1; float* P2;   // [G][ldp], G = 2 * number of 64-row chunks; EVERY column < panels * samples-per-block is written
                             //   (P2: second values for SCR_TOP2, int row indices for SCR_ARG, unused for SCR_MAX)
     int ldp;                //   (ldp >= that: the stores are unconditional, so that the counted vmcnt below never depends on data)
+    float* R;               // SCR_TOP2: [ranges][ldp] largest P1 of every sample over the groups of one row range (the refine kernel
+                            //   looks at 16 of these per sample instead of 254 partials, and then only at the ranges that matter)
+    float* na;              // SCR_TOP2: [ldp] sum of squares of the sample's bf16 activations (the bound's ||a||^2, from the registers)
     int NO, n, K;
     int nchunks;            // 64-row chunks that hold real rows: ceil(NO / 64)
     int cpr;                // chunks per row range
@@ -50,6 +53,7 @@ struct ScreenArgs {
 constexpr int kScrUnitBytes = 64 * 512;      // 64 rows x 256 bf16
 constexpr int kScrBufs = 3;
 
+__device__ __forceinline__ long long ocol_of(int s0, int r5) { return (long long)s0 + r5; }
 template <int N> __device__ __forceinline__ void scr_wait_vm() {
     static_assert(N >= 0 && N < 64, "vmcnt");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -118,7 +122,8 @@ enum { SCR_TOP2 = 0, SCR_ARG = 1, SCR_MAX = 2 };
 // SCR_TOP2, two values per step: 2 v_and_or (tags), v_med3, v_max3, and one v_max3 per two steps for the running second value =
 // 2.25 VALU per value.  SCR_ARG: rows ascending with a strict > (the lane's first maximum): compare + two selects per value.
 template <int NS, int MODE, int DBG>
-__device__ __forceinline__ void scr_fold(const f32x16 (&acc)[2][NS], float* __restrict__ P1, float* __restrict__ P2, long long o, int rowbase) {
+__device__ __forceinline__ void scr_fold(const f32x16 (&acc)[2][NS], float* __restrict__ P1, float* __restrict__ P2, long long o, int rowbase,
+                                         float (&bmax)[NS]) {
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         float m1 = kColmaxPadBias, m2 = kColmaxPadBias;
@@ -145,6 +150,7 @@ __device__ __forceinline__ void scr_fold(const f32x16 (&acc)[2][NS], float* __re
                 }
             }
         P1[o + 32 * j] = m1;
+        bmax[j] = fmaxf(bmax[j], m1);                 // running maximum of this lane's groups over the block's chunks
         if (MODE == SCR_TOP2) P2[o + 32 * j] = m2;
         if (MODE == SCR_ARG) reinterpret_cast<int*>(P2)[o + 32 * j] = mi;
     }
@@ -159,12 +165,7 @@ __device__ __forceinline__ void scr_wait_landed(bool more, bool stored) {
 
 // DBG (tools/screen_probe.hip only; 0 in the library): 1 = no fold (stores one accumulator element), 2 = no activation loads,
 // 4 = no LDS-DMA in the loop, 8 = s_memtime / s_memrealtime stamps into a.dbg
-// SPLIT: the two waves of a SIMD (waves w and w + 4 of the block) share its matrix pipe, and the older one wins the arbitration: in
-// every iteration waves 0-3 issue their MFMAs first and waves 4-7 behind them.  With the fold in front of the barrier in all waves,
-// the fold of waves 4-7 would run with the pipe idle (everybody else waits at the barrier).  So waves 4-7 fold BEHIND the barrier,
-// at the top of the next iteration, under the MFMAs of waves 0-3 (their own MFMAs could not issue then anyway); waves 0-3 fold in
-// front of the barrier, under the MFMAs of waves 4-7.  Waves 0-3 also get s_setprio 1 so that this order does not hang on age.
-template <int KU, int NS, int MODE = SCR_TOP2, int SPLIT = 1, int DBG = 0>
+template <int KU, int NS, int MODE = SCR_TOP2, int DBG = 0>
 __global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
     constexpr int NSTORES = (MODE == SCR_MAX ? 1 : 2) * NS;     // partial stores of one wave per finished chunk
     static_assert(KU * NS == 2, "register budget: NS * K / 4 = 128 VGPRs of activations");
@@ -189,8 +190,6 @@ __global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
     if (DBG & 8) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
     float* bias_s = reinterpret_cast<float*>(lds + NBUF * kScrUnitBytes);
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)lds);   // LDS byte address of the ring
-    const bool late = SPLIT && wid >= 4;
-    if (SPLIT && wid < 4) __builtin_amdgcn_s_setprio(1);
 
     // ---- weight stream: unit u = (chunk u / KU, k-half u % KU) -> buffer u % NBUF, four 1-KB LDS-DMA pieces per wave ----
     // piece p = 4 wid + j holds rows 2p, 2p + 1; the lane at linear LDS position (row, c) fetches 16-byte chunk c ^ (row & 15)
@@ -230,6 +229,30 @@ __global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
     scr_wait_vm<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the bias ds_writes (a raw s_barrier waits for no counter)
     __builtin_amdgcn_s_barrier();
+    float bmax[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) bmax[j] = kColmaxPadBias;
+    if (MODE == SCR_TOP2 && a.na) {
+        // ||bf16(a)||^2 of every sample, from the register-resident operand: the (wave, column tile) pairs of a panel are shared out
+        // over its row-range blocks (pair p belongs to the block with range == p mod ranges), each pair computed exactly once
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            if ((wid * NS + j) % a.ranges == range) {
+                float ss = 0.f;
+#pragma unroll
+                for (int s = 0; s < K / 16; ++s) {
+                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf2 x = {bfrag[j][s][2 * e], bfrag[j][s][2 * e + 1]};
+                        ss = __builtin_amdgcn_fdot2_f32_bf16(x, x, ss, false);
+                    }
+                }
+                ss += __shfl_xor(ss, 32, 64);                     // the other half-wave holds the other 8 of every 16 k
+                if (h == 0) a.na[ocol_of(s0, r5) + 32 * j] = ss;
+            }
+        }
+    }
 
     // fragment of k-step s, row tile i: chunk (2 s + h) ^ (r5 & 15) of row 32 i + r5.  2 s + h = 2 s ^ h, so the byte offset inside
     // the unit is  (r5 * 512 | ((h ^ (r5 & 15)) << 4)) ^ (s << 5)  + 16384 i : ONE register, one v_xor per k-step, immediates for i
@@ -246,17 +269,13 @@ __global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
         const bool more = u + 2 < U;
         if (more && !(DBG & 4)) issue_unit(u + 2);
         bool stored = false;
-        if (late && ku == 0 && cl > 0) {                         // waves 4-7: the fold of the previous chunk, behind its barrier
-            scr_fold<NS, MODE, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + cl - 1) + h) * a.ldp + ocol, 64 * (c_first + cl - 1) + 4 * h);
-            stored = true;
-        }
         unsigned fr = frag0;
         asm volatile("" : "+v"(fr));                             // opaque: keeps the 16 per-step offsets out of 16 loop-invariant registers
         const unsigned char* buf = lds + (u % NBUF) * kScrUnitBytes;
         if (ku == 0) scr_bias_init<NS>(bias_s + cl * 64 + 4 * h, acc);
         scr_mma<KU, NS, ku, 0, 16>(buf, fr, bfrag, acc);
-        if (!late && ku == KU - 1) {                             // waves 0-3: fold in front of the barrier
-            scr_fold<NS, MODE, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + cl) + h) * a.ldp + ocol, 64 * (c_first + cl) + 4 * h);
+        if (ku == KU - 1) {
+            scr_fold<NS, MODE, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + cl) + h) * a.ldp + ocol, 64 * (c_first + cl) + 4 * h, bmax);
             stored = true;
         }
         if (DBG & 4) scr_wait_vm<0>(); else scr_wait_landed<NSTORES>(more, stored);
@@ -267,7 +286,14 @@ __global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
         iteration(std::integral_constant<int, 0>{});
         if constexpr (KU > 1) iteration(std::integral_constant<int, KU - 1>{});
     }
-    if (late) scr_fold<NS, MODE, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + nch - 1) + h) * a.ldp + ocol, 64 * (c_first + nch - 1) + 4 * h);
+    if (MODE == SCR_TOP2 && a.R) {
+        // the block's maximum per sample: the two half-waves hold different groups of the same 32 samples
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const float v = fmaxf(bmax[j], __shfl_xor(bmax[j], 32, 64));
+            if (h == 0) a.R[(long long)range * a.ldp + ocol + 32 * j] = v;
+        }
+    }
     if (DBG & 8) {
         const unsigned long long st2 = __builtin_amdgcn_s_memtime(), sr2 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {

@@ -1,0 +1,45 @@
+// tools/f32_fwd_probe.hip — the fp32 hidden-layer forward product of configs[3] (8192 x 512 x 512, bias + tanh) on the tile kernel of
+// xq_gemm.hip.h with different block tiles: which tiling fills 256 CUs best when there are only 256 128x128 tiles?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <random>
+#include "../cn_chess_ai_amd/csrc/xq_gemm.hip.h"
+using namespace xq;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+template <int TM, int TN, int EPI = EPI_BIAS_TANH> static void run(const char* name, GemmArgs g, hipEvent_t e0, hipEvent_t e1) {
+    dim3 grid((g.M + 64 * TM - 1) / (64 * TM), (g.N + 64 * TN - 1) / (64 * TN), g.grouped ? g.grouped : 1);
+    auto fn = [&] { hipLaunchKernelGGL((gemm_f32_kernel<L_KCONTIG, L_KCONTIG, EPI, TM, TN>), grid, dim3(256), 0, 0, g); };
+    fn(); fn();
+    float ms = 0;
+    hipEventRecord(e0, 0); for (int i = 0; i < 20; ++i) fn(); hipEventRecord(e1, 0); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 2.0 * g.M * g.N * g.K * (g.grouped ? g.grouped : 1);
+    printf("  %-40s grid %4d x %d x %d: %7.2f us  %6.1f TFLOP/s = %.3f of 157.3\n", name, grid.x, grid.y, grid.z, ms * 50, flop / (ms / 20 * 1e-3) / 1e12, flop / (ms / 20 * 1e-3) / 157.3e12);
+}
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 8192, H = argc > 2 ? atoi(argv[2]) : 512;
+    std::mt19937 rng(1); std::uniform_real_distribution<float> u(-1.f, 1.f);
+    std::vector<float> a((size_t)n * H), w((size_t)H * H), b(H, 0.01f);
+    for (auto& x : a) x = u(rng); for (auto& x : w) x = 0.05f * u(rng);
+    float *dA, *dW, *dB, *dC;
+    CK(hipMalloc(&dA, a.size() * 4)); CK(hipMalloc(&dW, w.size() * 4)); CK(hipMalloc(&dB, b.size() * 4)); CK(hipMalloc(&dC, a.size() * 4 * 2));
+    CK(hipMemcpy(dA, a.data(), a.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, w.data(), w.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    GemmArgs g; memset(&g, 0, sizeof g);
+    g.M = n; g.N = H; g.K = H; g.A = dA; g.lda = H; g.B = dW; g.ldb = H; g.C = dC; g.ldc = H; g.bias = dB; g.a_vec = g.b_vec = 1; g.k_chunk = H;
+    printf("n %d H %d\n", n, H);
+    run<1, 1>("64 x 64 tiles", g, e0, e1);
+    run<2, 1>("128 x 64 tiles", g, e0, e1);
+    run<1, 2>("64 x 128 tiles", g, e0, e1);
+    run<2, 2>("128 x 128 tiles", g, e0, e1);
+    run<1, 1, EPI_STORE>("64 x 64 tiles, plain store (no tanh)", g, e0, e1);
+    run<2, 1, EPI_STORE>("128 x 64 tiles, plain store (no tanh)", g, e0, e1);
+    run<2, 2, EPI_STORE>("128 x 128 tiles, plain store (no tanh)", g, e0, e1);
+    g.grouped = 2; g.Ax[0] = dA; g.Bx[0] = dW; g.Cx[0] = dC + a.size(); g.biasx[0] = dB;
+    run<1, 1>("two chains grouped, 64 x 64", g, e0, e1);
+    run<2, 1>("two chains grouped, 128 x 64", g, e0, e1);
+    run<2, 2>("two chains grouped, 128 x 128", g, e0, e1);
+    return 0;
+}

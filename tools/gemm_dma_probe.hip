@@ -1,4 +1,4 @@
-// tools/gemm_bf16_probe.hip — gemm_bf16_kernel (xq_gemm_bf16.hip.h): the three products of the bf16 Q-net against a CPU reference
+// tools/gemm_dma_probe.hip — gemm_bf16_kernel (xq_gemm_dma.hip.h): the three products of the bf16 Q-net against a CPU reference
 // (exact: bf16 inputs, double accumulation) at a small shape, then timing at the configs[4] shapes beside the tile kernel it replaces.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -8,16 +8,16 @@
 #include <cstring>
 #include <random>
 #include <vector>
-#include "../cn_chess_ai_amd/csrc/xq_gemm_bf16.hip.h"
+#include "../cn_chess_ai_amd/csrc/xq_gemm_dma.hip.h"
 using namespace xq;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 static uint16_t f2bf(float v) { uint32_t u; memcpy(&u, &v, 4); u += 0x7FFF + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
 static float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
 
-template <int AL, int BL, int EPI> static void launch(const Bf16GemmArgs& g, int gz) {
+template <int AL, int BL, int EPI, int DT = DT_BF16, int TI = 2, int TJ = 2> static void launch(const Bf16GemmArgs& g, int gz) {
     static bool once = false;
-    if (!once) { CK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<AL, BL, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, kBgLdsBytes)); once = true; }
-    hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, EPI>), dim3(g.M / kBgBM, g.N / kBgBN, gz), dim3(512), kBgLdsBytes, 0, g);
+    if (!once) { CK(hipFuncSetAttribute((const void*)gemm_dma_kernel<DT, AL, BL, EPI, TI, TJ>, hipFuncAttributeMaxDynamicSharedMemorySize, bg_lds_bytes(TI, TJ))); once = true; }
+    hipLaunchKernelGGL((gemm_dma_kernel<DT, AL, BL, EPI, TI, TJ>), dim3(g.M / (128 * TI), g.N / (64 * TJ), gz), dim3(512), bg_lds_bytes(TI, TJ), 0, g);
 }
 template <typename T> static T* dev(const std::vector<T>& v) { T* p; CK(hipMalloc(&p, v.size() * sizeof(T))); CK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return p; }
 
@@ -111,6 +111,47 @@ int main() {
         memset(&g, 0, sizeof g);
         g.M = H; g.N = H; g.K = n; g.A = dA[0]; g.lda = H; g.B = dA[1]; g.ldb = H; g.k_chunk = 512; g.slab_stride = (long long)H * H; g.C = dC; g.ldc = H;
         timeit("weight gradient 512 x 512 x 16384, 32 slabs", 2.0 * n * H * H, [&] { launch<L_MCONTIG, L_MCONTIG, BG_STORE>(g, 32); });
+    }
+    {   // ---- fp32 forward on the same loop: bit-identical to the tile kernel of xq_gemm.hip.h (same k association), timing ----
+        for (int H : {512, 256}) {
+            const int n = 8192;
+            std::vector<float> a((size_t)n * H), w((size_t)H * H), b(H);
+            for (auto& x : a) x = u(rng); for (auto& x : w) x = 0.05f * u(rng); for (auto& x : b) x = 0.1f * u(rng);
+            float *dA = dev(a), *dW = dev(w), *dB = dev(b), *dC0, *dC1; uint16_t* dCb;
+            CK(hipMalloc(&dC0, a.size() * 4)); CK(hipMalloc(&dC1, a.size() * 4)); CK(hipMalloc(&dCb, a.size() * 2));
+            GemmArgs o; memset(&o, 0, sizeof o);
+            o.M = n; o.N = H; o.K = H; o.A = dA; o.lda = H; o.B = dW; o.ldb = H; o.C = dC0; o.ldc = H; o.bias = dB; o.a_vec = o.b_vec = 1; o.k_chunk = H;
+            auto old_fn = [&] { hipLaunchKernelGGL((gemm_f32_kernel<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH, 1, 1>), dim3(n / 64, H / 64, 1), dim3(256), 0, 0, o); };
+            Bf16GemmArgs g; memset(&g, 0, sizeof g);
+            g.M = n; g.N = H; g.K = H; g.A = dA; g.lda = H; g.B = dW; g.ldb = H; g.k_chunk = H; g.bias = dB; g.C = dC1; g.ldc = H; g.Cb = dCb; g.ldcb = H; g.cb_frag_mask = 1;
+            auto new_fn = [&] { if (H == 512) launch<L_KCONTIG, L_KCONTIG, BG_TANH, DT_F32, 1, 2>(g, 1); else launch<L_KCONTIG, L_KCONTIG, BG_TANH, DT_F32, 1, 1>(g, 1); };
+            old_fn(); new_fn(); CK(hipDeviceSynchronize());
+            std::vector<float> c0(a.size()), c1(a.size()); std::vector<uint16_t> cb(a.size());
+            CK(hipMemcpy(c0.data(), dC0, c0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(c1.data(), dC1, c1.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(cb.data(), dCb, cb.size() * 2, hipMemcpyDeviceToHost));
+            long long diff = 0, cbbad = 0; double maxe = 0;
+            for (size_t i = 0; i < c0.size(); ++i) { if (memcmp(&c0[i], &c1[i], 4)) ++diff; }
+            for (int m = 0; m < n; m += 37) for (int nn = 0; nn < H; ++nn) {
+                double s2 = b[nn]; for (int k = 0; k < H; ++k) s2 += (double)a[(size_t)m * H + k] * w[(size_t)nn * H + k];
+                maxe = std::max(maxe, std::fabs(std::tanh(s2) - c1[(size_t)m * H + nn]));
+                if (cb[(size_t)scr_afrag_index(m, nn, H)] != f2bf(c1[(size_t)m * H + nn])) ++cbbad;
+            }
+            printf("fp32 forward 8192 x %d x %d: elements that differ from the tile kernel %lld, max |err| vs fp64 %.3g, bf16 fragment-order copy mismatches %lld\n", H, H, diff, maxe, cbbad);
+            bad += (diff != 0) + (maxe > 2e-6) + (cbbad != 0);
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            auto timeit = [&](const char* name, double flop, auto fn) {
+                float ms = 0; fn(); fn();
+                hipEventRecord(e0, 0); for (int i = 0; i < 20; ++i) fn(); hipEventRecord(e1, 0); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
+                printf("  %-58s %7.2f us  %6.1f TFLOP/s = %.3f of 157.3\n", name, ms * 50, flop / (ms / 20 * 1e-3) / 1e12, flop / (ms / 20 * 1e-3) / 157.3e12);
+            };
+            timeit("tile kernel, 64 x 64 tiles", 2.0 * n * H * H, old_fn);
+            timeit("LDS-DMA loop", 2.0 * n * H * H, new_fn);
+            g.Cb = nullptr;
+            timeit("LDS-DMA loop, no bf16 copy", 2.0 * n * H * H, new_fn);
+            g.groups = 2; g.Ax[0] = dA; g.Bx[0] = dW; g.biasx[0] = dB; g.Cx[0] = dC0;
+            timeit("LDS-DMA loop, two chains grouped", 4.0 * n * H * H, [&] { if (H == 512) launch<L_KCONTIG, L_KCONTIG, BG_TANH, DT_F32, 1, 2>(g, 2); else launch<L_KCONTIG, L_KCONTIG, BG_TANH, DT_F32, 1, 1>(g, 2); });
+            if (H == 512) timeit("LDS-DMA loop, two chains grouped, 256 x 128 tiles", 4.0 * n * H * H, [&] { launch<L_KCONTIG, L_KCONTIG, BG_TANH, DT_F32, 2, 2>(g, 2); });
+        }
     }
     return bad;
 }

@@ -18,11 +18,11 @@ static uint16_t f2bf(float v) { uint32_t u; memcpy(&u, &v, 4); u += 0x7FFF + ((u
 static float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
 static int screen_row_host(int g, int code) { const int q = code & 15; return (g >> 2) * 128 + ((g >> 1) & 1) * 64 + 4 * (g & 1) + (code >> 4) * 32 + (q & 3) + 8 * (q >> 2); }
 
-template <int KU, int NS, int DBG = 0, int SPLIT = 1> static void launch_new(const ScreenArgs& a, hipStream_t s) {
+template <int KU, int NS, int DBG = 0> static void launch_new(const ScreenArgs& a, hipStream_t s) {
     static bool once = false;
     const size_t lds = screen_lds_bytes(a);
-    if (!once) { CK(hipFuncSetAttribute((const void*)screen_top2_kernel<KU, NS, SCR_TOP2, SPLIT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
-    hipLaunchKernelGGL((screen_top2_kernel<KU, NS, SCR_TOP2, SPLIT, DBG>), dim3(a.panels * a.ranges), dim3(512), lds, s, a);
+    if (!once) { CK(hipFuncSetAttribute((const void*)screen_top2_kernel<KU, NS, SCR_TOP2, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+    hipLaunchKernelGGL((screen_top2_kernel<KU, NS, SCR_TOP2, DBG>), dim3(a.panels * a.ranges), dim3(512), lds, s, a);
 }
 
 int main(int argc, char** argv) {
@@ -121,8 +121,9 @@ int main(int argc, char** argv) {
             hipEventRecord(e0, 0); for (int i = 0; i < 20; ++i) fn(); hipEventRecord(e1, 0); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
             printf("  %-52s %.2f us\n", name, ms * 50);
         };
-        timeit("full kernel (split fold, fragment-order activations)", [&] { launch_new<1, 2, 0>(a, 0); });
-        timeit("all waves fold in front of the barrier", [&] { launch_new<1, 2, 0, 0>(a, 0); });
+        timeit("full kernel (fragment-order activations)", [&] { launch_new<1, 2, 0>(a, 0); });
+        { ScreenArgs x = a; CK(hipMalloc(&x.R, (size_t)a.ranges * npad * 4)); CK(hipMalloc(&x.na, (size_t)npad * 4));
+          timeit("+ per-range maxima and activation norms (what the library runs)", [&] { launch_new<1, 2, 0>(x, 0); }); }
         { ScreenArgs x = a; x.A = dA; x.a_frag = 0; timeit("row-major activations", [&] { launch_new<1, 2, 0>(x, 0); }); }
         { ScreenArgs x = a; x.xcd_rows = 1; timeit("full kernel, XCD = row ranges", [&] { launch_new<1, 2, 0>(x, 0); }); }
         timeit("no fold", [&] { launch_new<1, 2, 1>(a, 0); });

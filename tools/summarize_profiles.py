@@ -23,6 +23,22 @@ def counter_means(path_glob):
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 
 
+def mfma_cycles(kernel):
+    """matrix-pipe cycles of one MFMA of the kernel: 32 (v_mfma_f32_32x32x16_bf16) or 64 (v_mfma_f32_32x32x2_f32), from its template arguments"""
+    def targs(name):
+        return [a.strip() for a in kernel.split(name + "<")[1].split(">")[0].split(",")]
+    if "screen_top2_kernel" in kernel:
+        return 32.0
+    if "gemm_dma_kernel" in kernel:
+        return 32.0 if targs("gemm_dma_kernel")[0] == "1" else 64.0
+    if "gemm_colmax_persistent_kernel" in kernel:
+        return 32.0 if targs("gemm_colmax_persistent_kernel")[2] == "1" else 64.0
+    if "gemm_f32_kernel" in kernel:
+        a = targs("gemm_f32_kernel")
+        return 32.0 if len(a) >= 6 and a[5] == "1" else 64.0
+    return 64.0
+
+
 def main(tag):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
@@ -36,15 +52,30 @@ def main(tag):
     fetch = counter_means(os.path.join(src, "fetch", "**", "*_counter_collection.csv"))
     write = counter_means(os.path.join(src, "write", "**", "*_counter_collection.csv"))
     sq = counter_means(os.path.join(src, "sq", "**", "*_counter_collection.csv"))
+    for k, v in counter_means(os.path.join(src, "sq2", "**", "*_counter_collection.csv")).items():
+        sq.setdefault(k, {}).update(v)
     out = {}
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, {}).get("FETCH_SIZE", 0.0)
         w = write.get(k, {}).get("WRITE_SIZE", 0.0)
         out[k] = {"FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB_raw": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
                   "sq": sq.get(k, {})}
+    # matrix-pipe view of the MFMA kernels: MFMAs = SQ_VALU_MFMA_BUSY_CYCLES / cycles per MFMA (32 for 32x32x16 bf16, 64 for 32x32x2 f32);
+    # pipe utilisation = busy cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); SQ_INSTS_VALU counts the MFMAs too
+    for k, v in out.items():
+        q = v["sq"]
+        if q.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and q.get("GRBM_GUI_ACTIVE", 0) > 0:
+            per = mfma_cycles(k)
+            mf = q["SQ_VALU_MFMA_BUSY_CYCLES"] / per
+            v["derived"] = {"mfma_instructions": mf, "cycles_per_mfma_assumed": per,
+                            "mfma_pipe_utilisation": q["SQ_VALU_MFMA_BUSY_CYCLES"] / (q["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)}
+            if q.get("SQ_INSTS_VALU"):
+                v["derived"]["valu_instructions_per_mfma_excluding_the_mfma"] = q["SQ_INSTS_VALU"] / mf - 1.0
+            if q.get("SQ_INSTS_LDS"):
+                v["derived"]["lds_instructions_per_mfma"] = q["SQ_INSTS_LDS"] / mf
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
     for k, v in out.items():
-        if "gemm_colmax" in k or "env_kernel<2>" in k or "l0_grad" in k:
+        if "gemm_colmax" in k or "env_kernel<2>" in k or "l0_grad" in k or "screen_top2" in k or "gemm_dma" in k:
             print(k[:70], {a: round(b) for a, b in v.items() if a != "sq"})
 
 
