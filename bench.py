@@ -249,6 +249,8 @@ def main():
     ap.add_argument("--bracket-all", action="store_true", help="HIP-event bracket around EVERY launch of the dominant GEMM (default: every 4th)")
     ap.add_argument("--bf16-fp32-backward", action="store_true",
                     help="--config 5: XQ_PRECISION_BF16 (bf16 forward, fp32 backward products) instead of XQ_PRECISION_BF16_FULL")
+    ap.add_argument("--no-derive", action="store_true",
+                    help="gather layer 0 of the s' chain in full (the library default) instead of deriving it from the s chain")
     ap.add_argument("--no-variants", action="store_true", help="skip the variant legs (other TD net, full fp32 product): A/B runs")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps, barrier + synchronize on both sides) is run this many times back to "
@@ -308,6 +310,7 @@ def main():
     plies = CFG["plies"]
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
     t.dqn.set_qmax_mode(_capi.QMAX_SCREENED if args.qmax == "screened" else _capi.QMAX_FULL)
+    t.dqn.set_l0_derive(not args.no_derive)       # layer-0 sums of s' from those of s (library default: off, the reference's order)
     grads, comm, comm_error = None, None, ""
     if world == 1 and os.environ.get("XQ_BENCH_COMM1"):
         # rehearsal on one GPU: a one-rank communicator attached, so that the whole N > 1 code path of the library runs (bucketed
@@ -471,6 +474,7 @@ def main():
                        "games_per_gpu": n_games, "layer_sizes": list(LAYERS), "replay_capacity": max(REPLAY, n_games),
                        "minibatch": minibatch, "plies_per_update": plies, "epsilon": 0.1, "backprop": "reference-compatible",
                        "td_net": td_text, "prioritized_replay": bool(CFG["prioritized"]),
+                       "layer0_next_state": "derived from the state's sums (xq_dqn_set_l0_derive)" if not args.no_derive else "gathered in full",
                        "q_net_precision": ("bf16 forward (fp32 master weights, fp32 backward)" if args.bf16_fp32_backward else
                                            "bf16 forward and bf16 operands in the backward products (fp32 accumulation, fp32 master weights)")
                                           if CFG["bf16"] else "fp32",

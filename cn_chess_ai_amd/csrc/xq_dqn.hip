@@ -67,6 +67,7 @@ struct xq_dqn {
     float* sel_q90 = nullptr;
     int sel_cap = 0;
     bool small_tiles = false;                   // force 64x64 GEMM tiles (<= 80 VGPRs: fits beside the persistent GEMM)
+    bool l0_derive = false;                     // xq_dqn_set_l0_derive: layer-0 sums of s' from those of s (online TD rule, fp32 net)
     // exact screening of max_a' Q(s', a') (xq_dqn_set_qmax_mode): bf16 copies of the output-layer weights and of
     // the last hidden activations of s', the two screening partial arrays, the largest row norm of the weights, counters
     int qmax_mode = XQ_QMAX_FULL;
@@ -82,12 +83,14 @@ struct xq_dqn {
     bool scr_new_kernel_ready = false;          // dynamic-LDS attribute of screen_top2_kernel set
     unsigned long long* scr_stats = nullptr;    // [4] TD steps, samples, candidate (sample, group) pairs, pairs recomputed as whole groups
     unsigned long long scr_host_steps = 0, scr_host_samples = 0;
-    // guard: every kScreenCheckEvery screened steps the candidate counters come back asynchronously; a net that leaves the screen too
-    // many candidates (outputs all within the bf16 bound of each other) gets the full product for the next kScreenHoldSteps steps
+    // guard: every kScreenCheckEvery screened steps the candidate counters are copied back asynchronously and evaluated kScreenCheckEvery
+    // steps later; a net that leaves the screen too many candidates (outputs all within the bf16 bound of each other) gets the full
+    // product for the next kScreenHoldSteps steps
     unsigned long long* scr_guard_host = nullptr;      // pinned copy of scr_stats
     hipEvent_t scr_guard_ev = nullptr;
     bool scr_guard_pending = false;
     unsigned long long scr_guard_samples = 0;          // scr_host_samples when the pending copy was queued
+    unsigned long long scr_guard_queued_at = 0;        // scr_host_steps when it was queued
     unsigned long long scr_seen[3] = {0, 0, 0};        // samples, pairs, whole groups at the last evaluation
     int scr_hold = 0;                                  // > 0: that many TD steps still run the full product
     unsigned long long scr_fallbacks = 0;
@@ -1076,7 +1079,9 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
         const float wmx = fmaxf(__builtin_bit_cast(float, wm[parity]), __builtin_bit_cast(float, wm[4]));
         const float bmx = fmaxf(__builtin_bit_cast(float, wm[2 + parity]), __builtin_bit_cast(float, wm[5]));
         const float B = kScreenEps * sqrtf(na[sl]) * wmx + kScreenBiasEps * bmx;
-        thr[sl] = b0 + sl < n ? m - 2.f * B * 1.03125f - 1.52587890625e-05f * (fabsf(m) + 2.f * B) : __builtin_inff();   // no candidates past n
+        float t0 = m - 2.f * B * 1.03125f - 1.52587890625e-05f * (fabsf(m) + 2.f * B);
+        if (!(t0 == t0)) t0 = -__builtin_inff();      // a non-finite norm (diverged net): every group is a candidate, like the full product
+        thr[sl] = b0 + sl < n ? t0 : __builtin_inff();   // no candidates past n
     }
     __syncthreads();
     {
@@ -1109,7 +1114,7 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             z[r] = quarter_sum(z[r]) + bias[row[r]];
-            if (live[r] && ql == 0) atomicMax(&best[s2[r]], float_order_key(z[r]));
+            if (live[r] && ql == 0 && z[r] == z[r]) atomicMax(&best[s2[r]], float_order_key(z[r]));   // (a NaN output never wins: fmaxf semantics)
         }
     }
     for (int e = 0; e < wholes; ++e) {                           // a whole group: its 32 rows over the 16 quarters, one round
@@ -1171,7 +1176,9 @@ __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restri
         const float wmx = fmaxf(__builtin_bit_cast(float, wm[parity]), __builtin_bit_cast(float, wm[4]));
         const float bmx = fmaxf(__builtin_bit_cast(float, wm[2 + parity]), __builtin_bit_cast(float, wm[5]));
         const float B = kScreenEps * sqrtf(na_all[bc]) * wmx + kScreenBiasEps * bmx;
-        thr[sl] = ok ? m - 2.f * B * 1.03125f - 1.52587890625e-05f * (fabsf(m) + 2.f * B) : __builtin_inff();   // no candidates past n
+        float t0 = m - 2.f * B * 1.03125f - 1.52587890625e-05f * (fabsf(m) + 2.f * B);
+        if (!(t0 == t0)) t0 = -__builtin_inff();      // a non-finite norm (diverged net): every group is a candidate, like the full product
+        thr[sl] = ok ? t0 : __builtin_inff();            // no candidates past n
     }
     __syncthreads();
     {
@@ -1213,7 +1220,7 @@ __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             z[r] = quarter_sum(z[r]) + bias[row[r]];
-            if (live[r] && ql == 0) atomicMax(&best[s2[r]], float_order_key(z[r]));
+            if (live[r] && ql == 0 && z[r] == z[r]) atomicMax(&best[s2[r]], float_order_key(z[r]));   // (a NaN output never wins: fmaxf semantics)
         }
     }
     for (int e = 0; e < wholes; ++e) {                           // a whole group: its 32 rows over the 16 quarters, one round
@@ -1508,9 +1515,7 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
         // the screening shadow of the output-layer weights rides in the same grid (one more row of blocks) when the grid is wide
         // enough for it; a launch of its own otherwise
         // online TD rule on an fp32 net: the s' chain (job 1, same net, same slots) is derived inside job 0's waves
-        static const bool no_derive = getenv("XQ_NO_DERIVE") != nullptr;
-        const bool derive = !bf && njobs == 2 && jobs[0].net == jobs[1].net && (H & 3) == 0 && jobs[1].gathered == nullptr &&
-                            no_derive == false;
+        const bool derive = d->l0_derive && !bf && njobs == 2 && jobs[0].net == jobs[1].net && (H & 3) == 0 && jobs[1].gathered == nullptr;
         J.derive_next = derive ? 1 : 0;
         bool ride = false;
         if (shadow) {
@@ -2023,6 +2028,12 @@ static int refresh_shadow(xq_dqn* d, int net) {
     return XQ_OK;
 }
 
+int xq_dqn_set_l0_derive(xq_dqn* d, int on) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    d->l0_derive = on != 0;
+    return XQ_OK;
+}
+
 int xq_dqn_set_qmax_mode(xq_dqn* d, int mode) {
     if (!d || (mode != XQ_QMAX_FULL && mode != XQ_QMAX_SCREENED)) return fail(XQ_ERR_INVALID_ARGUMENT, "bad qmax mode");
     d->qmax_mode = mode;
@@ -2290,12 +2301,11 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     bool screened = want_screen;
     if (screened) {
         XQ_TRY(ensure_screen_capacity(d, n));
-        bool arrived = false;
-        if (d->scr_guard_pending) {
-            arrived = hipEventQuery(d->scr_guard_ev) == hipSuccess;
-            if (!arrived) (void)hipGetLastError();           // hipErrorNotReady is an answer, not a failure
-        }
-        if (arrived) {
+        // the counters queued at one check boundary are evaluated at the NEXT one (32 screened steps later: the copy finished long
+        // ago, the wait returns at once) — the step at which a fallback begins is a function of the step count alone, never of how
+        // far the host runs ahead of the device
+        if (d->scr_guard_pending && d->scr_host_steps % kScreenCheckEvery == 0 && d->scr_host_steps != d->scr_guard_queued_at) {
+            XQ_HIP(hipEventSynchronize(d->scr_guard_ev));
             d->scr_guard_pending = false;
             const unsigned long long* h = d->scr_guard_host;
             const double ds = (double)(d->scr_guard_samples - d->scr_seen[0]);
@@ -2402,6 +2412,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             XQ_HIP(hipEventRecord(d->scr_guard_ev, d->cur));
             d->scr_guard_pending = true;
             d->scr_guard_samples = d->scr_host_samples;
+            d->scr_guard_queued_at = d->scr_host_steps;
         }
         zparts = 1;
     } else {

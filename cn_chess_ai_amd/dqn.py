@@ -178,6 +178,14 @@ def _set_qmax_mode(self, mode):
     call("xq_dqn_set_qmax_mode", self._h, int(mode))
 
 
+def _set_l0_derive(self, on):
+    """Layer-0 sums of s' derived from those of s (online TD rule, fp32 net): one gather instead of two, a different summation order."""
+    call("xq_dqn_set_l0_derive", self._h, 1 if on else 0)
+
+
+DQN.set_l0_derive = _set_l0_derive
+
+
 def _qmax_stats(self):
     """(TD steps screened, samples, candidate (sample, group) pairs, pairs re-evaluated as whole groups); synchronises."""
     st = (C.c_uint64 * 4)()

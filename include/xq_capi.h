@@ -208,6 +208,12 @@ int xq_dqn_destroy(xq_dqn* d);
 /* XQ_PRECISION_*: arithmetic of the forward passes on packed boards (action select, TD targets, Q(s,a)).  The dense-state entry
  * points (xq_dqn_forward / xq_dqn_backpropagate: the reference's std::vector<double> API) always compute in fp32. */
 int xq_dqn_set_precision(xq_dqn* d, int precision);
+/* Layer 0 of the s' chain of a TD step (online TD rule, fp32 net; no upstream analogue — the reference evaluates every state from
+ * scratch, dqn.cu:199-260).  0 (default): the sum over the occupied squares of s' in ascending square order, the reference's
+ * i-ascending accumulation with the zeros skipped.  1: z1(s') = z1(s) - rows of the squares that changed + rows of what stands there
+ * now (two squares for a move; boards more than 8 squares apart are gathered in full): one gather instead of two, a DIFFERENT
+ * summation order (differences ~1e-7 on the activations, far inside the 1e-4 budget on Q).  bench.py switches it on. */
+int xq_dqn_set_l0_derive(xq_dqn* d, int on);
 /* XQ_QMAX_*: how the TD step finds max_a' Q(s',a').  XQ_QMAX_SCREENED applies to fp32 nets with XQ_TD_ONLINE_NET / XQ_TD_TARGET_NET
  * whose last hidden width is a multiple of 64 and whose product is large enough for the persistent GEMM (>= 512 tiles of 128 x 128);
  * every other case silently keeps the full fp32 product.  Guard: every 32 screened steps the candidate counters are read back

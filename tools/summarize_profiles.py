@@ -41,6 +41,8 @@ def mfma_cycles(kernel):
 
 def main(tag):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    if not os.path.isdir(src):
+        raise SystemExit(f"no {src}")
     dst = os.path.join(ROOT, "profiles")
     stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
     if stats:
@@ -76,7 +78,7 @@ def main(tag):
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
     for k, v in out.items():
         if "gemm_colmax" in k or "env_kernel<2>" in k or "l0_grad" in k or "screen_top2" in k or "gemm_dma" in k:
-            print(k[:70], {a: round(b) for a, b in v.items() if a != "sq"})
+            print(k[:70], {a: round(b) for a, b in v.items() if a not in ("sq", "derived")}, v.get("derived", ""))
 
 
 if __name__ == "__main__":
