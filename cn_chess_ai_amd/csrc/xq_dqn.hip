@@ -688,6 +688,67 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
             o.z = delta * vv.z * (1.f - av.z * av.z); o.w = delta * vv.w * (1.f - av.w * av.w);
         }
         *reinterpret_cast<float4*>(dtop + (long long)b * 256 + lane * 4) = o;
+    } else if (H == 512 && X.wout_bf && n_partial <= 4 && (!X.double_dqn || X.wout_t_bf)) {
+        // bf16 net, 512-wide last hidden layer (BASELINE configs[4]): the same idea — every load that depends only on (b, s, a) issued up
+        // front, 8 columns per lane as 16-byte loads; Double DQN adds ONE dependent round trip (the target net's row of the arg-max)
+        const int ac = live ? a : 0;
+        const float* arp = ar + lane * 8;
+        const float4 av0 = *reinterpret_cast<const float4*>(arp), av1 = *reinterpret_cast<const float4*>(arp + 4);
+        const uint4 wq = *reinterpret_cast<const uint4*>(X.wout_bf + (long long)ac * 512 + lane * 8);
+        const bool has_view = live && a < view_kmax;
+        const float* vp = view + (long long)(has_view ? a : 0) * view_ld + lane * 8;
+        float4 vv0 = *reinterpret_cast<const float4*>(vp), vv1 = *reinterpret_cast<const float4*>(vp + 4);
+        float pm[4]; int pi[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            pm[t] = partial[(long long)min(t, n_partial - 1) * n + b];
+            pi[t] = X.double_dqn ? X.partial_idx[(long long)min(t, n_partial - 1) * n + b] : 0;
+        }
+        uint4 atq = make_uint4(0u, 0u, 0u, 0u);
+        if (X.double_dqn) atq = *reinterpret_cast<const uint4*>(X.alast_t_bf + (long long)b * 512 + lane * 8);
+        const float bo = b_out[ac], r = reward[s];
+        const bool dn = done[s] != 0;
+        const float isw = X.is_w ? X.is_w[b] / X.is_wmax[0] : 1.f;
+        auto lo = [](uint32_t x) { return __builtin_bit_cast(float, x << 16); };
+        auto hi = [](uint32_t x) { return __builtin_bit_cast(float, x & 0xFFFF0000u); };
+        float z = ((av0.x * lo(wq.x) + av0.y * hi(wq.x)) + (av0.z * lo(wq.y) + av0.w * hi(wq.y))) +
+                  ((av1.x * lo(wq.z) + av1.y * hi(wq.z)) + (av1.z * lo(wq.w) + av1.w * hi(wq.w)));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+        float zm = pm[0]; int zi = pi[0];
+#pragma unroll
+        for (int t = 1; t < 4; ++t) {
+            if (X.double_dqn) { if (pm[t] > zm || (pm[t] == zm && pi[t] < zi)) { zm = pm[t]; zi = pi[t]; } }
+            else zm = fmaxf(zm, pm[t]);
+        }
+        if (X.double_dqn) {          // value of the online net's greedy action on the TARGET net
+            const int astar = (zi >= 0 && zi < X.nout) ? zi : 0;
+            const uint4 tq = *reinterpret_cast<const uint4*>(X.wout_t_bf + (long long)astar * 512 + lane * 8);
+            float zt = ((lo(atq.x) * lo(tq.x) + hi(atq.x) * hi(tq.x)) + (lo(atq.y) * lo(tq.y) + hi(atq.y) * hi(tq.y))) +
+                       ((lo(atq.z) * lo(tq.z) + hi(atq.z) * hi(tq.z)) + (lo(atq.w) * lo(tq.w) + hi(atq.w) * hi(tq.w)));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) zt += __shfl_xor(zt, off, 64);
+            zm = zt + X.bout_t[astar];
+        }
+        if (live) {
+            q = tanhf(z + bo);
+            y = dn ? r : r + gamma * tanhf(zm);
+            delta = (q - y) * (1.f - q * q) * isw;
+        }
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (has_view) {
+            o[0] = delta * vv0.x * (1.f - av0.x * av0.x); o[1] = delta * vv0.y * (1.f - av0.y * av0.y);
+            o[2] = delta * vv0.z * (1.f - av0.z * av0.z); o[3] = delta * vv0.w * (1.f - av0.w * av0.w);
+            o[4] = delta * vv1.x * (1.f - av1.x * av1.x); o[5] = delta * vv1.y * (1.f - av1.y * av1.y);
+            o[6] = delta * vv1.z * (1.f - av1.z * av1.z); o[7] = delta * vv1.w * (1.f - av1.w * av1.w);
+        }
+        float* dp = dtop + (long long)b * 512 + lane * 8;
+        *reinterpret_cast<float4*>(dp) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(dp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        if (X.dtop_bf)
+            *reinterpret_cast<uint4*>(X.dtop_bf + (long long)b * 512 + lane * 8) =
+                make_uint4((uint32_t)bf16_bits(o[0]) | ((uint32_t)bf16_bits(o[1]) << 16), (uint32_t)bf16_bits(o[2]) | ((uint32_t)bf16_bits(o[3]) << 16),
+                           (uint32_t)bf16_bits(o[4]) | ((uint32_t)bf16_bits(o[5]) << 16), (uint32_t)bf16_bits(o[6]) | ((uint32_t)bf16_bits(o[7]) << 16));
     } else {
     if (live) {
         float z = 0.f;
