@@ -251,6 +251,7 @@ struct L0Jobs {
     uint16_t* out_bf[kMaxChains];            // bf16 Q-net: bf16 bits of the activations
     uint32_t* gathered[kMaxChains];
     int njobs;
+    int nrows;                               // grid rows that gather (njobs - derive_next); the shadow row, if any, is row nrows
     int derive_next;                         // 1: job 0's waves also produce job 1 (s' = s after one move, SAME net) from their own layer-0 sums:
                                              // z1(s') = z1(s) - rows of the squares that changed + rows of what stands there now
     int out_bf_frag;                         // fp32 net: the bf16 copy out_bf is written in MFMA B-fragment order (scr_afrag_index)
@@ -263,14 +264,14 @@ struct L0Jobs {
 template <bool BF16>
 __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, int n, int H) {
     __shared__ int rows[4][96];
-    if ((int)blockIdx.y == J.njobs) {                   // block-uniform: the screening shadow rides in the same grid
+    if ((int)blockIdx.y == J.nrows) {                   // block-uniform: the screening shadow rides in the same grid
         if ((int)blockIdx.x < J.shadow.nblocks) screen_shadow_block(J.shadow, (int)blockIdx.x, reinterpret_cast<float*>(&rows[0][0]));
         return;
     }
     const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int b = (int)blockIdx.x * 4 + wid;
     if (b >= n) return;
-    const int job = (int)blockIdx.y;
+    const int job = (J.derive_next && blockIdx.y >= 1) ? (int)blockIdx.y + 1 : (int)blockIdx.y;    // job 1 is produced by job 0's waves
     const float* __restrict__ W0T = J.W0T[job];
     const uint16_t* __restrict__ W0B = J.W0T_bf[job];
     const float* __restrict__ b0 = J.b0[job];
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
     __shared__ int dpair[4][8][2];
     __shared__ int rows2[4][96];
     int nd = -1, cnt2 = 0;                                // nd = -1: nothing derived here; nd > 8: cnt2 rows in rows2
-    if (!BF16 && J.derive_next) {
+    if (J.derive_next && job == 0) {
         const uint32_t* bw2 = J.boards[1] + (long long)srow * kBoardWords;
         const uint32_t p0 = (bw2[s0 >> 3] >> (4 * (s0 & 7))) & 15u;
         const uint32_t p1 = s1 < kSquares ? (bw2[s1 >> 3] >> (4 * (s1 & 7))) & 15u : 0u;
@@ -365,6 +366,46 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
                 if (out) {
                     *reinterpret_cast<float4*>(out + (long long)b * H + col) = make_float4(tv[0], tv[1], tv[2], tv[3]);
                     *reinterpret_cast<float4*>(out + (long long)b * H + col + 4) = make_float4(tv[4], tv[5], tv[6], tv[7]);
+                }
+                if (nd >= 0) {                          // the s' chain of the same sample, same net (xq_dqn_set_l0_derive), from these sums
+                    float a2[8];
+                    if (nd <= 8) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) a2[k] = a[k];
+                        auto acc8 = [&](const uint4& x, float sgn) {
+                            a2[0] += sgn * __builtin_bit_cast(float, x.x << 16); a2[1] += sgn * __builtin_bit_cast(float, x.x & 0xFFFF0000u);
+                            a2[2] += sgn * __builtin_bit_cast(float, x.y << 16); a2[3] += sgn * __builtin_bit_cast(float, x.y & 0xFFFF0000u);
+                            a2[4] += sgn * __builtin_bit_cast(float, x.z << 16); a2[5] += sgn * __builtin_bit_cast(float, x.z & 0xFFFF0000u);
+                            a2[6] += sgn * __builtin_bit_cast(float, x.w << 16); a2[7] += sgn * __builtin_bit_cast(float, x.w & 0xFFFF0000u);
+                        };
+                        for (int k = 0; k < nd; ++k) {     // wave-uniform
+                            const int ro = dpair[wid][k][0], ri = dpair[wid][k][1];
+                            if (ro >= 0) acc8(*reinterpret_cast<const uint4*>(W0B + (long long)ro * H + col), -1.f);
+                            if (ri >= 0) acc8(*reinterpret_cast<const uint4*>(W0B + (long long)ri * H + col), 1.f);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) a2[k] = 0.f;
+                        for (int k = 0; k < cnt2; ++k) {
+                            const uint4 x = *reinterpret_cast<const uint4*>(W0B + (long long)rows2[wid][k] * H + col);
+                            a2[0] += __builtin_bit_cast(float, x.x << 16); a2[1] += __builtin_bit_cast(float, x.x & 0xFFFF0000u);
+                            a2[2] += __builtin_bit_cast(float, x.y << 16); a2[3] += __builtin_bit_cast(float, x.y & 0xFFFF0000u);
+                            a2[4] += __builtin_bit_cast(float, x.z << 16); a2[5] += __builtin_bit_cast(float, x.z & 0xFFFF0000u);
+                            a2[6] += __builtin_bit_cast(float, x.w << 16); a2[7] += __builtin_bit_cast(float, x.w & 0xFFFF0000u);
+                        }
+                    }
+                    uint16_t q2[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) q2[k] = bf16_bits(tanh_fast(a2[k] + bias[k]));
+                    *reinterpret_cast<uint4*>(J.out_bf[1] + (long long)b * H + col) =
+                        make_uint4((uint32_t)q2[0] | ((uint32_t)q2[1] << 16), (uint32_t)q2[2] | ((uint32_t)q2[3] << 16),
+                                   (uint32_t)q2[4] | ((uint32_t)q2[5] << 16), (uint32_t)q2[6] | ((uint32_t)q2[7] << 16));
+                    if (J.out[1]) {
+                        *reinterpret_cast<float4*>(J.out[1] + (long long)b * H + col) =
+                            make_float4(bf16_to_float(q2[0]), bf16_to_float(q2[1]), bf16_to_float(q2[2]), bf16_to_float(q2[3]));
+                        *reinterpret_cast<float4*>(J.out[1] + (long long)b * H + col + 4) =
+                            make_float4(bf16_to_float(q2[4]), bf16_to_float(q2[5]), bf16_to_float(q2[6]), bf16_to_float(q2[7]));
+                    }
                 }
             }
         }
@@ -1576,8 +1617,12 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
         // the screening shadow of the output-layer weights rides in the same grid (one more row of blocks) when the grid is wide
         // enough for it; a launch of its own otherwise
         // online TD rule on an fp32 net: the s' chain (job 1, same net, same slots) is derived inside job 0's waves
-        const bool derive = d->l0_derive && !bf && njobs == 2 && jobs[0].net == jobs[1].net && (H & 3) == 0 && jobs[1].gathered == nullptr;
+        // (bf16 net: in the 16-byte gather path only; Double DQN's third chain — the target net — is gathered as before)
+        const bool wide_bf = bf && (H & 7) == 0 && ((H >= 512 && (H & 511) == 0) || (H >= 64 && 512 % H == 0));
+        const bool derive = d->l0_derive && njobs >= 2 && jobs[0].net == jobs[1].net && jobs[1].gathered == nullptr &&
+                            (bf ? wide_bf : (njobs == 2 && (H & 3) == 0));
         J.derive_next = derive ? 1 : 0;
+        J.nrows = njobs - (derive ? 1 : 0);
         bool ride = false;
         if (shadow) {
             const int sblocks = shadow->nblocks;
@@ -1589,19 +1634,16 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
             }
         }
         ProfScope ps(d, "l0_forward_gather", 2.0 * njobs * n * 32 * H, (double)njobs * n * (48 + 32.0 * H * (bf ? 2 : 4) + H * 4));
-        if (bf) hipLaunchKernelGGL(l0_forward_kernel<true>, dim3((n + 3) / 4, njobs), dim3(256), 0, d->cur, J, src, n, H);
-        else {
-            // (grid rows: the job rows that are really gathered, then the shadow row; the kernel tests blockIdx.y == J.njobs for it)
-            if (derive) J.njobs = 1;
-            hipLaunchKernelGGL(l0_forward_kernel<false>, dim3((n + 3) / 4, J.njobs + (ride ? 1 : 0)), dim3(256), 0, d->cur, J, src, n, H);
-        }
+        // (grid rows: the job rows that are really gathered, then the shadow row; the kernel tests blockIdx.y == J.nrows for it)
+        if (bf) hipLaunchKernelGGL(l0_forward_kernel<true>, dim3((n + 3) / 4, J.nrows), dim3(256), 0, d->cur, J, src, n, H);
+        else hipLaunchKernelGGL(l0_forward_kernel<false>, dim3((n + 3) / 4, J.nrows + (ride ? 1 : 0)), dim3(256), 0, d->cur, J, src, n, H);
         XQ_HIP(hipGetLastError());
     }
     for (int l = 1; l + 1 < d->nl; ++l) {
         GemmArgs g; memset(&g, 0, sizeof g);
         g.M = n; g.N = d->L[l + 1];
         g.grouped = njobs > 1 ? njobs : 0;
-        if (bf && (n % kBgBM) == 0 && (d->L[l + 1] % kBgBN) == 0 && (d->L[l] % kBgBK) == 0 && !d->small_tiles) {
+        if (bf && (n % kBgBM) == 0 && (d->L[l + 1] % kBgBN) == 0 && (d->L[l] % kBgBK) == 0) {
             // the bf16 loop of its own (xq_gemm_bf16.hip.h): whole 256 x 128 tiles only, the chains as groups of one launch
             Bf16GemmArgs b; memset(&b, 0, sizeof b);
             b.M = n; b.N = d->L[l + 1]; b.K = d->L[l]; b.lda = b.ldb = d->L[l]; b.k_chunk = b.K;

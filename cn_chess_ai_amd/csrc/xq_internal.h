@@ -45,6 +45,8 @@ struct xq_replay {
         size_t off[8] = {0};              // offset of level lv inside `upper` (lv >= 1)
         unsigned* scalars = nullptr;      // [0] max priority, live (atomicMax of float bits)  [1] its snapshot at the last rebuild
                                           // [2] max raw importance weight of the last sample (float bits)  [3] eligible slots (p > 0)
+        unsigned* wave_counts = nullptr;  // per-wave counts of non-zero leaves of the last rebuild (summed into scalars[3] by per_upper_kernel)
+        bool wmax_clean = false;          // scalars[2] is zero (set by a rebuild, consumed by the next draw)
         float* is_w = nullptr;            // [slots_cap] raw importance weights of the last prioritized sample
         bool last_prioritized = false;
     } per;

@@ -47,10 +47,10 @@ __global__ __launch_bounds__(256) void per_level_kernel(const float* __restrict_
         }
         parent[i] = s;
     }
-    if (count_nonzero) {
+    if (count_nonzero) {         // one count per wave, summed by per_upper_kernel: nothing to zero beforehand, no atomics
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nz += __shfl_xor(nz, off, 64);
-        if ((threadIdx.x & 63) == 0 && nz) atomicAdd(count_nonzero, (unsigned)nz);     // integer: order-independent
+        if ((threadIdx.x & 63) == 0) count_nonzero[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = (unsigned)nz;
     }
 }
 
@@ -60,8 +60,22 @@ struct PerTree {
     int nlv, n[8];
     long long off[8];
 };
-// levels 2.. in one block (they hold <= a few thousand nodes), then the snapshot of the running maximum priority
-__global__ __launch_bounds__(1024) void per_upper_kernel(PerTree T, unsigned* scalars) {
+// levels 2.. in one block (they hold <= a few thousand nodes), then the snapshot of the running maximum priority, the number of eligible
+// slots (sum of per_level_kernel's per-wave counts) and a clean batch-maximum slot for the next draw
+__global__ __launch_bounds__(1024) void per_upper_kernel(PerTree T, unsigned* scalars, const unsigned* __restrict__ wave_counts, int n_counts) {
+    __shared__ unsigned csum[16];
+    unsigned c = 0;
+    for (int i = (int)threadIdx.x; i < n_counts; i += (int)blockDim.x) c += wave_counts[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0) csum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += csum[w];
+        if (wave_counts) scalars[3] = t;
+        scalars[2] = 0u;
+    }
     for (int lv = 2; lv < T.nlv; ++lv) {
         const float* child = T.upper + T.off[lv - 1];
         float* parent = T.upper + T.off[lv];
@@ -143,17 +157,21 @@ int replay_per_rebuild(xq_replay* r, int retire_start, int retire_count, hipStre
                            r->dev.capacity, nullptr, 0.f);
         XQ_HIP(hipGetLastError());
     }
-    XQ_HIP(hipMemsetAsync(r->per.scalars + 3, 0, sizeof(unsigned), s));
     PerTree T = per_tree(r);
+    int n_counts = 0;
     if (T.nlv > 1) {
-        hipLaunchKernelGGL(per_level_kernel, dim3((T.n[1] + 255) / 256), dim3(256), 0, s, r->dev.prio, T.upper + T.off[1], T.n[1],
-                           r->per.scalars + 3, r->per.leaves);
+        const int blocks = (T.n[1] + 255) / 256;
+        n_counts = blocks * 4;                                       // one count per wave of the level-1 grid
+        hipLaunchKernelGGL(per_level_kernel, dim3(blocks), dim3(256), 0, s, r->dev.prio, T.upper + T.off[1], T.n[1],
+                           r->per.wave_counts, r->per.leaves);
         XQ_HIP(hipGetLastError());
     } else {
+        XQ_HIP(hipMemsetAsync(r->per.scalars + 3, 0, sizeof(unsigned), s));        // (a ring of <= 32 slots: counted by the sampler's callers)
         XQ_HIP(hipMemcpyAsync(r->per.leaves, r->dev.prio, 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    hipLaunchKernelGGL(per_upper_kernel, dim3(1), dim3(1024), 0, s, T, r->per.scalars);
+    hipLaunchKernelGGL(per_upper_kernel, dim3(1), dim3(1024), 0, s, T, r->per.scalars, n_counts ? r->per.wave_counts : nullptr, n_counts);
     XQ_HIP(hipGetLastError());
+    r->per.wmax_clean = true;                                        // per_upper_kernel zeroed the batch-maximum slot
     return XQ_OK;
 }
 
@@ -170,7 +188,8 @@ int replay_per_sample(xq_replay* r, int batch, hipStream_t on) {
         r->slots_cap = batch;
     }
     if (!r->per.is_w) XQ_HIP(hipMalloc(&r->per.is_w, (size_t)r->slots_cap * sizeof(float)));
-    XQ_HIP(hipMemsetAsync(r->per.scalars + 2, 0, sizeof(unsigned), s));
+    if (!r->per.wmax_clean) XQ_HIP(hipMemsetAsync(r->per.scalars + 2, 0, sizeof(unsigned), s));     // a second draw from the same tree
+    r->per.wmax_clean = false;
     hipLaunchKernelGGL(per_sample_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, per_tree(r), batch, (uint32_t)r->sample_calls,
                        (uint32_t)r->seed, (uint32_t)(r->seed >> 32), r->per.beta, r->per.scalars, r->slots_dev, r->per.is_w);
     XQ_HIP(hipGetLastError());
@@ -240,7 +259,7 @@ int xq_replay_destroy(xq_replay* r) {
     hipStreamSynchronize(r->stream);
     hipFree(r->dev.boards); hipFree(r->dev.next_boards); hipFree(r->dev.action_to); hipFree(r->dev.reward);
     hipFree(r->dev.done); hipFree(r->slots_dev);
-    hipFree(r->dev.prio); hipFree(r->per.leaves); hipFree(r->per.upper); hipFree(r->per.scalars); hipFree(r->per.is_w);
+    hipFree(r->dev.prio); hipFree(r->per.leaves); hipFree(r->per.upper); hipFree(r->per.scalars); hipFree(r->per.wave_counts); hipFree(r->per.is_w);
     if (r->own_stream) hipStreamDestroy(r->stream);
     delete r;
     return XQ_OK;
@@ -311,6 +330,7 @@ int xq_replay_enable_per(xq_replay* r, double alpha, double beta, double eps) {
     XQ_HIP(hipMalloc(&P.upper, std::max<size_t>(upper, 32) * sizeof(float)));
     XQ_HIP(hipMemset(P.upper, 0, std::max<size_t>(upper, 32) * sizeof(float)));
     XQ_HIP(hipMalloc(&P.scalars, 4 * sizeof(unsigned)));
+    XQ_HIP(hipMalloc(&P.wave_counts, (size_t)((P.n[1] + 255) / 256 * 4 + 4) * sizeof(unsigned)));
     const float one = 1.0f;                      // initial maximum priority (Schaul et al.: new transitions get the maximum, 1 at start)
     unsigned init[4];
     memcpy(&init[0], &one, 4); init[1] = init[0]; init[2] = 0; init[3] = 0;

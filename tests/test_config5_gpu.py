@@ -409,3 +409,26 @@ def test_bf16_full_td_update_matches_oracle(xq, trace, td_rule, mode):
     h1 = slice(sizes[0] * sizes[1], sizes[0] * sizes[1] + sizes[1] * sizes[2])
     assert np.abs(w2[h1] - got_w[h1]).max() > 0
     d.close(); d2.close()
+
+
+@pytest.mark.parametrize("sizes,td_rule", [(CFG4_NET, 2), (CFG4_NET, 0), (CFG2_NET, 2)])
+def test_bf16_next_state_chain_derived_and_direct(xq, trace, sizes, td_rule):
+    """xq_dqn_set_l0_derive on a bf16 net (what bench.py --config 5 runs): layer 0 of the online net's s' chain comes from the s chain's
+    sums (rows out / rows in, fp32) inside the same wave; Double DQN's third chain (target net) is still gathered.  Same targets as the
+    direct gather up to bf16 noise of a summation-order change, on real transitions and on unrelated board pairs (full re-gather)."""
+    n = 64
+    S, A, R, D, S2 = transitions(trace, valid_indices(trace, n, seed=7))
+    R = R / 1000.0
+    d, w, b = make_net(xq, sizes, seed=9)
+    wt, bt = xo.init_weights(sizes, 78)
+    d.set_params(wt, bt, net=1)
+    d.set_precision(xq._capi.PRECISION_BF16)
+    for nxt in (S2, np.roll(S2, 5, axis=0)):
+        d.set_l0_derive(False)
+        q0, y0 = d.td_update(S, nxt, A, R, D, td_net=td_rule, mode=0, learning_rate=0.0, grad_scale=1.0)
+        d.set_l0_derive(True)
+        q1, y1 = d.td_update(S, nxt, A, R, D, td_net=td_rule, mode=0, learning_rate=0.0, grad_scale=1.0)
+        assert np.array_equal(q0, q1)                               # the s chain itself is untouched
+        close = np.abs(y0 - y1) < 2 * BF16_QTOL
+        assert close.mean() > (0.8 if td_rule == 2 else 0.999)     # (an arg-max may flip between near-equal outputs)
+    d.close()
