@@ -1655,6 +1655,8 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
                 float* C = jobs[k].outs ? jobs[k].outs[l] : nullptr;
                 if (k == 0) { b.A = A; b.B = B; b.C = C; b.bias = d->bl(jobs[k].net, l); b.Cb = jobs[k].outs_bf[l]; }
                 else { b.Ax[k - 1] = A; b.Bx[k - 1] = B; b.Cx[k - 1] = C; b.biasx[k - 1] = d->bl(jobs[k].net, l); b.Cbx[k - 1] = jobs[k].outs_bf[l]; }
+                // the chain's last activations in B-fragment order when only screen_top2_kernel reads them (bf16 net: max / arg-max pass)
+                if (l == d->nl - 2 && jobs[k].last_bf_frag) b.cb_frag_mask |= 1 << k;
             }
             XQ_TRY((launch_bf16_gemm<L_KCONTIG, L_KCONTIG, BG_TANH>(d, b, njobs, "gemm_hidden_fwd")));
         } else if (bf) {
@@ -2438,8 +2440,11 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         shadow.nblocks = full ? (NO + kShadowRows - 1) / kShadowRows : std::min((int)kShadowDynBlocks, (NO + kShadowRows - 1) / kShadowRows);
         d->scr_static_net = sel_net;
     }
+    // bf16 net: the s' chain's last activations feed only the max / arg-max pass; when both that pass and the forward product run on
+    // their own loops (whole tiles), the product writes them in fragment order
+    const bool bf_frag = bf && nl >= 3 && (Hl == 256 || Hl == 512) && n >= 1024 && (n % kBgBM) == 0 && (d->L[nl - 2] % kBgBK) == 0;
     ChainJob jobs[3] = {{XQ_NET_ONLINE, boards, outs, outs_bf, d->gboards, nullptr, false},
-                        {sel_net, next_boards, touts, touts_bf, nullptr, screened ? d->scr_ab : nullptr, scr_new},
+                        {sel_net, next_boards, touts, touts_bf, nullptr, screened ? d->scr_ab : nullptr, scr_new || bf_frag},
                         {XQ_NET_TARGET, next_boards, t2outs, t2outs_bf, nullptr, nullptr, false}};
     XQ_TRY(chain_boards(d, jobs, dbl ? 3 : 2, slots, n, screened ? &shadow : nullptr));
     int zparts = kReduceParts;
@@ -2525,7 +2530,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         // bf16 Q-net: the same kernel as the screening pass (xq_screen.hip.h) in its exact max / arg-max mode — here the bf16 product
         // IS the net's output layer, not a screen: per 32-row lane group the largest value (+ its row, first maximum: Double DQN)
         ScreenArgs a; memset(&a, 0, sizeof a);
-        a.W = d->wl_bf(sel_net, nl - 1); a.A = touts_bf[nl - 2]; a.a_frag = 0; a.bias = d->bl(sel_net, nl - 1);
+        a.W = d->wl_bf(sel_net, nl - 1); a.A = touts_bf[nl - 2]; a.a_frag = bf_frag ? 1 : 0; a.bias = d->bl(sel_net, nl - 1);
         a.P1 = d->partial; a.P2 = reinterpret_cast<float*>(d->partial_idx);
         screen_geometry(NO, n, Hl, d->ncu, a);
         a.ldp = screen_padded_samples(n, Hl);
