@@ -66,6 +66,8 @@ struct xq_dqn {
     float* sel_acts[XQ_MAX_LAYERS] = {nullptr};
     float* sel_q90 = nullptr;
     int sel_cap = 0;
+    float* qh_slabs[2] = {nullptr, nullptr};    // k-slabs of the select head (handle stream / any other stream)
+    size_t qh_cap[2] = {0, 0};
     bool small_tiles = false;                   // force 64x64 GEMM tiles (<= 80 VGPRs: fits beside the persistent GEMM)
     bool l0_derive = false;                     // xq_dqn_set_l0_derive: layer-0 sums of s' from those of s (online TD rule, fp32 net)
     // exact screening of max_a' Q(s', a') (xq_dqn_set_qmax_mode): bf16 copies of the output-layer weights and of
@@ -1346,6 +1348,18 @@ __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restri
     }
 }
 
+// Q head with the k range split over blocks (q_head): q[m][j] = tanh(b_j + ((s0 + s1) + (s2 + s3))[m][j]) over the four k-slabs of the
+// product (fixed association).  One thread per output.
+__global__ __launch_bounds__(256) void q_head_finish_kernel(const float* __restrict__ slabs, long long slab_stride, int n, int n_out, int lds_,
+                                                            const float* __restrict__ bias, float* __restrict__ q, int ldq) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * n_out) return;
+    const int m = (int)(i / n_out), j = (int)(i % n_out);
+    const float* p = slabs + (long long)m * lds_ + j;
+    const float s0 = p[0], s1 = p[slab_stride], s2 = p[2 * slab_stride], s3 = p[3 * slab_stride];
+    q[(long long)m * ldq + j] = tanhf(bias[j] + ((s0 + s1) + (s2 + s3)));
+}
+
 // bf16 shadow of a weight range (set_params / load_model / set_precision)
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -1702,8 +1716,31 @@ static int q_head(xq_dqn* d, int net, const float* a_last, int n, int n_out, flo
     g.M = n; g.N = n_out; g.K = d->hlast();
     g.A = a_last; g.lda = d->hlast();
     g.B = d->wl(net, d->nl - 1); g.ldb = d->hlast();
-    g.C = q; g.ldc = ldq;
     g.bias = d->bl(net, d->nl - 1);
+    // The select head (selectAction reads q[action.to] only, dqn.cpp:47): 8192 x 96 x K is two column tiles of 64 — 256 blocks, one per
+    // CU, each walking all K / 32 k-tiles behind one another with nothing to hide the load latency behind (20 us at K = 256, 32 us at
+    // K = 512 for 0.4 / 0.8 GFLOP).  Four k-slabs per tile put four blocks on every CU; a one-thread-per-output kernel adds the slabs in a
+    // fixed order, the bias and the tanh.  fp32 nets, large batches (the small ones are not latency-bound per CU to begin with).
+    if (n_out <= 96 && n >= 2048 && (g.K % 128) == 0) {
+        const int nc = round_up(n_out, 4);
+        const size_t need = (size_t)4 * n * nc;
+        float** slab = d->cur == d->stream ? &d->qh_slabs[0] : &d->qh_slabs[1];      // the select chain may run on its own stream beside a TD step
+        size_t* cap = d->cur == d->stream ? &d->qh_cap[0] : &d->qh_cap[1];
+        if (need > *cap) {
+            XQ_HIP(hipDeviceSynchronize());
+            if (*slab) XQ_HIP(hipFree(*slab));
+            XQ_HIP(hipMalloc(slab, need * sizeof(float)));
+            *cap = need;
+        }
+        g.C = *slab; g.ldc = nc; g.slab_stride = (long long)n * nc;
+        XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_STORE>(d, g, 4, name, nullptr, true)));
+        const long long total = (long long)n * n_out;
+        hipLaunchKernelGGL(q_head_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d->cur, *slab, g.slab_stride, n, n_out, nc,
+                           g.bias, q, ldq);
+        XQ_HIP(hipGetLastError());
+        return XQ_OK;
+    }
+    g.C = q; g.ldc = ldq;
     XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH>(d, g, 1, name)));
     return XQ_OK;
 }
@@ -2064,6 +2101,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     for (int i = 0; i < 2; ++i) { hipFree(d->params_bf[i]); hipFree(d->tacts_bf[i]); hipFree(d->t2acts_bf[i]); hipFree(d->t2acts[i]); }
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts_bf[l]); hipFree(d->sel_acts_bf[l]); }
     hipFree(d->partial_idx);
+    hipFree(d->qh_slabs[0]); hipFree(d->qh_slabs[1]);
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) hipFree(d->deltas_bf[l]);
     if (d->side) { hipStreamSynchronize(d->side); hipStreamDestroy(d->side); }
     if (d->ev_fork) hipEventDestroy(d->ev_fork);
