@@ -36,6 +36,7 @@ struct xq_trainer {
     // actually has to wait for them (collect-first or mixed call orders), not on every iteration of the learn_grads -> collect loop
     bool params_event_stale = true;         // ev_params has not been recorded since the last parameter update
     bool grads_event_stale = true;          // ev_grads has not been recorded since the queued learn_grads
+    bool early_collect = false;             // collects_per_update > 1: collects start behind the previous parameter update (see collect_impl)
 };
 
 using namespace xq;
@@ -90,6 +91,7 @@ static int trainer_init(xq_trainer* t, const xq_trainer_config* cfg, void* hip_s
         XQ_HIP(hipEventCreateWithFlags(&t->ev_grads, hipEventDisableTiming));
         XQ_HIP(hipEventRecord(t->ev_params, t->stream));      // orders the first collect after the handles' initialisation
         t->params_event_stale = false;
+        t->early_collect = cfg->collects_per_update > 1;
     }
     return XQ_OK;
 }
@@ -120,9 +122,14 @@ static int collect_impl(xq_trainer* t) {
     hipStream_t on = nullptr;
     if (t->cstream) {
         on = t->cstream;
-        if (t->grads_queued) {
+        if (t->grads_queued && !t->early_collect) {
             // queued behind the column-max GEMM (which wants the chip to itself); that event lies behind every parameter update
             if (t->inflight == 0) XQ_HIP(hipStreamWaitEvent(on, dqn_qmax_event(t->dqn), 0));
+        } else if (t->grads_queued) {
+            // several plies per update: the collect chain is the long pole of the iteration (each ply waits for the move of the one
+            // before) — it starts behind the previous parameter update, recorded there (learn_apply), and runs beside the whole TD step
+            if (t->inflight == 0 && !t->params_event_stale) XQ_HIP(hipStreamWaitEvent(on, t->ev_params, 0));
+            else if (t->inflight == 0) XQ_HIP(hipStreamWaitEvent(on, dqn_qmax_event(t->dqn), 0));     // (no record yet: first iteration)
         } else if (t->inflight == 0) {
             if (t->params_event_stale) { XQ_HIP(hipEventRecord(t->ev_params, t->stream)); t->params_event_stale = false; }
             XQ_HIP(hipStreamWaitEvent(on, t->ev_params, 0));
@@ -265,6 +272,10 @@ int xq_trainer_learn_apply(xq_trainer* t, int world_size) {
         t->per_ready = true;
     }
     t->params_event_stale = true;
+    if (t->cstream && t->early_collect) {       // the next iteration's collects start here, whatever the caller queues first
+        XQ_HIP(hipEventRecord(t->ev_params, t->stream));
+        t->params_event_stale = false;
+    }
     t->inflight = 0;
     t->grads_queued = false;
     return XQ_OK;
