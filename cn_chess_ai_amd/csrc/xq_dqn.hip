@@ -1866,7 +1866,8 @@ static int grad_splits(const xq_dqn* d, int M, int N, int K) {
     if (!grad_bf16_ok(d, M, N, K)) return pick_splits(M, N, K);
     const int tiles = (M / kBgBM) * (N / kBgBN);
     int s = std::max(1, d->ncu / tiles);
-    s = std::min(s, 32);
+    s = std::min(s, 16);                                    // (32 slabs = one block per CU: 0.717 ms per step of bench --config 5; 16: 0.713, and
+                                                            //  half the slab bytes for the SGD kernel)
     while (s > 1 && (K % (s * kBgBK)) != 0) --s;           // whole k-tiles per slab
     return s;
 }
@@ -1957,7 +1958,9 @@ static int bias_grads(xq_dqn* d, BiasJobs& bj, int n) {
 // layer 0: per-(square, piece) segmented sums of delta_0 rows (no dense one-hot product); launches on d->cur
 static int l0_gradient(xq_dqn* d, int n, float* dst) {
     const int H = d->L[1];
-    const int chunk = 1024;                          // samples per block (list entries hold 11 bits of sample index)
+    // samples per block (list entries hold 11 bits of sample index).  8192 samples: 1024 (2048 measured 56 against 52 us, round 2);
+    // 16384 samples: 2048 — half the partial slabs for the SGD kernel to sum (41 -> 20 MB), bench --config 5 0.717 -> 0.704 ms
+    const int chunk = n >= 16384 ? 2048 : 1024;
     const int nchunks = (n + chunk - 1) / chunk;
     const long long len = (long long)kStateSize * H;
     float* out = dst;
