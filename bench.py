@@ -251,6 +251,8 @@ def main():
                     help="--config 5: XQ_PRECISION_BF16 (bf16 forward, fp32 backward products) instead of XQ_PRECISION_BF16_FULL")
     ap.add_argument("--no-derive", action="store_true",
                     help="gather layer 0 of the s' chain in full (the library default) instead of deriving it from the s chain")
+    ap.add_argument("--no-td-tail", action="store_true",
+                    help="A/B: the gradient kernels of the TD step one by one on two streams instead of the fused launches (xq_dqn_set_td_tail)")
     ap.add_argument("--no-variants", action="store_true", help="skip the variant legs (other TD net, full fp32 product): A/B runs")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps, barrier + synchronize on both sides) is run this many times back to "
@@ -311,6 +313,7 @@ def main():
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
     t.dqn.set_qmax_mode(_capi.QMAX_SCREENED if args.qmax == "screened" else _capi.QMAX_FULL)
     t.dqn.set_l0_derive(not args.no_derive)       # layer-0 sums of s' from those of s (library default: off, the reference's order)
+    if args.no_td_tail: t.dqn.set_td_tail(False)  # A/B: the gradient kernels one by one on two streams (library default: fused launches)
     grads, comm, comm_error = None, None, ""
     if world == 1 and os.environ.get("XQ_BENCH_COMM1"):
         # rehearsal on one GPU: a one-rank communicator attached, so that the whole N > 1 code path of the library runs (bucketed
@@ -548,7 +551,10 @@ def main():
             line["roofline_env"] = {"kernel": "env_kernel<SELFPLAY> (movegen+select+move+reward+reset, %d boards)" % n_games,
                                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("env_kernel<2>", args.config)[0], "avg_launch_ms": ms,
-                                    "bytes_per_launch": by, "launches": e["launches"]}
+                                    "bytes_per_launch": by, "launches": e["launches"],
+                                    "launches_note": "HIP-event brackets on " + ("every launch" if args.bracket_all or args.profile_all else
+                                                     "every 5th launch (the brackets sit on the collect stream: ~12 us per ply, which "
+                                                     "is the critical chain when an update has several plies)")}
             mix = env_instruction_mix() if args.config == 2 else None
             if mix:
                 # the bound that actually applies: instruction issue.  Floor = the larger of the VALU issue time (a wave64 VALU

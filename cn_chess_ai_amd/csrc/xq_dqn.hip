@@ -23,6 +23,7 @@
 #include <cmath>
 #include <random>
 
+namespace xq { struct TailArgs; }
 struct xq_dqn {
     int ns = 0, nl = 0;
     int L[XQ_MAX_LAYERS + 1] = {0};
@@ -114,6 +115,7 @@ struct xq_dqn {
     int l0_pending = 0;                         // > 0: that many layer-0 slabs wait in slabs_l0, not yet reduced into grads_td
     struct PendingSlab { const float* src = nullptr; int nslabs = 0; long long stride = 0; };
     PendingSlab pend_hidden[XQ_MAX_LAYERS], pend_wout, pend_bout;   // same for the hidden / output-layer gradients (fused_apply)
+    PendingSlab pend_bh;                        // ... and the hidden biases (rows of column sums, bias_grads)
     float* bias_work = nullptr;  size_t bias_work_cap = 0;
     // dense API scratch
     float* xdense = nullptr;  size_t xdense_cap = 0;
@@ -122,6 +124,12 @@ struct xq_dqn {
     uint32_t* hb = nullptr;   size_t hb_cap = 0;     // host-batch staging: boards, next boards
     int32_t* ha = nullptr; float* hr = nullptr; uint8_t* hd = nullptr;
     xq::Profiler prof;
+    // fused launches of the TD step's tail (td_tail_kernel): while `tail_open`, the launch helpers of the small fp32 GEMMs, the
+    // output-layer / layer-0 segmented sums and the bias column sums append their blocks to `tail` instead of launching
+    xq::TailArgs* tail = nullptr;
+    bool tail_open = false;
+    bool td_tail = true;                        // xq_dqn_set_td_tail
+    size_t tail_lds = 0;  double tail_flops = 0, tail_bytes = 0;
 
     // partial-sum slabs may stay unreduced until the SGD kernel only when nothing (an all-reduce) reads the buffer in between
     bool fused() const { return fused_apply && comm == nullptr; }
@@ -146,7 +154,8 @@ hipEvent_t dqn_qmax_event(xq_dqn* d) { return d->ev_qmax; }
 
 struct ProfScope {
     Profiler& p; hipStream_t s; int h; double flops, bytes;
-    ProfScope(xq_dqn* d, const char* name, double fl, double by) : p(d->prof), s(d->cur), flops(fl), bytes(by) { h = p.begin(name, s); }
+    // (while a fused tail launch is being assembled nothing is launched, so nothing is bracketed: tail_launch has its own scope)
+    ProfScope(xq_dqn* d, const char* name, double fl, double by) : p(d->prof), s(d->cur), flops(fl), bytes(by) { h = d->tail_open ? -1 : p.begin(name, s); }
     ~ProfScope() { p.end(h, s, flops, bytes); }
 };
 
@@ -486,17 +495,18 @@ __constant__ unsigned char kL0SquareOrder[90] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 19, 
 // Wide layers: blockIdx.z picks a slab of HS columns (grid z = H / HS) — at H = 512 one block per (square, chunk) could keep only two
 // accumulator sets in LDS (two of its four waves streaming, 265 us at 16384 x 512); two 256-column slabs are two blocks of the
 // H = 256 shape each (four sets, 2 blocks per CU).  Every slab compacts the chunk for itself (cheap) and streams its own columns.
-__global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict__ gboards, const float* __restrict__ delta0_all,
-                                                      int n, int Hfull, int HS, int chunk, int nsets, float* __restrict__ partial_all) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// (block body: `lin` = linear id of the block inside its column slab, nch = chunks, slab = column slab — gridDim (90, nch, H / HS) in
+// l0_grad_kernel; td_tail_kernel hands the same triple to its layer-0 blocks)
+__device__ __forceinline__ void l0_grad_block(const uint32_t* __restrict__ gboards, const float* __restrict__ delta0_all,
+                                              int n, int Hfull, int HS, int chunk, int nsets, float* __restrict__ partial_all,
+                                              int lin, int nch, int slab, float* __restrict__ smem) {
     const int H = HS;                                   // width this block works on; rows of delta0 / partial are Hfull apart
-    const float* __restrict__ delta0 = delta0_all + (long long)blockIdx.z * HS;
-    float* __restrict__ partial = partial_all + (long long)blockIdx.z * HS;
+    const float* __restrict__ delta0 = delta0_all + (long long)slab * HS;
+    float* __restrict__ partial = partial_all + (long long)slab * HS;
     float* acc = smem;                                  // [nsets][14][H]
     uint16_t* list = reinterpret_cast<uint16_t*>(smem + (long long)nsets * 14 * H);   // [chunk] (b_local | piece << 11)
     // workgroups go to the 8 XCDs round-robin in linear order: chunk = linear id mod nchunks keeps all 90 square-blocks of a chunk
     // (they stream the same 1 MB of delta rows, each up to 32 times) behind one XCD's L2 when there are 8 chunks
-    const int lin = (int)(blockIdx.x + gridDim.x * blockIdx.y), nch = (int)gridDim.y;
     const int s = kL0SquareOrder[lin / nch];
     const int c0 = (lin % nch) * chunk;
     const int c1 = min(n, c0 + chunk);
@@ -601,6 +611,12 @@ __global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict
         for (int w = 1; w < used; ++w) t += acc[(long long)w * 14 * H + i];
         out[(long long)(i / H) * Hfull + (i % H)] = t;
     }
+}
+__global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict__ gboards, const float* __restrict__ delta0_all,
+                                                      int n, int Hfull, int HS, int chunk, int nsets, float* __restrict__ partial_all) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    l0_grad_block(gboards, delta0_all, n, Hfull, HS, chunk, nsets, partial_all, (int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.y,
+                  (int)blockIdx.z, smem);
 }
 
 // zmax[b] = max over the column-max GEMM's partial rows t of partial[t][b] (and, for Double DQN, the row index that came with
@@ -861,16 +877,14 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
 // activation row is read exactly once.  Block (group of 4 actions, chunk of samples): ordered compaction of the chunk's
 // samples whose action falls in the group, then the rows are streamed into per-wave LDS accumulators (combined in fixed
 // order => bitwise reproducible).  partial[chunk][96*H + 96] (weights, then biases).
-__global__ __launch_bounds__(256) void out_grad_kernel(const int32_t* __restrict__ act, const float* __restrict__ dsc,
-                                                       const float* __restrict__ a_last, int n, int H, int chunk,
-                                                       float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void out_grad_block(const int32_t* __restrict__ act, const float* __restrict__ dsc,
+                                               const float* __restrict__ a_last, int n, int H, int chunk,
+                                               float* __restrict__ partial, int g /* actions 4g .. 4g+3 */, int chunk_id, float* __restrict__ smem) {
     float* acc = smem;                                  // [4 waves][4 actions][H]
     uint16_t* list = reinterpret_cast<uint16_t*>(smem + 16 * H);   // [chunk] (b_local | class << 11)
     __shared__ int total;
     __shared__ float bsum[4][4];
-    const int g = (int)blockIdx.x;                      // actions 4g .. 4g+3
-    const int c0 = (int)blockIdx.y * chunk, c1 = min(n, c0 + chunk);
+    const int c0 = chunk_id * chunk, c1 = min(n, c0 + chunk);
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // the chunk's actions first (all loads of a thread in flight together), accumulator zeroing under their latency; then the
     // ordered compaction with two barriers in all: per-wave counts of every round published first, offsets = prefix sums over
@@ -956,10 +970,16 @@ __global__ __launch_bounds__(256) void out_grad_kernel(const int32_t* __restrict
     }
     if (lane == 0) { bsum[wid][0] = bs0; bsum[wid][1] = bs1; bsum[wid][2] = bs2; bsum[wid][3] = bs3; }
     __syncthreads();
-    float* out = partial + (long long)blockIdx.y * (96LL * H + 96);
+    float* out = partial + (long long)chunk_id * (96LL * H + 96);
     for (int i = tid; i < 4 * H; i += 256)
         out[(long long)4 * g * H + i] = ((acc[i] + acc[4 * H + i]) + acc[8 * H + i]) + acc[12 * H + i];
     if (tid < 4) out[96LL * H + 4 * g + tid] = ((bsum[0][tid] + bsum[1][tid]) + bsum[2][tid]) + bsum[3][tid];
+}
+__global__ __launch_bounds__(256) void out_grad_kernel(const int32_t* __restrict__ act, const float* __restrict__ dsc,
+                                                       const float* __restrict__ a_last, int n, int H, int chunk,
+                                                       float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    out_grad_block(act, dsc, a_last, n, H, chunk, partial, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
 
 // dense output delta (general DQN::backpropagate target): d = (q - t) * (1 - q^2)
@@ -977,20 +997,20 @@ struct ColsumJobs {
     long long ld[XQ_MAX_LAYERS + 1];
     int C[XQ_MAX_LAYERS + 1];
     float* dst[XQ_MAX_LAYERS + 1];
-    long long poff[XQ_MAX_LAYERS + 1];   // offset of the job's [R][C] partial block in the workspace
+    long long poff[XQ_MAX_LAYERS + 1];   // first column of the job in the workspace
     int njobs, n, rows_per, R;
-    float* work;
+    float* work;                         // [R][wld]: row y = the sums over row chunk y, the jobs side by side — for the TD step in the
+    long long wld;                       // order of the hidden biases, so that the SGD kernel can take the R rows as slabs (fused_apply)
 };
-__global__ __launch_bounds__(256) void colsum_partial_kernel(ColsumJobs J) {
+__device__ __forceinline__ void colsum_partial_block(const ColsumJobs& J, int bx, int by, int job) {
     __shared__ float red[4][64];
-    const int job = (int)blockIdx.z;
     const int C = J.C[job];
     const int tx = (int)(threadIdx.x & 63), ty = (int)(threadIdx.x >> 6);
-    const int c = (int)blockIdx.x * 64 + tx;
-    if ((int)blockIdx.x * 64 >= C) return;
+    const int c = bx * 64 + tx;
+    if (bx * 64 >= C) return;
     const float* X = J.X[job];
     const long long ld = J.ld[job];
-    const int r0 = (int)blockIdx.y * J.rows_per, r1 = min(J.n, r0 + J.rows_per);
+    const int r0 = by * J.rows_per, r1 = min(J.n, r0 + J.rows_per);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < C) {
         int r = r0 + ty;
@@ -1005,7 +1025,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(ColsumJobs J) {
     red[ty][tx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (ty == 0 && c < C)
-        J.work[J.poff[job] + (long long)blockIdx.y * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        J.work[J.poff[job] + (long long)by * J.wld + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+__global__ __launch_bounds__(256) void colsum_partial_kernel(ColsumJobs J) {
+    colsum_partial_block(J, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(ColsumJobs J) {   // 64 columns x 4 partial lanes per block
     __shared__ float red[4][64];
@@ -1014,16 +1037,76 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(ColsumJobs J) {   // 
     const int tx = (int)(threadIdx.x & 63), ty = (int)(threadIdx.x >> 6);
     const int c = (int)blockIdx.x * 64 + tx;
     if ((int)blockIdx.x * 64 >= C) return;
-    float s0 = 0.f, s1 = 0.f;
+    // the order of reduce_slabs_kernel / sgd_segments_kernel (four chains z = j, j + 4, ..; ((s0 + s1) + (s2 + s3))): the SGD kernel may
+    // sum the rows itself (fused_apply) with the same bits
+    float s0 = 0.f;
     if (c < C) {
         const float* p = J.work + J.poff[job] + c;
-        int z = ty;
-        for (; z + 4 < J.R; z += 8) { s0 += p[(long long)z * C]; s1 += p[(long long)(z + 4) * C]; }
-        if (z < J.R) s0 += p[(long long)z * C];
+        for (int z = ty; z < J.R; z += 4) s0 += p[(long long)z * J.wld];
     }
-    red[ty][tx] = s0 + s1;
+    red[ty][tx] = s0;
     __syncthreads();
     if (ty == 0 && c < C) J.dst[job][c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+// The tail of a TD step as TWO launches on one stream instead of seven on two: every event record on the critical stream costs
+// ~6 us of idle time and the join at the end 3-12 us, more than the kernels between them are worth.  One launch
+// carries the blocks of several kernels ("horizontal fusion"): the grid is the concatenation of their grids, a block finds its body
+// from its linear id (block-uniform branch), dynamic LDS = the largest of the bodies present.  Launch 1 (behind td_delta_kernel,
+// once per hidden layer below the top one): the delta GEMM of the next layer down + what only needs the deltas already there — the
+// weight-gradient GEMM of the layer above it and, first time round, the output-layer segmented sum.  Launch 2: the layer-0
+// segmented sum + the bias column sums.  Long blocks come first in the grid.  Every body is the block function of the stand-alone
+// kernel, so the results are bitwise those of the two-stream path (tests/test_dqn_gpu.py).
+enum { TAIL_DELTA = 1, TAIL_GRAD = 2, TAIL_OUT = 4, TAIL_COLSUM = 8, TAIL_L0 = 16 };
+struct TailArgs {
+    // grid order: [l0][grad][delta][out][colsum]; n_* = blocks of each part (0 = absent)
+    int n_l0, n_grad, n_delta, n_out, n_colsum;
+    GemmArgs grad;  int grad_gx, grad_gy;          // 64x64 tiles: grid (gx, gy, splits)
+    GemmArgs delta; int delta_gx;                  // grid (gx, gy, 1)
+    const int32_t* og_act; const float* og_dsc; const float* og_alast; int og_n, og_H, og_chunk; float* og_partial;   // grid (24, chunks)
+    const uint32_t* l0_boards; const float* l0_delta; int l0_n, l0_H, l0_HS, l0_chunk, l0_nsets, l0_nch; float* l0_partial;   // (90, nch, H / HS)
+    ColsumJobs cj; int cj_gx, cj_gy;               // grid (gx, R, njobs)
+};
+template <unsigned KINDS>
+__global__ __launch_bounds__(256) void td_tail_kernel(const TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tail_smem[];
+    int b = (int)blockIdx.x;
+    if (KINDS & TAIL_L0) {
+        if (b < a.n_l0) {
+            const int per = kSquares * a.l0_nch;
+            l0_grad_block(a.l0_boards, a.l0_delta, a.l0_n, a.l0_H, a.l0_HS, a.l0_chunk, a.l0_nsets, a.l0_partial, b % per, a.l0_nch, b / per, tail_smem);
+            return;
+        }
+        b -= a.n_l0;
+    }
+    if (KINDS & TAIL_GRAD) {
+        if (b < a.n_grad) {
+            const int per = a.grad_gx * a.grad_gy, r = b % per;
+            gemm_f32_block<L_MCONTIG, L_MCONTIG, EPI_STORE, 1, 1>(a.grad, r % a.grad_gx, r / a.grad_gx, b / per, tail_smem, tail_smem + g_tile_floats(64));
+            return;
+        }
+        b -= a.n_grad;
+    }
+    if (KINDS & TAIL_DELTA) {
+        if (b < a.n_delta) {
+            gemm_f32_block<L_KCONTIG, L_MCONTIG, EPI_DELTA, 1, 1>(a.delta, b % a.delta_gx, b / a.delta_gx, 0, tail_smem, tail_smem + g_tile_floats(64));
+            return;
+        }
+        b -= a.n_delta;
+    }
+    if (KINDS & TAIL_OUT) {
+        if (b < a.n_out) {
+            out_grad_block(a.og_act, a.og_dsc, a.og_alast, a.og_n, a.og_H, a.og_chunk, a.og_partial, b % 24, b / 24, tail_smem);
+            return;
+        }
+        b -= a.n_out;
+    }
+    if (KINDS & TAIL_COLSUM) {
+        if (b < a.n_colsum) {
+            const int per = a.cj_gx * a.cj_gy, r = b % per;
+            colsum_partial_block(a.cj, r % a.cj_gx, r / a.cj_gx, b / per);
+        }
+    }
 }
 
 // out[i] = sum_z slabs[z*stride + i], z ascending (deterministic)
@@ -1419,6 +1502,20 @@ static int launch_gemm(xq_dqn* d, GemmArgs g, int splits, const char* name, int*
     const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.grouped ? groups : splits);
     const bool big = force_big || (!force_small && !d->small_tiles && t128 >= 512);
     const double kk = DT == DT_BF16 ? 2.0 * g.K : (double)g.K;       // bf16: K counts pairs
+    if (d->tail_open) {                  // fused tail launch (td_tail_kernel): the blocks join the open grid instead of launching
+        TailArgs& T = *d->tail;
+        const bool is_delta = AL == L_KCONTIG && BL == L_MCONTIG && EPI == EPI_DELTA, is_grad = AL == L_MCONTIG && BL == L_MCONTIG && EPI == EPI_STORE;
+        if (DT != DT_F32 || big || g.grouped || !(is_delta || is_grad) || (is_delta && (T.n_delta || splits != 1)) || (is_grad && T.n_grad))
+            return fail(XQ_ERR_RUNTIME, "GEMM %s cannot join the fused tail launch", name);
+        const int gx = (g.M + 63) / 64, gy = (g.N + 63) / 64;
+        if (is_delta) { T.delta = g; T.delta_gx = gx; T.n_delta = gx * gy; }
+        else { T.grad = g; T.grad_gx = gx; T.grad_gy = gy; T.n_grad = gx * gy * splits; }
+        d->tail_flops += 2.0 * g.M * g.N * kk;
+        d->tail_bytes += 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+        d->tail_lds = std::max(d->tail_lds, 2 * (size_t)g_tile_floats(64) * sizeof(float));
+        if (used_splits) *used_splits = splits;
+        return XQ_OK;
+    }
     ProfScope ps(d, name, 2.0 * g.M * g.N * kk, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
     if (g.grouped) {
         if (splits != 1) return fail(XQ_ERR_INVALID_ARGUMENT, "grouped GEMM cannot be split-K");
@@ -1815,11 +1912,11 @@ static int check_reference_topology(const xq_dqn* d) {
 // hidden deltas l = nl-2 .. 0 from the output-side delta `dnext` ([n][ld_next], only the first k_nz columns can be
 // non-zero).  reference mode: delta_l = (dnext[:, :L[l+1]] x View) * (1-a^2), View[i][idx] = Wflat[wo[l+1] + i*L[l] + idx];
 // textbook: View[k][idx] = W_{l+1}[k][idx], k < L[l+2].
-static int hidden_deltas(xq_dqn* d, int n, const float* dnext, int ld_next, int k_nz, int mode, int l_start = -1) {
+static int hidden_deltas(xq_dqn* d, int n, const float* dnext, int ld_next, int k_nz, int mode, int l_start = -1, int l_stop = 0) {
     const float* up = dnext;
     int ld_up = ld_next, nz = k_nz;
     if (l_start < 0) l_start = d->nl - 2;
-    for (int l = l_start; l >= 0; --l) {
+    for (int l = l_start; l >= l_stop; --l) {
         GemmArgs g; memset(&g, 0, sizeof g);
         g.M = n; g.N = d->L[l + 1];
         const int kfull = (mode == XQ_BACKPROP_REFERENCE) ? d->L[l + 1] : d->L[l + 2];
@@ -1930,7 +2027,9 @@ struct BiasJobs {
         J.X[k] = X; J.ld[k] = ld; J.C[k] = C; J.dst[k] = dst;
     }
 };
-static int bias_grads(xq_dqn* d, BiasJobs& bj, int n) {
+// defer != nullptr (fused_apply, TD step: the jobs are the hidden layers in ascending order, their destinations contiguous): the rows
+// of partial sums are left to the SGD kernel as slabs — no final reduction launch
+static int bias_grads(xq_dqn* d, BiasJobs& bj, int n, xq_dqn::PendingSlab* defer = nullptr) {
     ColsumJobs& J = bj.J;
     if (J.njobs == 0) return XQ_OK;
     J.n = n;
@@ -1938,18 +2037,28 @@ static int bias_grads(xq_dqn* d, BiasJobs& bj, int n) {
     J.rows_per = (n + J.R - 1) / J.R;
     long long off = 0;
     int maxc = 0;
-    for (int k = 0; k < J.njobs; ++k) { J.poff[k] = off; off += (long long)J.R * J.C[k]; maxc = std::max(maxc, J.C[k]); }
+    for (int k = 0; k < J.njobs; ++k) { J.poff[k] = off; off += J.C[k]; maxc = std::max(maxc, J.C[k]); }
+    J.wld = off;
+    off *= J.R;
     if ((size_t)off > d->bias_work_cap) {
         if (d->bias_work) { XQ_HIP(hipStreamSynchronize(d->stream)); XQ_HIP(hipFree(d->bias_work)); }
         XQ_HIP(hipMalloc(&d->bias_work, (size_t)off * sizeof(float)));
         d->bias_work_cap = (size_t)off;
     }
     J.work = d->bias_work;
+    if (defer) { defer->src = J.work; defer->nslabs = J.R; defer->stride = J.wld; }
     double tot = 0;
     for (int k = 0; k < J.njobs; ++k) tot += (double)n * J.C[k];
+    if (d->tail_open) {                  // fused tail launch: the partial sums join the open grid (always deferred to the SGD kernel there)
+        TailArgs& T = *d->tail;
+        T.cj = J; T.cj_gx = (maxc + 63) / 64; T.cj_gy = J.R; T.n_colsum = T.cj_gx * T.cj_gy * J.njobs;
+        d->tail_flops += tot; d->tail_bytes += 4.0 * tot;
+        return XQ_OK;
+    }
     ProfScope ps(d, "bias_grad_colsum", tot, 4.0 * tot);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((maxc + 63) / 64, J.R, J.njobs), dim3(256), 0, d->cur, J);
     XQ_HIP(hipGetLastError());
+    if (defer) return XQ_OK;
     hipLaunchKernelGGL(colsum_final_kernel, dim3((maxc + 63) / 64, J.njobs), dim3(256), 0, d->cur, J);
     XQ_HIP(hipGetLastError());
     return XQ_OK;
@@ -1980,9 +2089,17 @@ static int l0_gradient(xq_dqn* d, int n, float* dst) {
         while (nsets > 1 && (size_t)nsets * 14 * HS * sizeof(float) > 60 * 1024) nsets >>= 1;
         const size_t shmem = (size_t)nsets * 14 * HS * sizeof(float) + (size_t)chunk * sizeof(uint16_t);
         if (shmem > 64 * 1024) return fail(XQ_ERR_INVALID_ARGUMENT, "first hidden layer too wide for the layer-0 gradient kernel (%d)", H);
+        if (d->tail_open) {              // fused tail launch
+            TailArgs& T = *d->tail;
+            T.l0_boards = d->gboards; T.l0_delta = d->deltas[0]; T.l0_n = n; T.l0_H = H; T.l0_HS = HS; T.l0_chunk = chunk; T.l0_nsets = nsets;
+            T.l0_nch = nchunks; T.l0_partial = out; T.n_l0 = kSquares * nchunks * (H / HS);
+            d->tail_flops += 2.0 * n * 32 * H; d->tail_bytes += (double)n * (32.0 * H * 4 + 48) + 4.0 * nchunks * len;
+            d->tail_lds = std::max(d->tail_lds, shmem);
+        } else {
         hipLaunchKernelGGL(l0_grad_kernel, dim3(kSquares, nchunks, H / HS), dim3(256), shmem, d->cur, d->gboards, d->deltas[0], n, H, HS,
                            chunk, nsets, out);
         XQ_HIP(hipGetLastError());
+        }
     }
     d->l0_pending = 0;
     if (nchunks > 1 && d->fused()) {
@@ -2107,6 +2224,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     hipFree(d->qh_slabs[0]); hipFree(d->qh_slabs[1]);
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) hipFree(d->deltas_bf[l]);
     if (d->side) { hipStreamSynchronize(d->side); hipStreamDestroy(d->side); }
+    delete d->tail;
     if (d->ev_fork) hipEventDestroy(d->ev_fork);
     if (d->ev_join) hipEventDestroy(d->ev_join);
     if (d->ev_delta) hipEventDestroy(d->ev_delta);
@@ -2180,6 +2298,12 @@ int xq_dqn_set_l0_derive(xq_dqn* d, int on) {
     return XQ_OK;
 }
 
+int xq_dqn_set_td_tail(xq_dqn* d, int on) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    d->td_tail = on != 0;
+    return XQ_OK;
+}
+
 int xq_dqn_set_qmax_mode(xq_dqn* d, int mode) {
     if (!d || (mode != XQ_QMAX_FULL && mode != XQ_QMAX_SCREENED)) return fail(XQ_ERR_INVALID_ARGUMENT, "bad qmax mode");
     d->qmax_mode = mode;
@@ -2201,7 +2325,7 @@ int xq_dqn_qmax_stats(xq_dqn* d, uint64_t stats[4]) {
 int xq_dqn_set_precision(xq_dqn* d, int precision) {
     if (!d || (precision != XQ_PRECISION_F32 && precision != XQ_PRECISION_BF16 && precision != XQ_PRECISION_BF16_FULL))
         return fail(XQ_ERR_INVALID_ARGUMENT, "bad precision");
-    if (d->l0_pending > 0 || d->pend_wout.nslabs > 0)
+    if (d->l0_pending > 0 || d->pend_wout.nslabs > 0 || d->pend_bh.nslabs > 0)
         return fail(XQ_ERR_RUNTIME, "xq_dqn_set_precision: a TD step is waiting for its apply_grads");
     if (precision != XQ_PRECISION_F32) {
         for (int l = 1; l <= d->nl - 1; ++l)
@@ -2405,11 +2529,109 @@ static int side_gradients(xq_dqn* d, int n, float* const* outs, float* G) {
         XQ_TRY((grad_gemm<L_MCONTIG>(d, g, G + d->g_wh[l], "gemm_grad_hidden", fused ? d->slabs + off_h[l] : nullptr,
                                      fused ? &d->pend_hidden[l] : nullptr, d->bf16_bwd() ? d->deltas_bf[l] : nullptr,
                                      d->bf16_bwd() ? d->acts_bf[l - 1] : nullptr)));
-        bj.add(d->deltas[l], d->L[l + 1], d->L[l + 1], G + d->g_bh[l]);
     }
-    bj.add(d->deltas[0], d->L[1], d->L[1], G + d->g_bh[0]);
+    for (int l = 0; l <= nl - 2; ++l) bj.add(d->deltas[l], d->L[l + 1], d->L[l + 1], G + d->g_bh[l]);     // the order of the bias vector
     if (!waited) XQ_HIP(hipStreamWaitEvent(d->cur, d->ev_delta, 0));
-    return bias_grads(d, bj, n);
+    d->pend_bh = xq_dqn::PendingSlab();
+    return bias_grads(d, bj, n, fused ? &d->pend_bh : nullptr);
+}
+
+// ---- the same gradients as fused launches on the handle's stream (td_tail_kernel): no side stream, no event --------------------
+static void tail_begin(xq_dqn* d) {
+    if (!d->tail) d->tail = new TailArgs();
+    memset(d->tail, 0, sizeof(TailArgs));
+    d->tail_open = true; d->tail_lds = 0; d->tail_flops = d->tail_bytes = 0;
+}
+static int tail_launch(xq_dqn* d, bool last, const char* name) {
+    d->tail_open = false;
+    const TailArgs& T = *d->tail;
+    const long long total = (long long)T.n_l0 + T.n_grad + T.n_delta + T.n_out + T.n_colsum;
+    if (total <= 0) return XQ_OK;
+    ProfScope ps(d, name, d->tail_flops, d->tail_bytes);
+    auto launch = [&](auto kern) {
+        static size_t granted = 48 * 1024;            // per instantiation
+        if (d->tail_lds > granted) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            granted = 64 * 1024;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), d->tail_lds, d->cur, T);
+    };
+    if (last) launch(td_tail_kernel<TAIL_L0 | TAIL_GRAD | TAIL_OUT | TAIL_COLSUM>);
+    else launch(td_tail_kernel<TAIL_GRAD | TAIL_DELTA | TAIL_OUT>);
+    XQ_HIP(hipGetLastError());
+    return XQ_OK;
+}
+// shapes the fused launches take: fp32 products on 64x64 tiles (what launch_gemm picks for them anyway), slabs summed by the SGD
+// kernel (nothing between the launches may need a finished gradient), no communicator (its buckets ride on two streams)
+static bool tail_eligible(xq_dqn* d, int n) {
+    if (!d->td_tail || d->bf16() || d->comm || !d->fused()) return false;
+    for (int l = 0; l + 2 < d->nl; ++l)
+        if (!d->small_tiles && (long long)((n + 127) / 128) * ((d->L[l + 1] + 127) / 128) >= 512) return false;   // launch_gemm would go 128x128
+    return true;
+}
+static int tail_gradients(xq_dqn* d, int n, float* const* outs, float* G, int mode) {
+    const int nl = d->nl, Hl = d->hlast();
+    const int chunk = 256;                           // out_grad: samples per block (see side_gradients)
+    const int nchunks = (n + chunk - 1) / chunk;
+    const long long len_out = 96LL * Hl + 96;
+    size_t off_h[XQ_MAX_LAYERS] = {0}, need = 0;
+    if (nchunks > 1) need += (size_t)nchunks * (size_t)len_out;
+    for (int l = nl - 2; l >= 1; --l) {
+        off_h[l] = need;
+        const int sp = grad_splits(d, d->L[l + 1], d->L[l], n);
+        if (sp > 1) need += (size_t)sp * (size_t)d->L[l + 1] * (size_t)d->L[l];
+    }
+    XQ_TRY(ensure_slabs(d, need));
+    for (int l = 0; l < XQ_MAX_LAYERS; ++l) d->pend_hidden[l] = xq_dqn::PendingSlab();
+    d->pend_wout = d->pend_bout = xq_dqn::PendingSlab();
+    const size_t og_lds = (size_t)16 * Hl * sizeof(float) + (size_t)chunk * sizeof(uint16_t);
+    if (og_lds > 64 * 1024 || (Hl & 3)) return fail(XQ_ERR_INVALID_ARGUMENT, "last hidden layer width %d unsupported by the output-gradient kernel (multiple of 4, <= 960)", Hl);
+    auto add_out_grad = [&]() {
+        TailArgs& T = *d->tail;
+        float* out = nchunks > 1 ? d->slabs : G + d->g_wout;
+        T.og_act = d->act_mb; T.og_dsc = d->dsc; T.og_alast = outs[nl - 2]; T.og_n = n; T.og_H = Hl; T.og_chunk = chunk; T.og_partial = out;
+        T.n_out = 24 * nchunks;
+        d->tail_flops += 2.0 * n * Hl; d->tail_bytes += (double)n * (Hl * 4 + 8) + 4.0 * nchunks * len_out;
+        d->tail_lds = std::max(d->tail_lds, og_lds);
+        if (nchunks > 1) {
+            d->pend_wout.src = out; d->pend_wout.nslabs = nchunks; d->pend_wout.stride = len_out;
+            d->pend_bout.src = out + 96LL * Hl; d->pend_bout.nslabs = nchunks; d->pend_bout.stride = len_out;
+        }
+    };
+    // one launch per hidden layer below the top one: delta_l from delta_{l+1}, the weight gradient of layer l+1 (delta_{l+1}, a_l)
+    // beside it, the output-layer sums beside the first
+    auto add_grad = [&](int ll) -> int {             // weight gradient of hidden layer ll: delta_ll^T a_{ll-1}
+        GemmArgs g; memset(&g, 0, sizeof g);
+        g.M = d->L[ll + 1]; g.N = d->L[ll]; g.K = n;
+        g.A = d->deltas[ll]; g.lda = d->L[ll + 1];
+        g.B = outs[ll - 1]; g.ldb = d->L[ll];
+        return grad_gemm<L_MCONTIG>(d, g, G + d->g_wh[ll], "gemm_grad_hidden", d->slabs + off_h[ll], &d->pend_hidden[ll]);
+    };
+    // two hidden layers: the one weight-gradient product runs beside the layer-0 sums (L2-bound) rather than beside the delta product
+    // (both MFMA-bound, and the select chain's Q head is on the chip at that time): 0.2065 against 0.2086 ms per step of the headline
+    // bench; three hidden layers (bench --config 4): no difference, kept beside the delta products
+    const char* dg = getenv("XQ_TAIL_DEFER_GRAD");
+    const bool defer_grad = dg ? dg[0] == '1' : nl == 3;
+    int waiting = -1;
+    for (int l = nl - 3; l >= 0; --l) {
+        tail_begin(d);
+        XQ_TRY(hidden_deltas(d, n, d->deltas[l + 1], d->L[l + 2], d->L[l + 2], mode, l, l));
+        if (defer_grad) { if (waiting >= 0) XQ_TRY(add_grad(waiting)); waiting = l + 1; }
+        else XQ_TRY(add_grad(l + 1));
+        if (l == nl - 3) add_out_grad();
+        XQ_TRY(tail_launch(d, false, "td_tail_deltas"));
+    }
+    // last launch: the layer-0 sums and the bias column sums of every hidden delta (+ the output-layer sums of a net without a second
+    // hidden layer)
+    tail_begin(d);
+    XQ_TRY(l0_gradient(d, n, G + d->g_w0));
+    if (waiting >= 0) XQ_TRY(add_grad(waiting));
+    if (nl < 3) add_out_grad();
+    BiasJobs bj;
+    for (int l = 0; l <= nl - 2; ++l) bj.add(d->deltas[l], d->L[l + 1], d->L[l + 1], G + d->g_bh[l]);
+    d->pend_bh = xq_dqn::PendingSlab();
+    XQ_TRY(bias_grads(d, bj, n, &d->pend_bh));
+    return tail_launch(d, true, "td_tail_l0");
 }
 
 static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next_boards, const int32_t* action_to,
@@ -2669,6 +2891,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     // the output-layer gradient, the top hidden layer's gradient GEMM — and, once the deltas exist, the lower gradient
     // GEMMs and the bias column sums.
     float* G = d->grads_td;
+    if (tail_eligible(d, n)) return tail_gradients(d, n, outs, G, mode);
     XQ_HIP(hipEventRecord(d->ev_fork, d->stream));
     XQ_HIP(hipStreamWaitEvent(d->side, d->ev_fork, 0));
     if (nl >= 3) XQ_TRY(hidden_deltas(d, n, d->deltas[nl - 2], d->L[nl - 1], d->L[nl - 1], mode, nl - 3));
@@ -2702,7 +2925,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
 
 int xq_dqn_set_comm(xq_dqn* d, xq_comm* comm) {
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
-    if (d->l0_pending > 0 || d->pend_wout.nslabs > 0)
+    if (d->l0_pending > 0 || d->pend_wout.nslabs > 0 || d->pend_bh.nslabs > 0)
         return fail(XQ_ERR_RUNTIME, "xq_dqn_set_comm: a TD step is waiting for its apply_grads");
     d->comm = comm;
     return XQ_OK;
@@ -2710,7 +2933,7 @@ int xq_dqn_set_comm(xq_dqn* d, xq_comm* comm) {
 
 int xq_allreduce_grads(xq_dqn* d, xq_comm* comm) {
     if (!d || !comm) return fail(XQ_ERR_INVALID_ARGUMENT, "null handle");
-    if (d->l0_pending > 0 || d->pend_wout.nslabs > 0)
+    if (d->l0_pending > 0 || d->pend_wout.nslabs > 0 || d->pend_bh.nslabs > 0)
         return fail(XQ_ERR_RUNTIME, "xq_allreduce_grads: gradient slabs are still unreduced (xq_dqn_set_fused_apply is on)");
     return comm_allreduce_on(comm, d->grads_td, d->n_grads_td, d->stream);      // in order on the handle's stream
 }
@@ -2739,7 +2962,7 @@ int xq_dqn_apply_grads(xq_dqn* d, double lr, double grad_scale) {
     if (bf) t.dst_bf[k] = d->wl_bf(0, d->nl - 1);
     take(d->pend_wout); ++k;
     // hidden biases are contiguous in both layouts
-    t.dst[k] = d->bl(0, 0); t.src[k] = G + d->g_bh[0]; t.len[k] = (long long)(d->bo[d->nl - 1]); ++k;
+    t.dst[k] = d->bl(0, 0); t.src[k] = G + d->g_bh[0]; t.len[k] = (long long)(d->bo[d->nl - 1]); take(d->pend_bh); ++k;
     t.dst[k] = d->bl(0, d->nl - 1); t.src[k] = G + d->g_bout; t.len[k] = 96; take(d->pend_bout); ++k;
     t.nseg = k;
     return sgd_apply(d, t, lr * grad_scale);
@@ -2747,7 +2970,7 @@ int xq_dqn_apply_grads(xq_dqn* d, double lr, double grad_scale) {
 
 int xq_dqn_set_fused_apply(xq_dqn* d, int on) {
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
-    if (d->l0_pending > 0 || d->pend_wout.nslabs > 0)
+    if (d->l0_pending > 0 || d->pend_wout.nslabs > 0 || d->pend_bh.nslabs > 0)
         return fail(XQ_ERR_RUNTIME, "xq_dqn_set_fused_apply: a TD step is waiting for its apply_grads");
     d->fused_apply = on != 0;
     return XQ_OK;
@@ -2852,7 +3075,7 @@ int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_st
         d->prof.enabled = enable != 0;
         d->prof.roofline_only = enable == 3 || enable == 4;
         d->prof.sample_period = enable == 4 ? 4 : 1;
-        d->prof.sample_phase = 0;
+        d->prof.sample_phase = 0; d->prof.sample_phase_env = 0;
     }
     return XQ_OK;
 }

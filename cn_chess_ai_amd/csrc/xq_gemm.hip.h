@@ -323,23 +323,24 @@ __device__ __forceinline__ void epilogue_colmax(const GemmArgs& g, const f32x16 
     }
 }
 
+// One block of the product: tile (bx, by), k-slab / group bz; As / Bs = g_tile_floats(BM) / g_tile_floats(BN) floats of LDS.  The block
+// indices are arguments so that the same body serves gemm_f32_kernel and the fused launches of the TD step's tail (td_tail_kernel,
+// xq_dqn.hip), where blocks of several kernels share one grid.
 template <int AL, int BL, int EPI, int TM, int TN, int DT = DT_F32>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_f32_kernel(const GemmArgs g_in) {
+__device__ __forceinline__ void gemm_f32_block(const GemmArgs& g_in, int bx, int by, int bz, float* __restrict__ As, float* __restrict__ Bs) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     GemmArgs g = g_in;
-    if (g_in.grouped && blockIdx.z >= 1) {
-        const int k = (int)blockIdx.z - 1;
+    if (g_in.grouped && bz >= 1) {
+        const int k = bz - 1;
         g.A = g_in.Ax[k]; g.B = g_in.Bx[k]; g.C = g_in.Cx[k]; g.bias = g_in.biasx[k]; g.Cb = g_in.Cbx[k];
     }
-    __shared__ __attribute__((aligned(16))) float As[g_tile_floats(BM)];
-    __shared__ __attribute__((aligned(16))) float Bs[g_tile_floats(BN)];
 
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
-    const int m0 = (int)blockIdx.x * BM, n0 = (int)blockIdx.y * BN;
-    const int kbeg = g.grouped ? 0 : (int)blockIdx.z * g.k_chunk;
+    const int m0 = bx * BM, n0 = by * BN;
+    const int kbeg = g.grouped ? 0 : bz * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
 
     f32x16 acc[TM][TN];
@@ -358,10 +359,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
     // ---- epilogue.  32x32 accumulator map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ---------------
     if (EPI == EPI_COLMAX) {
-        epilogue_colmax<TM, TN>(g, acc, m0, n0, (int)blockIdx.x);
+        epilogue_colmax<TM, TN>(g, acc, m0, n0, bx);
         return;
     }
-    float* Cz = g.grouped ? g.C : g.C + (long long)blockIdx.z * g.slab_stride;
+    float* Cz = g.grouped ? g.C : g.C + (long long)bz * g.slab_stride;
     if (DT == DT_BF16 && EPI == EPI_BIAS_TANH) {
         // bf16 Q-net: a = bf16(tanh(acc + bias)); the bf16 bits feed the next layer's MFMA, the (optional) fp32 copy of the
         // SAME rounded value feeds the fp32 backward pass
@@ -473,6 +474,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 if (EPI == EPI_BIAS_TANH && g.Cb) g.Cb[g.cb_frag ? scr_afrag_index(m, n, g.N) : (long long)m * g.ldcb + n] = bf16_bits(v);
             }
         }
+}
+
+template <int AL, int BL, int EPI, int TM, int TN, int DT = DT_F32>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_f32_kernel(const GemmArgs g_in) {
+    __shared__ __attribute__((aligned(16))) float As[g_tile_floats(64 * TM)];
+    __shared__ __attribute__((aligned(16))) float Bs[g_tile_floats(64 * TN)];
+    gemm_f32_block<AL, BL, EPI, TM, TN, DT>(g_in, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, As, Bs);
 }
 
 // Persistent column-max GEMM for the dominant product (rows = output neurons, columns = samples, both operands

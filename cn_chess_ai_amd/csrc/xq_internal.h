@@ -84,6 +84,7 @@ struct Profiler {
     bool enabled = false;
     bool roofline_only = false;   // bracket only the two kernels bench.py prices (keeps the timed region undisturbed)
     int sample_period = 1;        // roofline_only: bracket every sample_period-th launch of a priced kernel (an event record drains
+    int sample_phase_env = 0;
     int sample_phase = 0;         // the recording queue: ~10 us per bracket on a stream of 10-50 us kernels, tools/sync_probe.hip)
     std::vector<Cat> cats;
     std::vector<Rec> recs;
@@ -102,7 +103,12 @@ struct Profiler {
         if (!enabled) return -1;
         if (roofline_only && strcmp(name, "gemm_qmax_rowmax") != 0 && strcmp(name, "gemm_qmax_screen") != 0 &&
             strcmp(name, "env_selfplay_step") != 0) return -1;
-        if (roofline_only && sample_period > 1 && strcmp(name, "env_selfplay_step") != 0 && (sample_phase++ % sample_period) != 0) return -1;
+        // (the env kernel on a counter and a period of its own, sample_period + 1: with 4 plies per update a shared counter would
+        // never pick the GEMM, and period 4 always the same ply)
+        if (roofline_only && sample_period > 1) {
+            const bool env = strcmp(name, "env_selfplay_step") == 0;
+            if (env ? (sample_phase_env++ % (sample_period + 1)) != 0 : (sample_phase++ % sample_period) != 0) return -1;
+        }
         Rec r; r.cat = cat_id(name); r.a = get_event(); r.b = get_event();
         (void)hipEventRecord(r.a, s);
         recs.push_back(r);

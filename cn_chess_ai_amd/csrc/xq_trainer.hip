@@ -26,6 +26,8 @@ struct xq_trainer {
     hipStream_t cstream = nullptr;          // collect stream
     hipEvent_t ev_params = nullptr;         // main: parameters of the next iteration are final (after learn_apply)
     hipEvent_t ev_collect = nullptr;        // cstream: the collects of this iteration are done
+    bool collect_event_stale = false;       // plies queued on cstream since ev_collect was last recorded (recorded when someone waits:
+                                            // a record per ply costs the collect stream ~6 us each, wait_collects())
     int inflight = 0;                       // ring slots written by collects since the last learn_apply
     bool grads_queued = false;              // learn_grads already queued in this iteration: collect starts behind its big GEMM
     int prepaid_collects = 0;               // collects learn_grads had to run itself (empty ring), owed to the next collect() calls
@@ -85,7 +87,13 @@ static int trainer_init(xq_trainer* t, const xq_trainer_config* cfg, void* hip_s
     if (cfg->overlap_collect) {
         int lo = 0, hi = 0;
         XQ_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));        // lo = least urgent: collect has slack until learn_apply,
-        XQ_HIP(hipStreamCreateWithPriority(&t->cstream, hipStreamNonBlocking, lo));   // the TD step is the critical path
+        // one ply per update: the TD step is the critical path, the select chain has slack until learn_apply => least urgent.
+        // Several plies per update: the plies ARE the critical path (each waits for the move of the one before, bench --config 4:
+        // 4 x 155 us alone, 375 + 314 us for the two that share the chip with the TD step) => most urgent: 1.096 -> 1.054 ms per step
+        const char* pe = getenv("XQ_COLLECT_PRIO");
+        int prio = cfg->collects_per_update > 1 ? hi : lo;
+        if (pe && pe[0] == 'h') prio = hi; else if (pe && pe[0] == 'l') prio = lo;
+        XQ_HIP(hipStreamCreateWithPriority(&t->cstream, hipStreamNonBlocking, prio));
         XQ_HIP(hipEventCreateWithFlags(&t->ev_params, hipEventDisableTiming));
         XQ_HIP(hipEventCreateWithFlags(&t->ev_collect, hipEventDisableTiming));
         XQ_HIP(hipEventCreateWithFlags(&t->ev_grads, hipEventDisableTiming));
@@ -115,6 +123,13 @@ int xq_trainer_destroy(xq_trainer* t) {
 int xq_trainer_env(xq_trainer* t, xq_env** e) { if (!t || !e) return fail(XQ_ERR_INVALID_ARGUMENT, "null"); *e = t->env; return XQ_OK; }
 int xq_trainer_dqn(xq_trainer* t, xq_dqn** d) { if (!t || !d) return fail(XQ_ERR_INVALID_ARGUMENT, "null"); *d = t->dqn; return XQ_OK; }
 int xq_trainer_replay(xq_trainer* t, xq_replay** r) { if (!t || !r) return fail(XQ_ERR_INVALID_ARGUMENT, "null"); *r = t->replay; return XQ_OK; }
+
+// the handle's stream waits for every ply queued on the collect stream so far
+static int wait_collects(xq_trainer* t) {
+    if (t->collect_event_stale) { XQ_HIP(hipEventRecord(t->ev_collect, t->cstream)); t->collect_event_stale = false; }
+    XQ_HIP(hipStreamWaitEvent(t->stream, t->ev_collect, 0));
+    return XQ_OK;
+}
 
 static int collect_impl(xq_trainer* t) {
     float* q90 = nullptr;
@@ -155,7 +170,7 @@ static int collect_impl(xq_trainer* t) {
     t->env_steps += (uint64_t)t->env->n;
     if (on) {
         t->inflight += t->env->n;
-        XQ_HIP(hipEventRecord(t->ev_collect, on));
+        t->collect_event_stale = true;
     }
     return XQ_OK;
 }
@@ -197,7 +212,7 @@ static int learn_grads_prioritized(xq_trainer* t) {
             for (int c = 0; c < plies; ++c) XQ_TRY(collect_impl(t));
             t->prepaid_collects = plies;
         }
-        if (t->cstream) { XQ_HIP(hipStreamWaitEvent(t->stream, t->ev_collect, 0)); t->inflight = 0; }
+        if (t->cstream) { XQ_TRY(wait_collects(t)); t->inflight = 0; }
         if (t->replay->size == 0) return fail(XQ_ERR_RUNTIME, "replay is empty");
         XQ_TRY(replay_per_rebuild(t->replay, 0, 0, t->stream));
         t->per_ready = true;
@@ -236,7 +251,7 @@ int xq_trainer_learn_grads(xq_trainer* t) {
                     for (int c = 0; c < plies; ++c) XQ_TRY(collect_impl(t));
                     t->prepaid_collects = plies;
                 }
-                XQ_HIP(hipStreamWaitEvent(t->stream, t->ev_collect, 0));
+                XQ_TRY(wait_collects(t));
                 t->inflight = 0;
                 start = 0; count = -1;
                 t->excluded = 0;
@@ -256,7 +271,7 @@ int xq_trainer_learn_apply(xq_trainer* t, int world_size) {
     if (!t || world_size < 1) return fail(XQ_ERR_INVALID_ARGUMENT, "bad argument");
     const int batch = t->cfg.replay_capacity > 0 ? t->cfg.minibatch : t->cfg.n_games;
     const double scale = t->cfg.mean_gradient ? 1.0 / ((double)batch * world_size) : 1.0;
-    if (t->cstream && t->inflight > 0) XQ_HIP(hipStreamWaitEvent(t->stream, t->ev_collect, 0));   // the select chain reads theta_t
+    if (t->cstream && t->inflight > 0) XQ_TRY(wait_collects(t));   // the select chain reads theta_t
     XQ_TRY(xq_dqn_apply_grads(t->dqn, t->cfg.learning_rate, scale));
     t->updates += 1;
     if (t->cfg.target_sync_interval > 0 && t->updates % (uint64_t)t->cfg.target_sync_interval == 0)

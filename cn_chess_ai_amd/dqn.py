@@ -186,6 +186,14 @@ def _set_l0_derive(self, on):
 DQN.set_l0_derive = _set_l0_derive
 
 
+def _set_td_tail(self, on):
+    """Gradient half of a TD step as fused launches on one stream (default) or kernel by kernel on two streams; same bits."""
+    call("xq_dqn_set_td_tail", self._h, 1 if on else 0)
+
+
+DQN.set_td_tail = _set_td_tail
+
+
 def _qmax_stats(self):
     """(TD steps screened, samples, candidate (sample, group) pairs, pairs re-evaluated as whole groups); synchronises."""
     st = (C.c_uint64 * 4)()

@@ -214,6 +214,13 @@ int xq_dqn_set_precision(xq_dqn* d, int precision);
  * now (two squares for a move; boards more than 8 squares apart are gathered in full): one gather instead of two, a DIFFERENT
  * summation order (differences ~1e-7 on the activations, far inside the 1e-4 budget on Q).  bench.py switches it on. */
 int xq_dqn_set_l0_derive(xq_dqn* d, int on);
+/* How the gradient half of xq_dqn_td_grads is queued (no upstream analogue: dqn.cu:323-467 launches one kernel per layer and waits
+ * for each).  1 (default): as fused launches on the handle's stream — per hidden layer below the top one ONE grid that holds the blocks
+ * of the delta product, of the weight-gradient product above it and (first time) of the output-layer sums, then ONE grid with the
+ * layer-0 sums and the bias column sums; taken when the net is fp32, its backward products fit 64 x 64 tiles, no communicator is
+ * attached and xq_dqn_set_fused_apply is on.  0, or any other case: the same kernels one by one on two streams (critical chain +
+ * side stream, three event records and a join).  Results are bitwise identical either way. */
+int xq_dqn_set_td_tail(xq_dqn* d, int on);
 /* XQ_QMAX_*: how the TD step finds max_a' Q(s',a').  XQ_QMAX_SCREENED applies to fp32 nets with XQ_TD_ONLINE_NET / XQ_TD_TARGET_NET
  * whose last hidden width is a multiple of 64 and whose product is large enough for the persistent GEMM (>= 512 tiles of 128 x 128);
  * every other case silently keeps the full fp32 product.  Guard: every 32 screened steps the candidate counters are read back

@@ -670,3 +670,39 @@ def test_screened_qmax_with_non_finite_weights(xq):
         assert (both_nan | (np.abs(y_full - y_scr) < 2e-6)).all(), bad
         assert np.isfinite(y_scr).mean() > 0.3
     env.close(); d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes,mode,n", [(REF_NET, 0, 700), (CFG2_NET, 0, 1100), (CFG2_NET, 1, 8192), ((1260, 512, 512, 512, 8100), 0, 1500),
+                                          ((1260, 64, 96, 200), 1, 333)])
+def test_td_tail_launches_equal_the_two_stream_path_bitwise(xq, sizes, mode, n):
+    """xq_dqn_set_td_tail: the gradient half of the TD step as fused launches on one stream (blocks of the delta product, the weight
+    gradients, the output-layer / layer-0 sums and the bias column sums in shared grids) against the same kernels launched one by
+    one on two streams — every block runs the same body on the same operands, so two updates leave bit-identical parameters.
+    Nets with one, two and three hidden layers, partial tiles (n not a multiple of 64), both backprop modes."""
+    env = xq.VecEnv(n, seed=5)
+    for _ in range(23):
+        env.selfplay_step(None)
+    S, _ = env.get_state()
+    res = env.selfplay_step(None)
+    S2, _ = env.get_state()
+    A = (res["action"] % 90).astype(np.int32)
+    R = (res["reward"] / 100.0).astype(np.float32)
+    D = res["done"].copy()
+    D[::9] = 1
+    out = {}
+    for tail in (True, False):
+        d, w, b = make_net(xq, sizes, seed=31)
+        d.set_fused_apply(True)                     # the fused launches leave their slabs to the SGD kernel
+        d.set_td_tail(tail)
+        for _ in range(2):
+            qsa, y = d.td_update(S, S2, A, R, D, td_net=0, mode=mode, learning_rate=0.05, grad_scale=1.0 / n)
+        out[tail] = (d.get_params(), qsa.copy(), y.copy())
+        d.close()
+    (w1, b1), q1, y1 = out[True]
+    (w0, b0), q0, y0 = out[False]
+    assert np.array_equal(q1, q0) and np.array_equal(y1, y0)
+    assert np.array_equal(w1, w0) and np.array_equal(b1, b0)
+    wi, bi = xo.init_weights(sizes, 31)
+    assert np.abs(w1 - wi).max() > 0                # ... and the updates did move the weights
+    env.close()
