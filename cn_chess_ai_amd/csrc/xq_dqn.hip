@@ -1431,16 +1431,22 @@ __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restri
     }
 }
 
-// Q head with the k range split over blocks (q_head): q[m][j] = tanh(b_j + ((s0 + s1) + (s2 + s3))[m][j]) over the four k-slabs of the
-// product (fixed association).  One thread per output.
-__global__ __launch_bounds__(256) void q_head_finish_kernel(const float* __restrict__ slabs, long long slab_stride, int n, int n_out, int lds_,
+// Q head with the k range split over blocks (q_head) or folded into the last hidden product (EPI_HEAD): q[m][j] = tanh(b_j + the sum of
+// the k-slabs of the product), slabs added four at a time as (s0 + s1) + (s2 + s3), the groups of four in ascending order (nslabs even).
+// One thread per output.
+__global__ __launch_bounds__(256) void q_head_finish_kernel(const float* __restrict__ slabs, long long slab_stride, int nslabs, int n, int n_out, int lds_,
                                                             const float* __restrict__ bias, float* __restrict__ q, int ldq) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)n * n_out) return;
     const int m = (int)(i / n_out), j = (int)(i % n_out);
     const float* p = slabs + (long long)m * lds_ + j;
-    const float s0 = p[0], s1 = p[slab_stride], s2 = p[2 * slab_stride], s3 = p[3 * slab_stride];
-    q[(long long)m * ldq + j] = tanhf(bias[j] + ((s0 + s1) + (s2 + s3)));
+    float s = 0.f;
+    for (int z = 0; z < nslabs; z += 4) {
+        float t = p[z * slab_stride] + p[(z + 1) * slab_stride];
+        if (z + 3 < nslabs) t += p[(z + 2) * slab_stride] + p[(z + 3) * slab_stride];
+        s = z == 0 ? t : s + t;
+    }
+    q[(long long)m * ldq + j] = tanhf(bias[j] + s);
 }
 
 // bf16 shadow of a weight range (set_params / load_model / set_precision)
@@ -1709,6 +1715,8 @@ struct ChainJob {
     uint32_t* gathered;
     uint16_t* last_bf;          // fp32 net: != nullptr => bf16 copy of the chain's LAST hidden activations (screening operand)
     bool last_bf_frag;          //   ... written in MFMA B-fragment order (scr_afrag_index) for screen_top2_kernel
+    float* head_slabs;          // fp32 net, one chain, >= 2 hidden layers: != nullptr => the select head's k-slabs [hlast / 64][n][96] come
+                                //   out of the last hidden product (EPI_HEAD); the last activations are stored only if outs[nl-2] != nullptr
 };
 // Up to three chains run in the same launches: one gather grid with blockIdx.y = chain, grouped GEMMs with blockIdx.z = chain.
 static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src, int n, const ShadowJob* shadow = nullptr) {
@@ -1784,6 +1792,18 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
             XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH, DT_BF16>(d, g, 1, "gemm_hidden_fwd")));
         } else {
             g.K = d->L[l]; g.lda = g.ldb = d->L[l]; g.ldc = d->L[l + 1]; g.ldcb = d->L[l + 1];
+            if (l == d->nl - 2 && njobs == 1 && jobs[0].head_slabs) {
+                if ((n & 63) || (g.N & 63) || (g.K & 31) || d->nout() < 128) return fail(XQ_ERR_RUNTIME, "select head cannot ride on this hidden product");
+                g.A = jobs[0].outs[l - 1]; g.B = d->wl(jobs[0].net, l); g.C = jobs[0].outs[l]; g.bias = d->bl(jobs[0].net, l);
+                g.a_vec = vec_ok(g.A, g.lda); g.b_vec = vec_ok(g.B, g.ldb); g.k_chunk = g.K;
+                g.head_W = d->wl(jobs[0].net, d->nl - 1); g.head_ldw = g.N;
+                g.head_slabs = jobs[0].head_slabs; g.head_slab_stride = (long long)n * 96; g.head_ld = 96;
+                if (!g.a_vec || !g.b_vec || !vec_ok(g.head_W, g.head_ldw)) return fail(XQ_ERR_RUNTIME, "select head: unaligned operand");
+                ProfScope ps(d, "gemm_hidden_fwd", 2.0 * n * g.N * (g.K + 96.0), 4.0 * ((double)n * g.K + (double)g.N * g.K + (double)(g.N / 64) * n * 96));
+                hipLaunchKernelGGL((gemm_f32_kernel<L_KCONTIG, L_KCONTIG, EPI_HEAD, 1, 1>), dim3(n / 64, g.N / 64, 1), dim3(256), 0, d->cur, g);
+                XQ_HIP(hipGetLastError());
+                continue;
+            }
             for (int k = 0; k < njobs; ++k) {
                 uint16_t* cb = (l == d->nl - 2) ? jobs[k].last_bf : nullptr;
                 if (cb && jobs[k].last_bf_frag) g.cb_frag = 1;
@@ -1818,9 +1838,12 @@ static int q_head(xq_dqn* d, int net, const float* a_last, int n, int n_out, flo
     // CU, each walking all K / 32 k-tiles behind one another with nothing to hide the load latency behind (20 us at K = 256, 32 us at
     // K = 512 for 0.4 / 0.8 GFLOP).  Four k-slabs per tile put four blocks on every CU; a one-thread-per-output kernel adds the slabs in a
     // fixed order, the bias and the tanh.  fp32 nets, large batches (the small ones are not latency-bound per CU to begin with).
+    // The slabs are 64 columns of the last hidden layer each — what the fused form (EPI_HEAD in chain_boards, dqn_q90_boards) produces
+    // per column tile, so both forms give the same bits.
     if (n_out <= 96 && n >= 2048 && (g.K % 128) == 0) {
         const int nc = round_up(n_out, 4);
-        const size_t need = (size_t)4 * n * nc;
+        const int nslabs = g.K / 64;
+        const size_t need = (size_t)nslabs * n * nc;
         float** slab = d->cur == d->stream ? &d->qh_slabs[0] : &d->qh_slabs[1];      // the select chain may run on its own stream beside a TD step
         size_t* cap = d->cur == d->stream ? &d->qh_cap[0] : &d->qh_cap[1];
         if (need > *cap) {
@@ -1830,9 +1853,9 @@ static int q_head(xq_dqn* d, int net, const float* a_last, int n, int n_out, flo
             *cap = need;
         }
         g.C = *slab; g.ldc = nc; g.slab_stride = (long long)n * nc;
-        XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_STORE>(d, g, 4, name, nullptr, true)));
+        XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_STORE>(d, g, nslabs, name, nullptr, true)));
         const long long total = (long long)n * n_out;
-        hipLaunchKernelGGL(q_head_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d->cur, *slab, g.slab_stride, n, n_out, nc,
+        hipLaunchKernelGGL(q_head_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d->cur, *slab, g.slab_stride, nslabs, n, n_out, nc,
                            g.bias, q, ldq);
         XQ_HIP(hipGetLastError());
         return XQ_OK;
@@ -1887,8 +1910,38 @@ int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev
         q = d->q90;
     }
     ChainJob job{XQ_NET_ONLINE, boards_dev, outs, outs_bf, nullptr};
-    int rc = chain_boards(d, &job, 1, explicit_slots(nullptr), n);
+    // fp32 net with >= 2 hidden layers, whole 64 x 64 tiles, the batch sizes q_head splits into k-slabs: the head rides on the last hidden
+    // product (same slabs, same bits) — its operand never goes to HBM and back (2 x 17 MB at 8192 x 512), one launch fewer per ply
+    const int Hl = d->hlast();
+    const bool ride = !bf && d->nl >= 3 && n >= 2048 && (n & 63) == 0 && (Hl % 128) == 0 && (d->L[d->nl - 2] & 31) == 0 && d->nout() >= 128 &&
+                      vec_ok(d->wl(XQ_NET_ONLINE, d->nl - 1), Hl) && vec_ok(d->wl(XQ_NET_ONLINE, d->nl - 2), d->L[d->nl - 2]);
+    int rc = XQ_OK;
+    if (ride) {
+        const int nslabs = Hl / 64;
+        const size_t need = (size_t)nslabs * n * 96;
+        float** slab = d->cur == d->stream ? &d->qh_slabs[0] : &d->qh_slabs[1];
+        size_t* cap = d->cur == d->stream ? &d->qh_cap[0] : &d->qh_cap[1];
+        if (need > *cap) {
+            XQ_HIP(hipDeviceSynchronize());
+            if (*slab) XQ_HIP(hipFree(*slab));
+            XQ_HIP(hipMalloc(slab, need * sizeof(float)));
+            *cap = need;
+        }
+        job.head_slabs = *slab;
+        float* keep = outs[d->nl - 2];
+        outs[d->nl - 2] = nullptr;                       // nobody else reads the select chain's last activations
+        rc = chain_boards(d, &job, 1, explicit_slots(nullptr), n);
+        outs[d->nl - 2] = keep;
+        if (rc == XQ_OK) {
+            ProfScope ps(d, "gemm_q90_select", (double)n * 96 * nslabs, 4.0 * n * 96 * (nslabs + 1));
+            hipLaunchKernelGGL(q_head_finish_kernel, dim3((unsigned)(((long long)n * 96 + 255) / 256)), dim3(256), 0, d->cur, *slab, (long long)n * 96,
+                               nslabs, n, 96, 96, d->bl(XQ_NET_ONLINE, d->nl - 1), q, 96);
+            if (hipGetLastError() != hipSuccess) rc = fail(XQ_ERR_RUNTIME, "q_head_finish_kernel launch failed");
+        }
+    } else {
+    rc = chain_boards(d, &job, 1, explicit_slots(nullptr), n);
     if (rc == XQ_OK) rc = q_head(d, XQ_NET_ONLINE, outs[d->nl - 2], n, 96, q, 96, "gemm_q90_select", bf ? outs_bf[d->nl - 2] : nullptr);
+    }
     d->cur = d->stream;
     d->small_tiles = false;
     XQ_TRY(rc);

@@ -49,7 +49,11 @@ __host__ __device__ __forceinline__ long long scr_afrag_index(int sample, int k,
 enum { L_KCONTIG = 0, L_MCONTIG = 1 };
 // EPI_COLMAX: per column n, max over the rows m of (acc + bias[m]) — the GEMM is launched "transposed" (rows = output
 // neurons, columns = samples) so that the reduction runs over accumulator REGISTERS of one lane, not across lanes.
-enum { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_COLMAX = 2, EPI_DELTA = 3 };
+// EPI_HEAD (fp32, 64x64 tiles, whole tiles only): EPI_BIAS_TANH of the last hidden layer with the select head folded in — the block's
+// fresh 64 x 64 activation tile goes straight on as the A operand of head_slabs[by][m][0..95] = a[m][64 by .. 64 by + 63] .
+// W_head[0..95][same columns]^T, one k-slab of the select head per column tile; q_head_finish_kernel adds the slabs, the bias and the
+// tanh.  The activations themselves are stored only when C != nullptr (the select chain has no other reader).
+enum { EPI_STORE = 0, EPI_BIAS_TANH = 1, EPI_COLMAX = 2, EPI_DELTA = 3, EPI_HEAD = 4 };
 
 constexpr int GBK = 32;
 constexpr int G_LDK = GBK + 4;    // 36: row stride of a k-contiguous LDS tile
@@ -79,6 +83,8 @@ struct GemmArgs {
     int bias_padded;              // EPI_COLMAX: bias[] is 16-byte aligned and readable up to the last tile's edge
     int prio_split;               // persistent kernel: blocks >= prio_split run at s_setprio 1 (0 = off) ...
     int prio_tiles;               // ... and own tiles [0, prio_tiles); the other blocks own [prio_tiles, total)
+    // EPI_HEAD: first 128 rows of the output layer's weights (row stride head_ldw = N), the slabs [N / 64][M][head_ld]
+    const float* head_W; long long head_ldw; float* head_slabs; long long head_slab_stride; int head_ld;
 };
 
 // ---- global -> register staging (4 x float4 per thread per operand) --------------------------------------------
@@ -362,6 +368,48 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g_in, int bx, int
         epilogue_colmax<TM, TN>(g, acc, m0, n0, bx);
         return;
     }
+    if (EPI == EPI_HEAD) {
+        // the two 32-deep k-tiles of the head product = the activation columns of the waves wn = 0 / wn = 1; the head's weight tiles
+        // (128 rows: 96 used) are requested before the tanh arithmetic, which hides their latency
+        float4 vb0[4], vb1[4];
+        stage_load<L_KCONTIG, 128, true>(g, g.head_W, g.head_ldw, 1, 0, 128, n0, n0 + 64, vb0);
+        stage_load<L_KCONTIG, 128, true>(g, g.head_W, g.head_ldw, 1, 0, 128, n0 + 32, n0 + 64, vb1);
+        const int n = n0 + wn * 32 + r;
+        const int mb = m0 + wm * 32 + 4 * h;
+        const float bias = g.bias[n];
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            v[q] = tanhf(acc[0][0][q] + bias);
+            if (g.C) g.C[(long long)(mb + (q & 3) + 8 * (q >> 2)) * g.ldc + n] = v[q];
+        }
+        f32x16 hacc[1][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) hacc[0][j][q] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            __syncthreads();                                       // the previous tile (main loop / kt = 0) fully consumed
+            if (wn == kt) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) As[(wm * 32 + 4 * h + (q & 3) + 8 * (q >> 2)) * G_LDK + r] = v[q];
+            }
+            stage_store<L_KCONTIG, 128>(Bs, kt == 0 ? vb0 : vb1);
+            __syncthreads();
+            tile_mma<L_KCONTIG, L_KCONTIG, 64, 128, 1, 2>(As, Bs, wm, wn, r, h, hacc);
+        }
+        float* slab = g.head_slabs + (long long)by * g.head_slab_stride;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wn * 64 + j * 32 + r;
+            if (col < g.head_ld) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) slab[(long long)(mb + (q & 3) + 8 * (q >> 2)) * g.head_ld + col] = hacc[0][j][q];
+            }
+        }
+        return;
+    }
     float* Cz = g.grouped ? g.C : g.C + (long long)bz * g.slab_stride;
     if (DT == DT_BF16 && EPI == EPI_BIAS_TANH) {
         // bf16 Q-net: a = bf16(tanh(acc + bias)); the bf16 bits feed the next layer's MFMA, the (optional) fp32 copy of the
@@ -479,7 +527,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g_in, int bx, int
 template <int AL, int BL, int EPI, int TM, int TN, int DT = DT_F32>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_f32_kernel(const GemmArgs g_in) {
     __shared__ __attribute__((aligned(16))) float As[g_tile_floats(64 * TM)];
-    __shared__ __attribute__((aligned(16))) float Bs[g_tile_floats(64 * TN)];
+    __shared__ __attribute__((aligned(16))) float Bs[g_tile_floats(EPI == EPI_HEAD ? 128 : 64 * TN)];     // EPI_HEAD: 128 head rows x 32
     gemm_f32_block<AL, BL, EPI, TM, TN, DT>(g_in, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, As, Bs);
 }
 

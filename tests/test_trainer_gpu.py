@@ -325,3 +325,48 @@ def test_screened_qmax_in_the_overlapped_trainer(xq):
     w_f, b_f, st_f, c_f, loss_f = run(_capi.QMAX_FULL)
     assert st_f[0] == 0 and c_f == c
     assert np.abs(w_s - w_f).max() < 1e-7 and np.abs(b_s - b_f).max() < 1e-7 and abs(loss_s - loss_f) < 1e-4 * abs(loss_f)
+
+
+@pytest.mark.parametrize("sizes", [CFG2_NET, (1260, 512, 512, 512, 8100)])
+def test_select_head_riding_on_the_last_hidden_product(xq, sizes):
+    """From 2048 games on, the trainer's select chain (dqn_q90_boards) takes Q[0..95] out of the last hidden product itself (EPI_HEAD:
+    one k-slab of the head per 64-column tile, q_head_finish_kernel adds them) — the stand-alone head (xq_dqn_forward_boards_dev,
+    k-slabs of the same 64 columns) must give the same bits: the two loops then play the same moves and learn the same weights.
+    The stand-alone head against the oracle on a few boards."""
+    n, iters, seed = 2048, 3, 77
+    cfg = xq.TrainerConfig(n_games=n, layer_sizes=sizes, learning_rate=0.01, gamma=0.99, epsilon=0.1, replay_capacity=4 * n,
+                           minibatch=n, td_net=0, backprop_mode=0, target_sync_interval=0, mean_gradient=1, seed=seed, first_game_id=0)
+    t = xq.Trainer(cfg)
+    w0, b0 = t.dqn.get_params()
+    t.random_plies(20)
+    tb0, tm0 = t.env.get_state()
+    t.step(iters)
+    tw, tb = t.dqn.get_params()
+    tboards, tmeta = t.env.get_state()
+
+    env = xq.VecEnv(n, seed=seed, first_game_id=0)
+    for _ in range(20):
+        env.selfplay_step_dev(0, 96, 0.1)
+    b_, m_ = env.get_state()
+    assert np.array_equal(b_, tb0) and np.array_equal(m_, tm0)
+    d = xq.DQN(sizes, 0.01, 0.99, seed=1)
+    d.set_params(w0, b0); d.updateTargetNetwork()
+    rp = xq.ReplayBuffer(4 * n, seed=seed + 0x1234567)
+    import torch
+    for it in range(iters):
+        q = d.q_boards(env, 96)
+        if it == 0:
+            qh = q.cpu().numpy()
+            for i in range(0, n, 257):
+                want = xo.nn_forward(sizes, w0, b0, xo.state_repr(xo.board_from(b_[i])))[:96]
+                assert np.abs(qh[i] - want).max() < 2e-5
+        env.selfplay_step_dev(q.data_ptr(), 96, 0.1, replay=rp)
+        torch.cuda.synchronize()
+        rp.sample(n)
+        d.td_grads_replay(rp, n, td_net=0, mode=0)
+        d.apply_grads(0.01, 1.0 / n)
+    w, b = d.get_params()
+    boards, meta = env.get_state()
+    assert np.array_equal(boards, tboards) and np.array_equal(meta, tmeta)
+    assert np.array_equal(w, tw) and np.array_equal(b, tb)
+    t.close(); env.close(); d.close(); rp.close()
