@@ -1890,8 +1890,9 @@ static int ensure_select_capacity_bf(xq_dqn* d, int n) {
 
 // Q(s)[0..95] of n packed boards on the online net.  `on` != nullptr queues the chain on that stream with its own
 // workspace and 64x64 tiles, so it can run concurrently with a TD step queued on the handle's stream.
-int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride, hipStream_t on) {
+int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride, hipStream_t on, QSource* qs) {
     if (d->nout() < 96) return fail(XQ_ERR_INVALID_ARGUMENT, "self-play select needs >= 96 outputs");
+    if (qs) memset(qs, 0, sizeof *qs);
     float* outs[XQ_MAX_LAYERS];
     uint16_t* outs_bf[XQ_MAX_LAYERS] = {nullptr};
     float* q = nullptr;
@@ -1932,7 +1933,10 @@ int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev
         outs[d->nl - 2] = nullptr;                       // nobody else reads the select chain's last activations
         rc = chain_boards(d, &job, 1, explicit_slots(nullptr), n);
         outs[d->nl - 2] = keep;
-        if (rc == XQ_OK) {
+        if (rc == XQ_OK && qs) {                         // the env kernel finishes the values it needs itself
+            qs->slabs = *slab; qs->slab_stride = (long long)n * 96; qs->nslabs = nslabs; qs->bias = d->bl(XQ_NET_ONLINE, d->nl - 1);
+            q = nullptr;
+        } else if (rc == XQ_OK) {
             ProfScope ps(d, "gemm_q90_select", (double)n * 96 * nslabs, 4.0 * n * 96 * (nslabs + 1));
             hipLaunchKernelGGL(q_head_finish_kernel, dim3((unsigned)(((long long)n * 96 + 255) / 256)), dim3(256), 0, d->cur, *slab, (long long)n * 96,
                                nslabs, n, 96, 96, d->bl(XQ_NET_ONLINE, d->nl - 1), q, 96);
@@ -2808,6 +2812,9 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_BF16, CM_TOP2>), dim3(grid), dim3(256), bias_lds_all, d->cur, g, tiles_m, total);
             XQ_HIP(hipGetLastError());
         }
+        // (the select chain of the trainer starts here.  Behind the refine kernel instead — which would then have the chip to itself,
+        // 17 instead of 27-34 us — the select chain ends after the gradients and the step waits for it: 0.197 -> 0.207 ms; in front of
+        // the screening pass: no difference)
         XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
         {
             ProfScope ps(d, "qmax_refine", 2.0 * n * Hl * 3, 12.0 * G * n + 4.0 * n * Hl);

@@ -29,6 +29,9 @@ struct EnvParams {
     // MODE_SELFPLAY
     const float* q90;
     int q_stride;
+    // ... or the k-slabs of the select head as the Q-net left them (QSource, xq_internal.h): q[j] = tanh(bias[j] + slabs summed in the
+    // order of q_head_finish_kernel) — the kernel that would do exactly this for all 96 x n values is then not launched
+    const float* q_slabs; long long q_slab_stride; int q_nslabs; const float* q_bias;
     uint32_t eps_u32, seed_lo, seed_hi, first_game_id;
     xq_step_result* results;
     // replay ring (optional)
@@ -103,14 +106,30 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
         wave_sync();
         if (n_moves > 0) {
             const Philox4 r = philox4x32_10(plies, 0u, P.first_game_id + (uint32_t)g, 0u, P.seed_lo, P.seed_hi);
-            explored = (P.q90 == nullptr) || (r.v[0] < P.eps_u32); // dqn.cpp:30-31
+            const bool have_q = P.q90 != nullptr || P.q_slabs != nullptr;
+            explored = !have_q || (r.v[0] < P.eps_u32);             // dqn.cpp:30-31
             int idx;
             if (explored) {
                 idx = (int)(r.v[1] % (uint32_t)n_moves);            // dqn.cpp:33
             } else {
+                if (P.q_slabs != nullptr) {
+                    auto q_of = [&](int j) {
+                        const float* p = P.q_slabs + (size_t)g * 96 + j;
+                        float sum = 0.f;
+                        for (int z = 0; z < P.q_nslabs; z += 4) {                    // q_head_finish_kernel's association
+                            float t = p[z * P.q_slab_stride] + p[(z + 1) * P.q_slab_stride];
+                            if (z + 3 < P.q_nslabs) t += p[(z + 2) * P.q_slab_stride] + p[(z + 3) * P.q_slab_stride];
+                            sum = z == 0 ? t : sum + t;
+                        }
+                        return tanhf(P.q_bias[j] + sum);
+                    };
+                    S.q[lane] = q_of(lane);
+                    if (lane < 26) S.q[64 + lane] = q_of(64 + lane);
+                } else {
                 const float* qrow = P.q90 + (size_t)g * P.q_stride; // dqn.cpp:37
                 S.q[lane] = qrow[lane];
                 if (lane < 26) S.q[64 + lane] = qrow[64 + lane];
+                }
                 wave_sync();
                 const float NEG = -__builtin_inff();
                 float v0 = NEG, v1 = NEG;
@@ -232,12 +251,13 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
         }
     }
 
-    if ((captured != 0 || ended_now || (explored && P.q90 != nullptr)) && lane == 0) {
+    const bool policy_q = P.q90 != nullptr || P.q_slabs != nullptr;
+    if ((captured != 0 || ended_now || (explored && policy_q)) && lane == 0) {
         uint4 s = P.stats[g];
         if (ended_now && winner == C_RED) s.x += 1;
         if (ended_now && winner == C_BLACK) s.y += 1;
         if (captured != 0) s.z += 1;
-        if (explored && P.q90 != nullptr) s.w += 1;
+        if (explored && policy_q) s.w += 1;
         P.stats[g] = s;
     }
 
@@ -352,10 +372,14 @@ static EnvParams base_params(xq_env* e) {
 }
 
 int env_selfplay_launch(xq_env* e, const float* q90_dev, int q_stride, uint32_t eps_u32, xq_step_result* results_dev,
-                        xq_replay* replay, hipStream_t on) {
+                        xq_replay* replay, hipStream_t on, const QSource* qs) {
     EnvParams P = base_params(e);
     P.q90 = q90_dev;
     P.q_stride = q_stride;
+    if (qs && qs->slabs) {
+        if (qs->nslabs < 2 || (qs->nslabs & 1)) return fail(XQ_ERR_INVALID_ARGUMENT, "select head slabs: even count >= 2");
+        P.q90 = nullptr; P.q_slabs = qs->slabs; P.q_slab_stride = qs->slab_stride; P.q_nslabs = qs->nslabs; P.q_bias = qs->bias;
+    }
     P.eps_u32 = eps_u32;
     P.results = results_dev;
     if (replay != nullptr) {

@@ -149,7 +149,12 @@ int comm_world(const xq_comm* c);
 Profiler* dqn_profiler(xq_dqn* d);
 xq_comm* dqn_comm(const xq_dqn* d);         // communicator attached with xq_dqn_set_comm, or nullptr
 int dqn_fused_apply(const xq_dqn* d);      // current xq_dqn_set_fused_apply setting
-int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride, hipStream_t on = nullptr);
+// Q[0..95] of the select chain still as the k-slabs of the head ([nslabs][n][96], nslabs even): the env kernel adds them, the bias and
+// the tanh itself, for the boards that exploit (dqn_q90_boards fills it when the head rode on the last hidden product)
+struct QSource { const float* slabs; long long slab_stride; int nslabs; const float* bias; };
+// qs != nullptr: when the select head rides on the last hidden product, its k-slabs are handed over as they are (qs->slabs != nullptr,
+// *q90_dev = nullptr) for the env kernel to finish; otherwise qs->slabs = nullptr and *q90_dev holds the finished values as always
+int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride, hipStream_t on = nullptr, QSource* qs = nullptr);
 hipStream_t dqn_stream(xq_dqn* d);
 hipEvent_t dqn_qmax_event(xq_dqn* d);      // recorded behind the column-max GEMM of the last xq_dqn_td_grads*
 
@@ -164,6 +169,6 @@ int replay_per_sample(xq_replay* r, int batch, hipStream_t on);
 
 // env-side launchers used by the trainer
 int env_selfplay_launch(xq_env* env, const float* q90_dev, int q_stride, uint32_t eps_u32, xq_step_result* results_dev,
-                        xq_replay* replay, hipStream_t on = nullptr);
+                        xq_replay* replay, hipStream_t on = nullptr, const QSource* qs = nullptr);
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 }  // namespace xq

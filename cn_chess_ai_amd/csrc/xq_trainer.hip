@@ -157,14 +157,15 @@ static int collect_impl(xq_trainer* t) {
         }
     }
     hipStream_t s = on ? on : t->stream;
-    XQ_TRY(dqn_q90_boards(t->dqn, t->env->boards, t->env->n, &q90, &stride, on));
+    QSource qs;
+    XQ_TRY(dqn_q90_boards(t->dqn, t->env->boards, t->env->n, &q90, &stride, on, &qs));
     if (t->cfg.replay_capacity == 0) {           // on-policy: the ring is exactly one batch, refilled every ply
         t->replay->write_pos = 0;
         t->replay->size = 0;
     }
     Profiler* p = dqn_profiler(t->dqn);
     const int h = p->begin("env_selfplay_step", s);
-    XQ_TRY(env_selfplay_launch(t->env, q90, stride, t->eps_u32, nullptr, t->replay, on));
+    XQ_TRY(env_selfplay_launch(t->env, q90, stride, t->eps_u32, nullptr, t->replay, on, &qs));
     // algorithmic HBM bytes per game and ply: board+meta in/out (2*(48+16)), Q row 360, transition 48+48+4+4+1
     p->end(h, s, 0.0, (double)t->env->n * (2.0 * (48 + 16) + 360 + 105));
     t->env_steps += (uint64_t)t->env->n;
