@@ -1330,13 +1330,26 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
 // ranges that reach it are looked at (usually one: the kernel reads ~1/10 of the partial arrays, and no activation rows for the norm).
 // ||a|| <= ||bf16(a)|| (1 + 2^-7): inside the slack of kScreenEps (2^-7 * 0.0625 - 2^-12 - 2^-16 = 2.3e-4 against 6.1e-5 + the fp32
 // rounding of the sum of squares).  Same block shape, candidate lists and fp32 re-evaluation as qmax_refine_kernel.
-template <int KFIX>
+// TD: the work of td_delta_kernel (its fp32, 256-wide fast path: same loads, same arithmetic, same bits) for the block's 32 samples —
+// wave w owns samples 8w .. 8w+7.  Everything that does not depend on the maximum (action, reward, Q(s,a) = the dot of two 1-KB rows) is
+// requested at the very top and lands under the refine phases; once the block's maxima exist the targets, the scalar deltas and the top
+// hidden deltas follow.  One launch and ~10 us of exposed latency chain fewer on the step's critical stream.
+struct TdFused {
+    SlotSrc src;
+    const int32_t* action_to; const float* reward; const uint8_t* done;
+    const float* a_s;              // last hidden activations of s on the online net [n][256]
+    const float* w_out; const float* b_out;
+    const float* view; long long view_ld; int view_kmax;
+    float gamma;
+    float* dtop; float* dsc; int32_t* act; float* qsa; float* yv; float* lossv;
+};
+template <int KFIX, bool TD = false>
 __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restrict__ R, int ranges, int gpr /* groups per range */,
                                                            const float* __restrict__ P1, const float* __restrict__ P2, int G, int n, long long ldp,
                                                            const float* __restrict__ na_all, const float* __restrict__ a_last, int K,
                                                            const float* __restrict__ W, const float* __restrict__ bias, int NO,
                                                            unsigned* __restrict__ wm, int parity, float* __restrict__ zmax,
-                                                           unsigned long long* __restrict__ stats) {
+                                                           unsigned long long* __restrict__ stats, const TdFused T) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cand[];            // [G * 32]: sample | row << 5
     uint16_t* wlist = reinterpret_cast<uint16_t*>(cand + (size_t)G * kRefineSamples);    // [G * 32]: sample | group << 5
     __shared__ float sv[8][32];
@@ -1352,6 +1365,30 @@ __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restri
     const int bc = min(b, n - 1);
     if (tid == 0) { cnt = 0; nexp = 0; if (blockIdx.x == 0) { wm[parity ^ 1] = 0u; wm[2 + (parity ^ 1)] = 0u; } }   // next step's slots
     if (tid < 32) best[tid] = (int)0x80000000;
+    // TD: lanes 0..7 of each wave hold action / reward / done / output bias of the wave's eight samples; zq[i] = Q(s,a) before the tanh
+    const int td_lane = tid & 63, td_w = tid >> 6;
+    int td_a = -1; float td_r = 0.f, td_bo = 0.f; bool td_dn = false;
+    float zq[8];
+    if (TD) {
+        static_assert(!TD || KFIX == 256, "fused TD delta: 256-wide last hidden layer");
+        if (td_lane < 8) {
+            const int bb = min(b0 + td_w * 8 + td_lane, n - 1);
+            const int sslot = slot_of(T.src, bb);
+            td_a = T.action_to[sslot];
+            td_r = T.reward[sslot];
+            td_dn = T.done[sslot] != 0;
+            td_bo = T.b_out[(td_a >= 0 && td_a < 96) ? td_a : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int bb = min(b0 + td_w * 8 + i, n - 1);
+            const int a = __shfl(td_a, i, 64);
+            const int ac = (a >= 0 && a < 96) ? a : 0;
+            const float4 av = *reinterpret_cast<const float4*>(T.a_s + (long long)bb * 256 + td_lane * 4);
+            const float4 wv = *reinterpret_cast<const float4*>(T.w_out + (long long)ac * 256 + td_lane * 4);
+            zq[i] = (av.x * wv.x + av.y * wv.y) + (av.z * wv.z + av.w * wv.w);
+        }
+    }
     float m = kColmaxPadBias;
     for (int r = phase; r < ranges; r += 8) m = fmaxf(m, R[(long long)r * ldp + bc]);
     sv[phase][sl] = m;
@@ -1428,6 +1465,50 @@ __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restri
     if (tid == 0) {
         atomicAdd(&stats[2], (unsigned long long)(singles + wholes));
         atomicAdd(&stats[3], (unsigned long long)wholes);
+    }
+    if (TD) {
+        // the rows for the top hidden delta (L2-hot: read a moment ago / shared by every sample with the same action), all in flight
+        float4 av[8], vv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int bb = min(b0 + td_w * 8 + i, n - 1);
+            const int a = __shfl(td_a, i, 64);
+            const bool has_view = a >= 0 && a < 96 && a < T.view_kmax;
+            av[i] = *reinterpret_cast<const float4*>(T.a_s + (long long)bb * 256 + td_lane * 4);
+            vv[i] = has_view ? *reinterpret_cast<const float4*>(T.view + (long long)a * T.view_ld + td_lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int bb = b0 + td_w * 8 + i;
+            const int a = __shfl(td_a, i, 64);
+            const float r = __shfl(td_r, i, 64), bo = __shfl(td_bo, i, 64);
+            const bool dn = __shfl((int)td_dn, i, 64) != 0;
+            const bool live = a >= 0 && a < 96;
+            float z = zq[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+            const float zm = float_from_key(best[td_w * 8 + i]);
+            float q = 0.f, y = 0.f, delta = 0.f;
+            if (live) {
+                q = tanhf(z + bo);
+                y = dn ? r : r + T.gamma * tanhf(zm);
+                delta = (q - y) * (1.f - q * q) * 1.f;
+            }
+            if (bb < n) {                                         // wave-uniform
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live && a < T.view_kmax) {
+                    o.x = delta * vv[i].x * (1.f - av[i].x * av[i].x); o.y = delta * vv[i].y * (1.f - av[i].y * av[i].y);
+                    o.z = delta * vv[i].z * (1.f - av[i].z * av[i].z); o.w = delta * vv[i].w * (1.f - av[i].w * av[i].w);
+                }
+                *reinterpret_cast<float4*>(T.dtop + (long long)bb * 256 + td_lane * 4) = o;
+                if (td_lane == 0) {
+                    T.dsc[bb] = delta;
+                    T.act[bb] = live ? a : -1;
+                    T.qsa[bb] = q; T.yv[bb] = y;
+                    T.lossv[bb] = live ? 0.5f * (q - y) * (q - y) : 0.f;
+                }
+            }
+        }
     }
 }
 
@@ -2724,6 +2805,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     const bool want_screen = d->qmax_mode == XQ_QMAX_SCREENED && !bf && !dbl && big_tiles && (Hl % 64) == 0 && Hl <= 1024 &&
                           bias_lds_all <= 40 * 1024 && (NO + 127) / 128 * 4 <= 8 * kRefineMaxPerThread;
     bool screened = want_screen;
+    bool td_fused = false;             // td_delta_kernel's work done inside the refine kernel (below)
     if (screened) {
         XQ_TRY(ensure_screen_capacity(d, n));
         // the counters queued at one check boundary are evaluated at the NEXT one (32 screened steps later: the copy finished long
@@ -2826,11 +2908,25 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             };
             const bool small = G <= 8 * 32;
             if (scr_new) {
+                TdFused T; memset(&T, 0, sizeof T);
+                // the TD target / delta kernel rides in the refine blocks (fp32 net, 256-wide last hidden layer, uniform replay)
+                td_fused = d->td_tail && Hl == 256 && !per && !d->bf16_bwd();
+                if (td_fused) {
+                    const int lt = nl - 2;
+                    T.src = slots; T.action_to = action_to; T.reward = reward; T.done = done;
+                    T.a_s = outs[lt]; T.w_out = d->wl(XQ_NET_ONLINE, nl - 1); T.b_out = d->bl(XQ_NET_ONLINE, nl - 1);
+                    T.view = d->wrest(XQ_NET_ONLINE) + (d->wo[lt + 1] - d->wo[1]);
+                    T.view_ld = (mode == XQ_BACKPROP_REFERENCE) ? d->L[lt] : d->L[lt + 1];
+                    T.view_kmax = (mode == XQ_BACKPROP_REFERENCE) ? d->L[lt + 1] : NO;
+                    T.gamma = (float)d->gamma;
+                    T.dtop = d->deltas[lt]; T.dsc = d->dsc; T.act = d->act_mb; T.qsa = d->qsa; T.yv = d->yv; T.lossv = d->lossv;
+                }
                 auto launch2 = [&](auto kern) {
                     hipLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, d->scr_R, scr_ranges, scr_gpr, d->scr_p1, d->scr_p2, G, n, ldp, d->scr_na,
-                                       touts[nl - 2], Hl, d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, d->scr_wmax, parity, d->zmax, d->scr_stats);
+                                       touts[nl - 2], Hl, d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, d->scr_wmax, parity, d->zmax, d->scr_stats, T);
                 };
-                if (Hl == 256) launch2(qmax_refine2_kernel<256>); else launch2(qmax_refine2_kernel<512>);
+                if (td_fused) launch2(qmax_refine2_kernel<256, true>);
+                else if (Hl == 256) launch2(qmax_refine2_kernel<256>); else launch2(qmax_refine2_kernel<512>);
             } else
             if (Hl == 256) { if (small) launch(qmax_refine_kernel<256, 32>); else launch(qmax_refine_kernel<256, 64>); }
             else if (Hl == 512) { if (small) launch(qmax_refine_kernel<512, 32>); else launch(qmax_refine_kernel<512, 64>); }
@@ -2920,7 +3016,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     }
     }   // !screened
     // 3. Q(s, a), target, the scalar output delta and the delta of the last hidden layer (one launch, no GEMM)
-    {
+    if (!td_fused) {
         const int lt = nl - 2;                               // last hidden layer
         const float* view = d->wrest(XQ_NET_ONLINE) + (d->wo[lt + 1] - d->wo[1]);
         const long long view_ld = (mode == XQ_BACKPROP_REFERENCE) ? d->L[lt] : d->L[lt + 1];

@@ -219,7 +219,10 @@ int xq_dqn_set_l0_derive(xq_dqn* d, int on);
  * of the delta product, of the weight-gradient product above it and (first time) of the output-layer sums, then ONE grid with the
  * layer-0 sums and the bias column sums; taken when the net is fp32, its backward products fit 64 x 64 tiles, no communicator is
  * attached and xq_dqn_set_fused_apply is on.  0, or any other case: the same kernels one by one on two streams (critical chain +
- * side stream, three event records and a join).  Results are bitwise identical either way. */
+ * side stream, three event records and a join).  The same switch covers the other fusion of the step's second half: with exact
+ * screening on a net whose last hidden layer is 256 wide (uniform replay), the TD target / output delta / top hidden delta are
+ * computed inside the blocks of the kernel that re-evaluates the screened maxima instead of by a launch of their own.
+ * Results are bitwise identical either way. */
 int xq_dqn_set_td_tail(xq_dqn* d, int on);
 /* XQ_QMAX_*: how the TD step finds max_a' Q(s',a').  XQ_QMAX_SCREENED applies to fp32 nets with XQ_TD_ONLINE_NET / XQ_TD_TARGET_NET
  * whose last hidden width is a multiple of 64 and whose product is large enough for the persistent GEMM (>= 512 tiles of 128 x 128);

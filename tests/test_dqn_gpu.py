@@ -673,13 +673,16 @@ def test_screened_qmax_with_non_finite_weights(xq):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sizes,mode,n", [(REF_NET, 0, 700), (CFG2_NET, 0, 1100), (CFG2_NET, 1, 8192), ((1260, 512, 512, 512, 8100), 0, 1500),
-                                          ((1260, 64, 96, 200), 1, 333)])
-def test_td_tail_launches_equal_the_two_stream_path_bitwise(xq, sizes, mode, n):
+@pytest.mark.parametrize("sizes,mode,n,screened", [(REF_NET, 0, 700, False), (CFG2_NET, 0, 1100, False), (CFG2_NET, 1, 8192, False),
+                                                   ((1260, 512, 512, 512, 8100), 0, 1500, False), ((1260, 64, 96, 200), 1, 333, False),
+                                                   (CFG2_NET, 0, 1100, True), (CFG2_NET, 1, 8192, True), ((1260, 512, 512, 512, 8100), 0, 1500, True)])
+def test_td_tail_launches_equal_the_two_stream_path_bitwise(xq, sizes, mode, n, screened):
     """xq_dqn_set_td_tail: the gradient half of the TD step as fused launches on one stream (blocks of the delta product, the weight
     gradients, the output-layer / layer-0 sums and the bias column sums in shared grids) against the same kernels launched one by
     one on two streams — every block runs the same body on the same operands, so two updates leave bit-identical parameters.
-    Nets with one, two and three hidden layers, partial tiles (n not a multiple of 64), both backprop modes."""
+    Nets with one, two and three hidden layers, partial tiles (n not a multiple of 64), both backprop modes.  With exact screening
+    the same switch also moves the TD target / delta arithmetic into the refine kernel's blocks (256-wide last hidden layer)."""
+    from cn_chess_ai_amd import _capi
     env = xq.VecEnv(n, seed=5)
     for _ in range(23):
         env.selfplay_step(None)
@@ -695,6 +698,7 @@ def test_td_tail_launches_equal_the_two_stream_path_bitwise(xq, sizes, mode, n):
         d, w, b = make_net(xq, sizes, seed=31)
         d.set_fused_apply(True)                     # the fused launches leave their slabs to the SGD kernel
         d.set_td_tail(tail)
+        d.set_qmax_mode(_capi.QMAX_SCREENED if screened else _capi.QMAX_FULL)
         for _ in range(2):
             qsa, y = d.td_update(S, S2, A, R, D, td_net=0, mode=mode, learning_rate=0.05, grad_scale=1.0 / n)
         out[tail] = (d.get_params(), qsa.copy(), y.copy())
