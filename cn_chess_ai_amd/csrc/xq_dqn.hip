@@ -2748,8 +2748,7 @@ static int tail_gradients(xq_dqn* d, int n, float* const* outs, float* G, int mo
     // two hidden layers: the one weight-gradient product runs beside the layer-0 sums (L2-bound) rather than beside the delta product
     // (both MFMA-bound, and the select chain's Q head is on the chip at that time): 0.2065 against 0.2086 ms per step of the headline
     // bench; three hidden layers (bench --config 4): no difference, kept beside the delta products
-    const char* dg = getenv("XQ_TAIL_DEFER_GRAD");
-    const bool defer_grad = dg ? dg[0] == '1' : nl == 3;
+    const bool defer_grad = nl == 3;
     int waiting = -1;
     for (int l = nl - 3; l >= 0; --l) {
         tail_begin(d);

@@ -90,9 +90,8 @@ static int trainer_init(xq_trainer* t, const xq_trainer_config* cfg, void* hip_s
         // one ply per update: the TD step is the critical path, the select chain has slack until learn_apply => least urgent.
         // Several plies per update: the plies ARE the critical path (each waits for the move of the one before, bench --config 4:
         // 4 x 155 us alone, 375 + 314 us for the two that share the chip with the TD step) => most urgent: 1.096 -> 1.054 ms per step
-        const char* pe = getenv("XQ_COLLECT_PRIO");
-        int prio = cfg->collects_per_update > 1 ? hi : lo;
-        if (pe && pe[0] == 'h') prio = hi; else if (pe && pe[0] == 'l') prio = lo;
+        // (one ply per update with the select chain most urgent: no difference on the headline bench, -0.5 % on bench --config 5)
+        const int prio = cfg->collects_per_update > 1 ? hi : lo;
         XQ_HIP(hipStreamCreateWithPriority(&t->cstream, hipStreamNonBlocking, prio));
         XQ_HIP(hipEventCreateWithFlags(&t->ev_params, hipEventDisableTiming));
         XQ_HIP(hipEventCreateWithFlags(&t->ev_collect, hipEventDisableTiming));
