@@ -39,11 +39,12 @@ def mfma_cycles(kernel):
     return 64.0
 
 
-def main(tag):
+def main(tag, dst=None):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     if not os.path.isdir(src):
         raise SystemExit(f"no {src}")
-    dst = os.path.join(ROOT, "profiles")
+    dst = dst or os.path.join(ROOT, "profiles")     # on the GPU box: a directory under gpurun_out/ (the raw traces exceed what travels back)
+    os.makedirs(dst, exist_ok=True)
     stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
@@ -77,9 +78,9 @@ def main(tag):
                 v["derived"]["lds_instructions_per_mfma"] = q["SQ_INSTS_LDS"] / mf
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
     for k, v in out.items():
-        if "gemm_colmax" in k or "env_kernel<2>" in k or "l0_grad" in k or "screen_top2" in k or "gemm_dma" in k:
+        if "gemm_colmax" in k or "env_kernel<2>" in k or "l0_grad" in k or "td_tail" in k or "screen_top2" in k or "gemm_dma" in k:
             print(k[:70], {a: round(b) for a, b in v.items() if a not in ("sq", "derived")}, v.get("derived", ""))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01", sys.argv[2] if len(sys.argv) > 2 else None)
