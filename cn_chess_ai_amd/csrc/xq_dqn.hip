@@ -132,7 +132,8 @@ struct xq_dqn {
     size_t tail_lds = 0;  double tail_flops = 0, tail_bytes = 0;
 
     // partial-sum slabs may stay unreduced until the SGD kernel only when nothing (an all-reduce) reads the buffer in between
-    bool fused() const { return fused_apply && comm == nullptr; }
+    bool force_defer = false;   // the fused launches of the gradient half leave their partial sums pending whatever follows (tail_gradients)
+    bool fused() const { return (fused_apply && comm == nullptr) || force_defer; }
     bool bf16() const { return precision != XQ_PRECISION_F32; }               // bf16 forward passes
     bool bf16_bwd() const { return precision == XQ_PRECISION_BF16_FULL; }     // ... and bf16 operands in the backward products
     uint16_t* wl_bf(int net, int l) const { return params_bf[net] + (l == 0 ? 0 : (size_t)L[0] * L[1] + (wo[l] - wo[1])); }
@@ -1042,7 +1043,9 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(ColsumJobs J) {   // 
     float s0 = 0.f;
     if (c < C) {
         const float* p = J.work + J.poff[job] + c;
-        for (int z = ty; z < J.R; z += 4) s0 += p[(long long)z * J.wld];
+        const int R4 = J.R & ~3;
+        for (int z = ty; z < R4; z += 4) s0 += p[(long long)z * J.wld];
+        if (ty == 0) for (int z = R4; z < J.R; ++z) s0 += p[(long long)z * J.wld];     // the leftover rows continue chain 0, as there
     }
     red[ty][tx] = s0;
     __syncthreads();
@@ -1133,6 +1136,7 @@ struct SegTable {
     long long stride[16];      //      of reduce_slabs_kernel (bit-identical to reducing first), instead of by a kernel of their own
     uint16_t* dst_bf[16];      // bf16 Q-net: shadow of dst, refreshed with the rounded new value (nullptr: none)
     int nseg;
+    int reduce_only;           // dst = the slab sum itself (no step): the gradient buffer a reader or an all-reduce needs, in one launch
 };
 // ---- exact screening of z_max[b] = max_j (W_out[j] . a[b] + b_out[j])  (xq_dqn_set_qmax_mode(XQ_QMAX_SCREENED)) ------
 // The fp32 column-max GEMM computes 8100 outputs per sample to keep one.  Screening computes all of them once on the bf16 matrix
@@ -1562,6 +1566,7 @@ __global__ void sgd_segments_kernel(SegTable t, float alpha) {
             s3 += s[(long long)(z + 3) * st + i];
         }
         for (; z < nslabs; ++z) s0 += s[(long long)z * st + i];
+        if (t.reduce_only) { d[i] = (s0 + s1) + (s2 + s3); continue; }
         const float v = d[i] - alpha * ((s0 + s1) + (s2 + s3));
         d[i] = v;
         if (db) db[i] = bf16_bits(v);
@@ -2255,7 +2260,7 @@ static int sgd_apply(xq_dqn* d, const SegTable& t, double alpha) {
     long long mx = 0;
     for (int i = 0; i < t.nseg; ++i) mx = std::max(mx, t.len[i]);
     const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>((mx + 255) / 256, 1024));
-    ProfScope ps(d, "sgd_apply", 0, 0);
+    ProfScope ps(d, t.reduce_only ? "reduce_slabs" : "sgd_apply", 0, 0);
     hipLaunchKernelGGL(sgd_segments_kernel, dim3(bx, t.nseg), dim3(256), 0, d->cur, t, (float)alpha);
     XQ_HIP(hipGetLastError());
     return XQ_OK;
@@ -2699,15 +2704,51 @@ static int tail_launch(xq_dqn* d, bool last, const char* name) {
     XQ_HIP(hipGetLastError());
     return XQ_OK;
 }
-// shapes the fused launches take: fp32 products on 64x64 tiles (what launch_gemm picks for them anyway), slabs summed by the SGD
-// kernel (nothing between the launches may need a finished gradient), no communicator (its buckets ride on two streams)
+// shapes the fused launches take: fp32 products on 64x64 tiles (what launch_gemm picks for them anyway).  Their partial sums stay
+// pending: with fused_apply and no communicator the SGD kernel adds them; otherwise ONE launch reduces all of them into the gradient
+// buffer behind the second fused launch (reduce_pending), and a communicator all-reduces that buffer behind it.
 static bool tail_eligible(xq_dqn* d, int n) {
-    if (!d->td_tail || d->bf16() || d->comm || !d->fused()) return false;
+    if (!d->td_tail || d->bf16()) return false;
     for (int l = 0; l + 2 < d->nl; ++l)
         if (!d->small_tiles && (long long)((n + 127) / 128) * ((d->L[l + 1] + 127) / 128) >= 512) return false;   // launch_gemm would go 128x128
     return true;
 }
+// every pending partial-sum slab of the step summed into its place in the gradient buffer, one launch (the order of reduce_slabs_kernel)
+static int reduce_pending(xq_dqn* d) {
+    SegTable t; memset(&t, 0, sizeof t);
+    float* G = d->grads_td;
+    int k = 0;
+    auto add = [&](float* dst, long long len, xq_dqn::PendingSlab& p) {
+        if (p.nslabs > 0) { t.dst[k] = dst; t.src[k] = p.src; t.len[k] = len; t.nslabs[k] = p.nslabs; t.stride[k] = p.stride; ++k; }
+        p = xq_dqn::PendingSlab();
+    };
+    if (d->l0_pending > 0) {
+        xq_dqn::PendingSlab p; p.src = d->slabs_l0; p.nslabs = d->l0_pending; p.stride = (long long)d->L[0] * d->L[1];
+        add(G + d->g_w0, p.stride, p);
+        d->l0_pending = 0;
+    }
+    for (int l = 1; l + 1 < d->nl; ++l) add(G + d->g_wh[l], (long long)d->L[l] * d->L[l + 1], d->pend_hidden[l]);
+    add(G + d->g_wout, 96LL * d->hlast(), d->pend_wout);
+    add(G + d->g_bout, 96, d->pend_bout);
+    add(G + d->g_bh[0], (long long)d->bo[d->nl - 1], d->pend_bh);
+    if (k == 0) return XQ_OK;
+    t.nseg = k; t.reduce_only = 1;
+    return sgd_apply(d, t, 0.0);
+}
+static int tail_gradients_impl(xq_dqn* d, int n, float* const* outs, float* G, int mode);
 static int tail_gradients(xq_dqn* d, int n, float* const* outs, float* G, int mode) {
+    const bool leave_pending = d->fused();          // fused_apply, no communicator: the SGD kernel adds the slabs
+    d->force_defer = true;
+    int rc = tail_gradients_impl(d, n, outs, G, mode);
+    d->force_defer = false;
+    if (rc == XQ_OK && !leave_pending) {
+        rc = reduce_pending(d);
+        // data-parallel step: the whole buffer in one collective on the handle's stream, right behind its last producer
+        if (rc == XQ_OK && d->comm) rc = comm_allreduce_on(d->comm, G, d->n_grads_td, d->stream);
+    }
+    return rc;
+}
+static int tail_gradients_impl(xq_dqn* d, int n, float* const* outs, float* G, int mode) {
     const int nl = d->nl, Hl = d->hlast();
     const int chunk = 256;                           // out_grad: samples per block (see side_gradients)
     const int nchunks = (n + chunk - 1) / chunk;
@@ -3162,8 +3203,14 @@ int xq_dqn_td_grads_replay(xq_dqn* d, xq_replay* r, int batch, int td_net, int m
         per.prio = r->dev.prio; per.pmax_live = r->per.scalars + 0;
         per.eps = r->per.eps; per.alpha = r->per.alpha;
     }
-    return td_grads_impl(d, r->dev.boards, r->dev.next_boards, r->dev.action_to, r->dev.reward, r->dev.done, src, batch, td_net,
-                         mode, prioritized ? &per : nullptr);
+    // a slot list drawn on the ring's own stream: this step starts behind the draw, and the next draw (which overwrites the list)
+    // behind this step
+    const bool listed = src.slots != nullptr;
+    if (listed) XQ_TRY(replay_consumer_begin(r, d->stream));
+    const int rc = td_grads_impl(d, r->dev.boards, r->dev.next_boards, r->dev.action_to, r->dev.reward, r->dev.done, src, batch, td_net,
+                                 mode, prioritized ? &per : nullptr);
+    if (listed && rc == XQ_OK) XQ_TRY(replay_consumer_end(r, d->stream));
+    return rc;
 }
 
 int xq_dqn_td_update_host(xq_dqn* d, int n, const uint8_t* boards90, const uint8_t* next_boards90, const int32_t* action_to,

@@ -35,6 +35,12 @@ struct xq_replay {
     int implicit_start = 0;           // windowed sample: slot = (start + philox % size) % capacity
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // A ring with a stream of its own draws its samples there while the consumer (xq_dqn_td_grads_replay) reads the slot list on the
+    // Q-net's stream: `ev_sampled` (recorded behind every draw) orders the consumer behind the draw, `ev_consumed` (recorded behind
+    // the consumer's TD step) orders the NEXT draw — which overwrites the list — behind the consumer.  A ring that shares its stream
+    // with the consumer (the trainer's) records nothing.
+    hipEvent_t ev_sampled = nullptr, ev_consumed = nullptr;
+    bool sampled_recorded = false, consumed_pending = false;
     // prioritized replay (build-defined, BASELINE configs[4]): radix-32 sum tree, level 0 = dev.prio
     struct Per {
         bool enabled = false;
@@ -163,6 +169,11 @@ hipEvent_t dqn_qmax_event(xq_dqn* d);      // recorded behind the column-max GEM
 // (start, count) restricts the draw to `count` ring slots from `start` (count < 0: the whole filled part).
 int replay_sample_implicit(xq_replay* r, int batch, int start = 0, int count = -1);
 
+// ordering of a draw / its consumer across streams (see xq_replay::ev_sampled)
+int replay_before_draw(xq_replay* r, hipStream_t draw_stream);
+int replay_after_draw(xq_replay* r, hipStream_t draw_stream);
+int replay_consumer_begin(xq_replay* r, hipStream_t consumer);
+int replay_consumer_end(xq_replay* r, hipStream_t consumer);
 // prioritized replay internals used by the trainer (xq_replay.hip)
 int replay_per_rebuild(xq_replay* r, int retire_start, int retire_count, hipStream_t on);
 int replay_per_sample(xq_replay* r, int batch, hipStream_t on);

@@ -188,15 +188,45 @@ int replay_per_sample(xq_replay* r, int batch, hipStream_t on) {
         r->slots_cap = batch;
     }
     if (!r->per.is_w) XQ_HIP(hipMalloc(&r->per.is_w, (size_t)r->slots_cap * sizeof(float)));
+    XQ_TRY(replay_before_draw(r, s));
     if (!r->per.wmax_clean) XQ_HIP(hipMemsetAsync(r->per.scalars + 2, 0, sizeof(unsigned), s));     // a second draw from the same tree
     r->per.wmax_clean = false;
     hipLaunchKernelGGL(per_sample_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, per_tree(r), batch, (uint32_t)r->sample_calls,
                        (uint32_t)r->seed, (uint32_t)(r->seed >> 32), r->per.beta, r->per.scalars, r->slots_dev, r->per.is_w);
     XQ_HIP(hipGetLastError());
+    XQ_TRY(replay_after_draw(r, s));
     r->sample_calls++;
     r->last_batch = batch;
     r->implicit = false;
     r->per.last_prioritized = true;
+    return XQ_OK;
+}
+
+// ---- a draw on one stream, its consumer on another (xq_replay::ev_sampled in xq_internal.h) ------------------------------------
+int replay_before_draw(xq_replay* r, hipStream_t draw_stream) {
+    if (r->consumed_pending) {                    // the last consumer may still be reading the list this draw overwrites
+        XQ_HIP(hipStreamWaitEvent(draw_stream, r->ev_consumed, 0));
+        r->consumed_pending = false;
+    }
+    return XQ_OK;
+}
+int replay_after_draw(xq_replay* r, hipStream_t draw_stream) {
+    r->sampled_recorded = false;
+    if (!r->own_stream || draw_stream != r->stream) return XQ_OK;      // the ring runs on its owner's stream: stream order does it
+    if (!r->ev_sampled) XQ_HIP(hipEventCreateWithFlags(&r->ev_sampled, hipEventDisableTiming));
+    XQ_HIP(hipEventRecord(r->ev_sampled, draw_stream));
+    r->sampled_recorded = true;
+    return XQ_OK;
+}
+int replay_consumer_begin(xq_replay* r, hipStream_t consumer) {
+    if (r->sampled_recorded && consumer != r->stream) XQ_HIP(hipStreamWaitEvent(consumer, r->ev_sampled, 0));
+    return XQ_OK;
+}
+int replay_consumer_end(xq_replay* r, hipStream_t consumer) {
+    if (!r->sampled_recorded || consumer == r->stream) return XQ_OK;
+    if (!r->ev_consumed) XQ_HIP(hipEventCreateWithFlags(&r->ev_consumed, hipEventDisableTiming));
+    XQ_HIP(hipEventRecord(r->ev_consumed, consumer));
+    r->consumed_pending = true;
     return XQ_OK;
 }
 
@@ -257,6 +287,8 @@ static int replay_init(xq_replay* r, int capacity, uint64_t seed, void* hip_stre
 int xq_replay_destroy(xq_replay* r) {
     if (!r) return XQ_OK;
     hipStreamSynchronize(r->stream);
+    if (r->ev_sampled) hipEventDestroy(r->ev_sampled);
+    if (r->ev_consumed) hipEventDestroy(r->ev_consumed);
     hipFree(r->dev.boards); hipFree(r->dev.next_boards); hipFree(r->dev.action_to); hipFree(r->dev.reward);
     hipFree(r->dev.done); hipFree(r->slots_dev);
     hipFree(r->dev.prio); hipFree(r->per.leaves); hipFree(r->per.upper); hipFree(r->per.scalars); hipFree(r->per.wave_counts); hipFree(r->per.is_w);
@@ -417,9 +449,11 @@ int xq_replay_sample_window(xq_replay* r, int batch, int start, int count, int32
         XQ_HIP(hipMalloc(&r->slots_dev, (size_t)batch * sizeof(int32_t)));
         r->slots_cap = batch;
     }
+    XQ_TRY(replay_before_draw(r, r->stream));
     hipLaunchKernelGGL(replay_sample_kernel, dim3((batch + 255) / 256), dim3(256), 0, r->stream, r->slots_dev, batch,
                        (uint32_t)start, (uint32_t)count, (uint32_t)r->dev.capacity, (uint32_t)r->sample_calls, (uint32_t)r->seed, (uint32_t)(r->seed >> 32));
     XQ_HIP(hipGetLastError());
+    XQ_TRY(replay_after_draw(r, r->stream));
     r->sample_calls++;
     r->last_batch = batch;
     r->implicit = false;

@@ -148,7 +148,11 @@ int xq_replay_size(xq_replay* r, int* size, int* capacity, uint64_t* total_pushe
 int xq_replay_push_host(xq_replay* r, int n, const uint8_t* boards90, const int32_t* action_to, const float* reward,
                         const uint8_t* done, const uint8_t* next_boards90);
 /* sample(B): uniform with replacement, Philox(ctr = {draw, 0, sample call #, 1}, key = seed) % size.
- * Returns the chosen slots; xq_dqn_train_replay consumes them on device. */
+ * Returns the chosen slots; xq_dqn_td_grads_replay consumes them on device.  Streams: the draw runs on the ring's stream, the
+ * consumer on the Q-net's.  When those differ the library orders them itself — the TD step waits for the draw, and the next draw
+ * (it overwrites the slot list) waits for the TD step that still reads it — so a caller may draw, queue the step and draw again
+ * without synchronising.  The CONTENTS of the ring are the caller's to order: a ply that writes slots a queued step still reads
+ * must wait for that step (the trainer draws from the ring minus the slots its collects write, xq_replay_sample_window). */
 int xq_replay_sample(xq_replay* r, int batch, int32_t* slots_host /* optional */);
 /* sample(B) restricted to the `count` ring slots that start at `start` (wrapping): slot = (start + Philox % count) % capacity.
  * The overlapped trainer uses it to leave out the slots a concurrent collect is writing; (0, size) == xq_replay_sample. */

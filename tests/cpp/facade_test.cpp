@@ -298,7 +298,7 @@ int main() {
             CHECK(completed == 32);
             ai.network()->getParameters(w[pass], bb[pass]);
         }
-        CHECK(comm.collectivesIssued() > 0 && comm.collectivesIssued() % 2 == 0);     // two buckets per update
+        CHECK(comm.collectivesIssued() > 0);            // one collective per update behind the fused launches (two buckets on two streams otherwise)
         CHECK(w[0] == w[1] && bb[0] == bb[1]);          // sum over one rank = identity: bit-identical training
     }
     // ---- ReplayBuffer / VecEnv ----

@@ -40,22 +40,25 @@ def test_gradient_buffer_is_visible_to_torch_zero_copy():
 
 
 def test_rccl_path_behind_the_c_abi_world_size_one(tmp_path):
-    """xq_comm_* / xq_dqn_set_comm / xq_allreduce_grads with a one-rank RCCL communicator: the bucketed all-reduce runs (two
-    collectives per update, every float of the gradient buffer once) and the training result is bit-identical to the same
-    loop without a communicator — also against the fused-apply single-GPU path."""
+    """xq_comm_* / xq_dqn_set_comm / xq_allreduce_grads with a one-rank RCCL communicator: the all-reduce runs inside every TD step
+    (one collective behind the fused launches of the gradient half; two buckets on two streams with xq_dqn_set_td_tail(0); every
+    float of the gradient buffer once either way) and the training result is bit-identical to the same loop without a communicator —
+    also against the fused-apply single-GPU path."""
     import cn_chess_ai_amd as xq
     from cn_chess_ai_amd import dist as xd, _capi
     sizes = (1260, 64, 64, 8100)
     mk = lambda overlap: xq.TrainerConfig(n_games=512, layer_sizes=sizes, replay_capacity=4096, minibatch=1024, td_net=0,
                                           target_sync_interval=3, seed=99, overlap_collect=overlap)
     for overlap in (0, 1):
-        ta, tb, tc = xq.Trainer(mk(overlap)), xq.Trainer(mk(overlap)), xq.Trainer(mk(overlap))
+        ta, tb, tc, td = xq.Trainer(mk(overlap)), xq.Trainer(mk(overlap)), xq.Trainer(mk(overlap)), xq.Trainer(mk(overlap))
         comm = xd.Comm(rank=0, world=1)                          # id drawn and consumed in this process
+        comm2 = xd.Comm(rank=0, world=1)
         assert comm.info() == dict(rank=0, world=1, collectives=0, floats=0)
         tb.set_comm(comm)
         tc.dqn.set_fused_apply(True)
+        td.set_comm(comm2); td.dqn.set_td_tail(False)            # the two-stream form: two buckets, each behind its producer
         steps = 6
-        for t in (ta, tb, tc):
+        for t in (ta, tb, tc, td):
             for _ in range(steps):
                 if overlap:
                     t.learn_grads(); t.collect()
@@ -64,10 +67,13 @@ def test_rccl_path_behind_the_c_abi_world_size_one(tmp_path):
                 t.learn_apply(1)
         _, n = tb.dqn.grad_buffer()
         info = comm.info()
-        assert info["collectives"] == 2 * steps and info["floats"] == n * steps
-        wa, ba = ta.dqn.get_params(); wb, bb = tb.dqn.get_params(); wc, bc = tc.dqn.get_params()
+        assert info["collectives"] == steps and info["floats"] == n * steps
+        info2 = comm2.info()
+        assert info2["collectives"] == 2 * steps and info2["floats"] == n * steps
+        wa, ba = ta.dqn.get_params(); wb, bb = tb.dqn.get_params(); wc, bc = tc.dqn.get_params(); wd, bd = td.dqn.get_params()
         assert np.array_equal(wa, wb) and np.array_equal(ba, bb)
         assert np.array_equal(wa, wc) and np.array_equal(ba, bc)
+        assert np.array_equal(wa, wd) and np.array_equal(ba, bd)
         sa, _ = ta.env.get_state(); sb, _ = tb.env.get_state()
         assert np.array_equal(sa, sb)
         # xq_trainer_step takes the world size from the attached communicator
@@ -83,14 +89,14 @@ def test_rccl_path_behind_the_c_abi_world_size_one(tmp_path):
         before = g.clone()
         _capi.call("xq_allreduce_grads", tb.dqn.handle, comm.handle)
         _capi.call("xq_stream_synchronize", None); torch.cuda.synchronize()
-        assert torch.equal(before, g) and comm.info()["collectives"] == 2 * steps + 2 * 2 + 1
+        assert torch.equal(before, g) and comm.info()["collectives"] == steps + 2 + 1
         v = C.c_uint64(41)
         _capi.call("xq_comm_sum_u64", comm.handle, C.byref(v))
         assert v.value == 41
         tb.learn_apply(1)
-        for t in (ta, tb, tc):
+        for t in (ta, tb, tc, td):
             t.close()
-        comm.close()
+        comm.close(); comm2.close()
     # file rendezvous (what the C++ facade uses)
     c2 = xd.Comm(rank=0, world=1, path=str(tmp_path / "xq_comm_id"))
     assert c2.info()["world"] == 1

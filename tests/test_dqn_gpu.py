@@ -694,19 +694,22 @@ def test_td_tail_launches_equal_the_two_stream_path_bitwise(xq, sizes, mode, n, 
     D = res["done"].copy()
     D[::9] = 1
     out = {}
-    for tail in (True, False):
+    # fused_apply: the partial sums of the step stay pending until the SGD kernel adds them; without it ONE launch behind the fused
+    # grids reduces all of them into the gradient buffer (what a reader of the buffer, or an all-reduce, needs)
+    for tail, fused in ((True, True), (True, False), (False, True), (False, False)):
         d, w, b = make_net(xq, sizes, seed=31)
-        d.set_fused_apply(True)                     # the fused launches leave their slabs to the SGD kernel
+        d.set_fused_apply(fused)
         d.set_td_tail(tail)
         d.set_qmax_mode(_capi.QMAX_SCREENED if screened else _capi.QMAX_FULL)
         for _ in range(2):
             qsa, y = d.td_update(S, S2, A, R, D, td_net=0, mode=mode, learning_rate=0.05, grad_scale=1.0 / n)
-        out[tail] = (d.get_params(), qsa.copy(), y.copy())
+        out[(tail, fused)] = (d.get_params(), qsa.copy(), y.copy())
         d.close()
-    (w1, b1), q1, y1 = out[True]
-    (w0, b0), q0, y0 = out[False]
-    assert np.array_equal(q1, q0) and np.array_equal(y1, y0)
-    assert np.array_equal(w1, w0) and np.array_equal(b1, b0)
+    (w1, b1), q1, y1 = out[(True, True)]
+    for key in ((True, False), (False, True), (False, False)):
+        (w0, b0), q0, y0 = out[key]
+        assert np.array_equal(q1, q0) and np.array_equal(y1, y0), key
+        assert np.array_equal(w1, w0) and np.array_equal(b1, b0), key
     wi, bi = xo.init_weights(sizes, 31)
     assert np.abs(w1 - wi).max() > 0                # ... and the updates did move the weights
     env.close()
