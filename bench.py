@@ -316,8 +316,8 @@ def main():
     if args.no_td_tail: t.dqn.set_td_tail(False)  # A/B: the gradient kernels one by one on two streams (library default: fused launches)
     grads, comm, comm_error = None, None, ""
     if world == 1 and os.environ.get("XQ_BENCH_COMM1"):
-        # rehearsal on one GPU: a one-rank communicator attached, so that the whole N > 1 code path of the library runs (bucketed
-        # all-reduce on the communicator's stream, unfused slab reductions) — shows what that path costs besides the wire time
+        # rehearsal on one GPU: a one-rank communicator attached, so that the whole N > 1 code path of the library runs (one launch
+        # that reduces the partial sums, the all-reduce behind it, unfused SGD) — shows what that path costs besides the wire time
         comm = xd.Comm(rank=0, world=1)
         t.set_comm(comm)
     elif world == 1 or args.independent:
@@ -326,8 +326,8 @@ def main():
         ptr, n = t.dqn.grad_buffer()
         grads = xd.wrap_device_floats(ptr, n)
     else:
-        # the exchange step lives behind the C ABI: learn_grads all-reduces the gradient buffer over RCCL itself, in two
-        # buckets released by their producers (xq_dqn_set_comm); torch.distributed only carries the 128-byte id and barriers
+        # the exchange step lives behind the C ABI: learn_grads all-reduces the gradient buffer over RCCL itself, right behind the
+        # launch that produces it (xq_dqn_set_comm); torch.distributed only carries the 128-byte id and barriers
         ok = torch.ones(1, device="cuda")
         try:
             comm = xd.Comm()
@@ -496,7 +496,7 @@ def main():
                        "parallelism": ("1 GPU" if world == 1 else
                                        f"{world} independent shards, no all-reduce (BASELINE configs[2])" if args.independent else
                                        f"dp{world} (games sharded; per update one RCCL sum all-reduce of the 1.65 MB gradient buffer "
-                                       f"behind the C ABI, two buckets released by their producers)" if comm is not None else
+                                       f"behind the C ABI, on the handle's stream right behind the launch that reduces the partial sums)" if comm is not None else
                                        f"dp{world} (games sharded, gradient all-reduce per update through torch.distributed)")},
         }
         if other is not None:

@@ -206,7 +206,7 @@ DQN.qmax_stats = _qmax_stats
 
 
 def _set_comm(self, comm):
-    """Attach an xq_comm (dist.Comm) or None: td_grads then all-reduces the gradient buffer itself, in buckets."""
+    """Attach an xq_comm (dist.Comm) or None: td_grads then all-reduces the gradient buffer itself."""
     call("xq_dqn_set_comm", self._h, comm.handle if comm is not None else None)
 
 

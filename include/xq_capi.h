@@ -321,11 +321,13 @@ int xq_comm_info(const xq_comm* c, int* rank, int* world, uint64_t* collectives_
 int xq_comm_sum_u64(xq_comm* c, uint64_t* inout_host);
 /* In-place sum of n_floats fp32 over all ranks on hip_stream (NULL = the communicator's own stream). */
 int xq_comm_allreduce(xq_comm* c, float* buf_dev, size_t n_floats, void* hip_stream);
-/* Attach (or detach with NULL) a communicator: every xq_dqn_td_grads* then all-reduces the gradient buffer itself, in two
- * buckets, each on the stream of its producer right behind it (no communicator stream, no extra events) — [hidden +
- * output-layer weights, biases] on the library's side stream, issued first, the layer-0 segment (the largest and last) on
- * the handle's stream behind the layer-0 kernel — and returns with the handle's stream ordered behind both.
- * xq_dqn_apply_grads therefore sees the global sum.  world = 1 is bit-identical to no communicator. */
+/* Attach (or detach with NULL) a communicator: every xq_dqn_td_grads* then all-reduces the gradient buffer itself, on the stream of
+ * its producer right behind it (no communicator stream, no extra events).  fp32 nets (fused launches, xq_dqn_set_td_tail): ONE
+ * collective over the whole buffer on the handle's stream, behind the launch that reduces the step's partial sums into it.  bf16
+ * nets and xq_dqn_set_td_tail(0): two buckets — [hidden + output-layer weights, biases] on the library's side stream, issued first,
+ * the layer-0 segment (the largest and last) on the handle's stream behind the layer-0 kernel.  Either way the call returns with
+ * the handle's stream ordered behind the exchange; xq_dqn_apply_grads therefore sees the global sum.  world = 1 is bit-identical
+ * to no communicator. */
 int xq_dqn_set_comm(xq_dqn* d, xq_comm* comm);
 /* One all-reduce of the whole gradient buffer on the handle's stream, for callers that do not attach a communicator. */
 int xq_allreduce_grads(xq_dqn* d, xq_comm* comm);
