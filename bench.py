@@ -251,6 +251,9 @@ def main():
                     help="--config 5: XQ_PRECISION_BF16 (bf16 forward, fp32 backward products) instead of XQ_PRECISION_BF16_FULL")
     ap.add_argument("--no-derive", action="store_true",
                     help="gather layer 0 of the s' chain in full (the library default) instead of deriving it from the s chain")
+    ap.add_argument("--exchange-overlap", type=int, default=-1, choices=(-1, 0, 1),
+                    help="data-parallel step: where the select chain starts (xq_dqn_set_exchange_overlap; -1 = library default: beside "
+                         "the all-reduce when there is more than one rank)")
     ap.add_argument("--no-td-tail", action="store_true",
                     help="A/B: the gradient kernels of the TD step one by one on two streams instead of the fused launches (xq_dqn_set_td_tail)")
     ap.add_argument("--no-variants", action="store_true", help="skip the variant legs (other TD net, full fp32 product): A/B runs")
@@ -314,6 +317,7 @@ def main():
     t.dqn.set_qmax_mode(_capi.QMAX_SCREENED if args.qmax == "screened" else _capi.QMAX_FULL)
     t.dqn.set_l0_derive(not args.no_derive)       # layer-0 sums of s' from those of s (library default: off, the reference's order)
     if args.no_td_tail: t.dqn.set_td_tail(False)  # A/B: the gradient kernels one by one on two streams (library default: fused launches)
+    if args.exchange_overlap >= 0: t.dqn.set_exchange_overlap(args.exchange_overlap)
     grads, comm, comm_error = None, None, ""
     if world == 1 and os.environ.get("XQ_BENCH_COMM1"):
         # rehearsal on one GPU: a one-rank communicator attached, so that the whole N > 1 code path of the library runs (one launch

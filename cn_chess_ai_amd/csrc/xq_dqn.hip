@@ -129,6 +129,8 @@ struct xq_dqn {
     xq::TailArgs* tail = nullptr;
     bool tail_open = false;
     bool td_tail = true;                        // xq_dqn_set_td_tail
+    int exchange_overlap = -1;                  // xq_dqn_set_exchange_overlap: -1 auto (on when the communicator has more than one rank), 0, 1
+    bool late_gate = false;                     // this TD step records ev_qmax behind its gradients (see tail_gradients)
     size_t tail_lds = 0;  double tail_flops = 0, tail_bytes = 0;
 
     // partial-sum slabs may stay unreduced until the SGD kernel only when nothing (an all-reduce) reads the buffer in between
@@ -2447,6 +2449,12 @@ int xq_dqn_set_td_tail(xq_dqn* d, int on) {
     return XQ_OK;
 }
 
+int xq_dqn_set_exchange_overlap(xq_dqn* d, int mode) {
+    if (!d || mode < -1 || mode > 1) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_set_exchange_overlap: mode -1, 0 or 1");
+    d->exchange_overlap = mode;
+    return XQ_OK;
+}
+
 int xq_dqn_set_qmax_mode(xq_dqn* d, int mode) {
     if (!d || (mode != XQ_QMAX_FULL && mode != XQ_QMAX_SCREENED)) return fail(XQ_ERR_INVALID_ARGUMENT, "bad qmax mode");
     d->qmax_mode = mode;
@@ -2741,6 +2749,9 @@ static int tail_gradients(xq_dqn* d, int n, float* const* outs, float* G, int mo
     d->force_defer = true;
     int rc = tail_gradients_impl(d, n, outs, G, mode);
     d->force_defer = false;
+    if (rc == XQ_OK && d->late_gate) {               // the select chain starts here, beside the exchange
+        if (hipEventRecord(d->ev_qmax, d->stream) != hipSuccess) rc = fail(XQ_ERR_RUNTIME, "hipEventRecord failed");
+    }
     if (rc == XQ_OK && !leave_pending) {
         rc = reduce_pending(d);
         // data-parallel step: the whole buffer in one collective on the handle's stream, right behind its last producer
@@ -2821,6 +2832,12 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     if (d->nout() < 96) return fail(XQ_ERR_INVALID_ARGUMENT, "TD path needs >= 96 outputs (action.to indexes outputs 0..89)");
     if (mode == XQ_BACKPROP_REFERENCE) XQ_TRY(check_reference_topology(d));
     const bool dbl = td_net == XQ_TD_DOUBLE, bf = d->bf16();
+    // Data-parallel step with more than one rank: the trainer's select chain (it waits for ev_qmax) starts behind the GRADIENTS
+    // instead of behind the max pass, so that it runs beside the all-reduce — the exchange is then hidden behind work the step has to
+    // do anyway, and the gradient kernels have the chip to themselves.  On one GPU there is nothing to hide behind and the early start
+    // is the faster one.
+    d->late_gate = d->comm != nullptr && tail_eligible(d, n) &&
+                   (d->exchange_overlap == 1 || (d->exchange_overlap < 0 && comm_world(d->comm) > 1));
     XQ_TRY(ensure_capacity(d, n));
     XQ_TRY(ensure_ext_capacity(d, n, dbl));
     const int nl = d->nl, Hl = d->hlast(), NO = d->nout();
@@ -2937,7 +2954,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         // (the select chain of the trainer starts here.  Behind the refine kernel instead — which would then have the chip to itself,
         // 17 instead of 27-34 us — the select chain ends after the gradients and the step waits for it: 0.197 -> 0.207 ms; in front of
         // the screening pass: no difference)
-        XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
+        if (!d->late_gate) XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
         {
             ProfScope ps(d, "qmax_refine", 2.0 * n * Hl * 3, 12.0 * G * n + 4.0 * n * Hl);
             const size_t lds = (size_t)G * kRefineSamples * (sizeof(uint32_t) + sizeof(uint16_t));
@@ -3047,7 +3064,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_COLMAX>(d, g, 1, "gemm_qmax_rowmax")));
         }
     }
-    XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
+    if (!d->late_gate) XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
     {   // the partial maxima of every sample folded into kReduceParts values (+ row indices): coalesced, block-cooperative
         ProfScope ps(d, "colmax_reduce", (double)n * n_part, (dbl ? 8.0 : 4.0) * n * (n_part + kReduceParts));
         hipLaunchKernelGGL(colmax_reduce_kernel, dim3((n + 63) / 64, kReduceParts), dim3(256), 0, d->cur, d->partial,

@@ -194,6 +194,14 @@ def _set_td_tail(self, on):
 DQN.set_td_tail = _set_td_tail
 
 
+def _set_exchange_overlap(self, mode):
+    """Data-parallel step: -1 auto, 0 select chain beside the gradient kernels, 1 beside the all-reduce (hides the exchange)."""
+    call("xq_dqn_set_exchange_overlap", self._h, int(mode))
+
+
+DQN.set_exchange_overlap = _set_exchange_overlap
+
+
 def _qmax_stats(self):
     """(TD steps screened, samples, candidate (sample, group) pairs, pairs re-evaluated as whole groups); synchronises."""
     st = (C.c_uint64 * 4)()

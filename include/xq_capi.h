@@ -329,6 +329,11 @@ int xq_comm_allreduce(xq_comm* c, float* buf_dev, size_t n_floats, void* hip_str
  * the handle's stream ordered behind the exchange; xq_dqn_apply_grads therefore sees the global sum.  world = 1 is bit-identical
  * to no communicator. */
 int xq_dqn_set_comm(xq_dqn* d, xq_comm* comm);
+/* Where the event the trainer's select chain waits for is recorded in a data-parallel TD step (fp32 nets, fused launches).  0: behind
+ * the max pass, as on one GPU (the select chain runs beside the gradient kernels).  1: behind the gradient kernels, in front of the
+ * all-reduce (the select chain runs beside the exchange and hides it).  -1 (default): 1 when the communicator has more than one
+ * rank, else 0.  No effect without a communicator.  Same results either way. */
+int xq_dqn_set_exchange_overlap(xq_dqn* d, int mode);
 /* One all-reduce of the whole gradient buffer on the handle's stream, for callers that do not attach a communicator. */
 int xq_allreduce_grads(xq_dqn* d, xq_comm* comm);
 

@@ -57,8 +57,11 @@ def test_rccl_path_behind_the_c_abi_world_size_one(tmp_path):
         tb.set_comm(comm)
         tc.dqn.set_fused_apply(True)
         td.set_comm(comm2); td.dqn.set_td_tail(False)            # the two-stream form: two buckets, each behind its producer
-        steps = 6
-        for t in (ta, tb, tc, td):
+        te = xq.Trainer(mk(overlap))
+        comm3 = xd.Comm(rank=0, world=1)
+        te.set_comm(comm3); te.dqn.set_exchange_overlap(1)       # what more than one rank runs: the select chain starts behind the
+        steps = 6                                                # gradients and runs beside the all-reduce
+        for t in (ta, tb, tc, td, te):
             for _ in range(steps):
                 if overlap:
                     t.learn_grads(); t.collect()
@@ -74,6 +77,10 @@ def test_rccl_path_behind_the_c_abi_world_size_one(tmp_path):
         assert np.array_equal(wa, wb) and np.array_equal(ba, bb)
         assert np.array_equal(wa, wc) and np.array_equal(ba, bc)
         assert np.array_equal(wa, wd) and np.array_equal(ba, bd)
+        we, be = te.dqn.get_params()
+        assert np.array_equal(wa, we) and np.array_equal(ba, be) and comm3.info()["collectives"] == steps
+        se, _ = te.env.get_state()
+        assert np.array_equal(ta.env.get_state()[0], se)
         sa, _ = ta.env.get_state(); sb, _ = tb.env.get_state()
         assert np.array_equal(sa, sb)
         # xq_trainer_step takes the world size from the attached communicator
@@ -94,9 +101,9 @@ def test_rccl_path_behind_the_c_abi_world_size_one(tmp_path):
         _capi.call("xq_comm_sum_u64", comm.handle, C.byref(v))
         assert v.value == 41
         tb.learn_apply(1)
-        for t in (ta, tb, tc, td):
+        for t in (ta, tb, tc, td, te):
             t.close()
-        comm.close(); comm2.close()
+        comm.close(); comm2.close(); comm3.close()
     # file rendezvous (what the C++ facade uses)
     c2 = xd.Comm(rank=0, world=1, path=str(tmp_path / "xq_comm_id"))
     assert c2.info()["world"] == 1
