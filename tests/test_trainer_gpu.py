@@ -327,15 +327,15 @@ def test_screened_qmax_in_the_overlapped_trainer(xq):
     assert np.abs(w_s - w_f).max() < 1e-7 and np.abs(b_s - b_f).max() < 1e-7 and abs(loss_s - loss_f) < 1e-4 * abs(loss_f)
 
 
-@pytest.mark.parametrize("sizes", [CFG2_NET, (1260, 512, 512, 512, 8100)])
-def test_select_head_riding_on_the_last_hidden_product(xq, sizes):
+@pytest.mark.parametrize("sizes,mode", [(CFG2_NET, 0), ((1260, 512, 512, 512, 8100), 0), ((1260, 128, 256, 8100), 1)])   # (the as-written
+def test_select_head_riding_on_the_last_hidden_product(xq, sizes, mode):                                                 # backprop has no 128 -> 256)
     """From 2048 games on, the trainer's select chain (dqn_q90_boards) takes Q[0..95] out of the last hidden product itself (EPI_HEAD:
     one k-slab of the head per 64-column tile, q_head_finish_kernel adds them) — the stand-alone head (xq_dqn_forward_boards_dev,
     k-slabs of the same 64 columns) must give the same bits: the two loops then play the same moves and learn the same weights.
     The stand-alone head against the oracle on a few boards."""
     n, iters, seed = 2048, 3, 77
     cfg = xq.TrainerConfig(n_games=n, layer_sizes=sizes, learning_rate=0.01, gamma=0.99, epsilon=0.1, replay_capacity=4 * n,
-                           minibatch=n, td_net=0, backprop_mode=0, target_sync_interval=0, mean_gradient=1, seed=seed, first_game_id=0)
+                           minibatch=n, td_net=0, backprop_mode=mode, target_sync_interval=0, mean_gradient=1, seed=seed, first_game_id=0)
     t = xq.Trainer(cfg)
     w0, b0 = t.dqn.get_params()
     t.random_plies(20)
@@ -363,7 +363,7 @@ def test_select_head_riding_on_the_last_hidden_product(xq, sizes):
         env.selfplay_step_dev(q.data_ptr(), 96, 0.1, replay=rp)
         torch.cuda.synchronize()
         rp.sample(n)
-        d.td_grads_replay(rp, n, td_net=0, mode=0)
+        d.td_grads_replay(rp, n, td_net=0, mode=mode)
         d.apply_grads(0.01, 1.0 / n)
     w, b = d.get_params()
     boards, meta = env.get_state()
