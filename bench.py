@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps, barrier + synchronize on both sides) is run this many times back to "
                          "back; ms_per_step / value are the MEDIAN repetition, all of them are listed in ms_per_step_samples")
+    ap.add_argument("--settle-steps", type=int, default=100,
+                    help="untimed training steps between the W warm-up steps and the timed region (reported in config.steady_state)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="queue collect and learn on one stream (collect -> learn -> apply) instead of running collect beside learn_grads")
     args = ap.parse_args()
@@ -369,7 +371,12 @@ def main():
     fill_collects = 0 if args.no_fill else (cap + n_games - 1) // n_games
     for _ in range(fill_collects):
         t.collect()                          # epsilon-greedy plies on the initial net, transitions into the ring
-    for _ in range(args.warmup):
+    # the HIP-event brackets of the roofline leg run during the warm-up too (the library's event pool is then filled before anything is
+    # timed), and `--settle-steps` more untimed steps follow the W warm-up steps: with the driver's short windows (W = 5, K = 20: 5 ms)
+    # the first repetitions otherwise still see the chip ramping up from the host-side preparation (0.2056, 0.2028, 0.1981, 0.1922,
+    # 0.1921 ms per step over five repetitions on one run)
+    t.dqn.kernel_stats(enable=2 if args.profile_all else 3 if args.bracket_all else 4)
+    for _ in range(args.warmup + args.settle_steps):
         one_step()
     torch.cuda.synchronize()
     c0 = t.counters()
@@ -490,6 +497,7 @@ def main():
                                                         - c0["updates"] // max(args.target_sync_interval, 1)) / len(samples)
                                                        if args.target_sync_interval else 0,
                        "steady_state": {"prefill_random_plies": args.prefill_plies, "fill_collects": fill_collects,
+                                        "settle_steps_untimed": args.settle_steps,
                                         "replay_fill": rp_size / rp_cap, "replay_total_pushed": rp_total,
                                         "mean_ply": float(np.mean(meta[:, 0])), "max_ply": int(np.max(meta[:, 0])),
                                         "mean_legal_moves": float(np.mean(legal_counts)), "max_legal_moves": int(np.max(legal_counts)),
