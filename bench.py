@@ -514,6 +514,24 @@ def main():
         if other is not None:
             line["variant_td_" + other] = {"value": world * n_games * plies * args.steps / el_other, "unit": "env steps/s",
                                            "updates_per_s": args.steps / el_other, "ms_per_step": 1e3 * el_other / args.steps}
+        def empty_bracket_ms(reps=48):
+            """What a HIP-event bracket reads around a kernel that does nothing (a 64-element add on the bench's stream, behind another
+            kernel like every bracket of the loop): dispatch + a ~2 us kernel + completion + the two records.  The bracket around the
+            dominant kernel contains the same overheads, which is why it reads 3-4 us more than rocprofv3's kernel duration."""
+            x = torch.zeros(64, device="cuda")
+            evs = []
+            with torch.cuda.stream(tstream):
+                for _ in range(reps):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    x.add_(1.0)
+                    a.record(tstream); x.add_(1.0); b.record(tstream)
+                    evs.append((a, b))
+            torch.cuda.synchronize()
+            ts = sorted(a.elapsed_time(b) for a, b in evs)
+            return ts[len(ts) // 2]
+
+        bracket_ms = empty_bracket_ms()
+
         def gemm_roofline(st, iso_st, screened_kernel):
             ms = st["ms"] / st["launches"]
             fl = st["flops"] / st["launches"]
@@ -537,6 +555,9 @@ def main():
                  "traffic_source": src, "avg_launch_ms": ms, "flops_per_launch": fl, "launches": st["launches"],
                  "launches_note": "HIP-event brackets inside the timed region, on " + ("every launch" if args.bracket_all or args.profile_all else
                                   "every 4th launch (two event records per bracket drain the stream's queue, ~10 us; --bracket-all for every launch)")}
+            # context for the difference between avg_launch_ms and rocprofv3's kernel duration (profiles/): the same bracket around a
+            # kernel that does nothing — the raw figure above contains up to this much that is not the kernel; it is NOT subtracted
+            r["hip_event_bracket_of_an_empty_kernel_ms"] = bracket_ms
             if iso_st and iso_st["launches"]:
                 r["isolated_avg_launch_ms"] = iso_st["ms"] / iso_st["launches"]
                 r["isolated_frac"] = fl / (iso_st["ms"] / iso_st["launches"] * 1e-3) / 1e12 / peak
