@@ -84,7 +84,9 @@ struct xq_dqn {
     unsigned* scr_wmax = nullptr;
     int scr_static_net = -1;                    // net whose rows >= 96 the shadow holds (-1: none — the next step converts everything)
     bool scr_new_kernel_ready = false;          // dynamic-LDS attribute of screen_top2_kernel set
-    unsigned long long* scr_stats = nullptr;    // [4] TD steps, samples, candidate (sample, group) pairs, pairs recomputed as whole groups
+    unsigned long long* scr_stats = nullptr;    // [refine blocks][2] running totals per block: candidate (sample, group) pairs, pairs recomputed as whole groups
+    int scr_stat_blocks = 0;                    // blocks the array (and its pinned copy) has room for
+    unsigned long long scr_carry[2] = {0, 0};   // totals of an array that was replaced by a larger one
     unsigned long long scr_host_steps = 0, scr_host_samples = 0;
     // guard: every kScreenCheckEvery screened steps the candidate counters are copied back asynchronously and evaluated kScreenCheckEvery
     // steps later; a net that leaves the screen too many candidates (outputs all within the bf16 bound of each other) gets the full
@@ -1238,6 +1240,8 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
     const int b = b0 + sl;
     const bool ok = b < n;
     if (tid == 0) { cnt = 0; nexp = 0; if (blockIdx.x == 0) { wm[parity ^ 1] = 0u; wm[2 + (parity ^ 1)] = 0u; } }   // next step's slots
+    unsigned long long st_pairs = 0, st_whole = 0;   // candidate counters: [block][2] running totals, one writer per slot (stream order)
+    if (tid == 0) { st_pairs = stats[2 * blockIdx.x]; st_whole = stats[2 * blockIdx.x + 1]; }
     if (tid < 32) best[tid] = (int)0x80000000;
     // this thread's screened values: groups phase, phase + 8, ...
     // (unconditional, clamped loads: a predicate per load compiles to a branch per load)
@@ -1325,9 +1329,9 @@ __global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restric
     }
     __syncthreads();
     if (tid < 32 && ok) zmax[b] = float_from_key(best[sl]);
-    if (tid == 0) {
-        atomicAdd(&stats[2], (unsigned long long)(singles + wholes));
-        atomicAdd(&stats[3], (unsigned long long)wholes);
+    if (tid == 0) {                                  // this block's own running totals (512 same-address atomics per launch cost the
+        stats[2 * blockIdx.x] = st_pairs + (unsigned long long)(singles + wholes);      // step 5 us)
+        stats[2 * blockIdx.x + 1] = st_whole + (unsigned long long)wholes;
     }
 }
 
@@ -1370,6 +1374,8 @@ __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restri
     const bool ok = b < n;
     const int bc = min(b, n - 1);
     if (tid == 0) { cnt = 0; nexp = 0; if (blockIdx.x == 0) { wm[parity ^ 1] = 0u; wm[2 + (parity ^ 1)] = 0u; } }   // next step's slots
+    unsigned long long st_pairs = 0, st_whole = 0;   // candidate counters: [block][2] running totals, one writer per slot (stream order)
+    if (tid == 0) { st_pairs = stats[2 * blockIdx.x]; st_whole = stats[2 * blockIdx.x + 1]; }
     if (tid < 32) best[tid] = (int)0x80000000;
     // TD: lanes 0..7 of each wave hold action / reward / done / output bias of the wave's eight samples; zq[i] = Q(s,a) before the tanh
     const int td_lane = tid & 63, td_w = tid >> 6;
@@ -1468,9 +1474,9 @@ __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restri
     }
     __syncthreads();
     if (tid < 32 && ok) zmax[b] = float_from_key(best[sl]);
-    if (tid == 0) {
-        atomicAdd(&stats[2], (unsigned long long)(singles + wholes));
-        atomicAdd(&stats[3], (unsigned long long)wholes);
+    if (tid == 0) {                                  // this block's own running totals (512 same-address atomics per launch cost the
+        stats[2 * blockIdx.x] = st_pairs + (unsigned long long)(singles + wholes);      // step 5 us)
+        stats[2 * blockIdx.x + 1] = st_whole + (unsigned long long)wholes;
     }
     if (TD) {
         // the rows for the top hidden delta (L2-hot: read a moment ago / shared by every sample with the same action), all in flight
@@ -1759,6 +1765,20 @@ static SlotSrc explicit_slots(const int32_t* slots) {
 
 // One forward chain of a launch group: a_1 .. a_{nl-1} of `net` for n packed boards; outs[l] receives a_{l+1} in fp32 (may be
 // nullptr per chain in bf16 mode when only the next layer reads it), outs_bf[l] its bf16 bits (bf16 Q-net only).
+// totals of the per-block candidate counters (synchronises the device)
+static int screen_stat_sums(xq_dqn* d, unsigned long long sums[2]) {
+    sums[0] = d->scr_carry[0]; sums[1] = d->scr_carry[1];
+    if (!d->scr_stats) return XQ_OK;
+    std::vector<unsigned long long> h((size_t)2 * d->scr_stat_blocks);
+    XQ_HIP(hipDeviceSynchronize());
+    XQ_HIP(hipMemcpy(h.data(), d->scr_stats, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < d->scr_stat_blocks; ++i) { sums[0] += h[2 * i]; sums[1] += h[2 * i + 1]; }
+    return XQ_OK;
+}
+static void screen_stat_sums_of(const xq_dqn* d, const unsigned long long* h, unsigned long long sums[2]) {
+    sums[0] = d->scr_carry[0]; sums[1] = d->scr_carry[1];
+    for (int i = 0; i < d->scr_stat_blocks; ++i) { sums[0] += h[2 * i]; sums[1] += h[2 * i + 1]; }
+}
 // buffers of the screened maximum (xq_dqn_set_qmax_mode), allocated on first use
 static int ensure_screen_capacity(xq_dqn* d, int n) {
     const int NO = d->nout(), Hl = d->hlast();
@@ -1768,10 +1788,6 @@ static int ensure_screen_capacity(xq_dqn* d, int n) {
         XQ_HIP(hipMemset(d->scr_wb, 0, wrows * Hl * sizeof(uint16_t)));
         XQ_HIP(hipMalloc(&d->scr_wmax, 6 * sizeof(unsigned)));
         XQ_HIP(hipMemset(d->scr_wmax, 0, 6 * sizeof(unsigned)));
-        XQ_HIP(hipMalloc(&d->scr_stats, 4 * sizeof(unsigned long long)));
-        XQ_HIP(hipMemset(d->scr_stats, 0, 4 * sizeof(unsigned long long)));
-        XQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->scr_guard_host), 4 * sizeof(unsigned long long), hipHostMallocDefault));
-        memset(d->scr_guard_host, 0, 4 * sizeof(unsigned long long));
         XQ_HIP(hipEventCreateWithFlags(&d->scr_guard_ev, hipEventDisableTiming));
         d->scr_static_net = -1;
     }
@@ -1790,6 +1806,19 @@ static int ensure_screen_capacity(xq_dqn* d, int n) {
         if (d->scr_na) XQ_HIP(hipFree(d->scr_na));
         XQ_HIP(hipMalloc(&d->scr_R, (size_t)((NO + 63) / 64) * rows * sizeof(float)));       // at most one range per 64-row chunk
         XQ_HIP(hipMalloc(&d->scr_na, rows * sizeof(float)));
+        // candidate counters: one pair per refine block (32 samples); the totals of the array it replaces are carried on the host
+        if (d->scr_stats) {
+            unsigned long long sums[2];
+            XQ_TRY(screen_stat_sums(d, sums));
+            d->scr_carry[0] = sums[0]; d->scr_carry[1] = sums[1];
+            XQ_HIP(hipFree(d->scr_stats)); XQ_HIP(hipHostFree(d->scr_guard_host));
+            d->scr_guard_pending = false;
+        }
+        d->scr_stat_blocks = (int)(rows / kRefineSamples);
+        XQ_HIP(hipMalloc(&d->scr_stats, (size_t)2 * d->scr_stat_blocks * sizeof(unsigned long long)));
+        XQ_HIP(hipMemset(d->scr_stats, 0, (size_t)2 * d->scr_stat_blocks * sizeof(unsigned long long)));
+        XQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->scr_guard_host), (size_t)2 * d->scr_stat_blocks * sizeof(unsigned long long), hipHostMallocDefault));
+        memset(d->scr_guard_host, 0, (size_t)2 * d->scr_stat_blocks * sizeof(unsigned long long));
         d->scr_cap = n;
     }
     return XQ_OK;
@@ -2464,12 +2493,9 @@ int xq_dqn_set_qmax_mode(xq_dqn* d, int mode) {
 
 int xq_dqn_qmax_stats(xq_dqn* d, uint64_t stats[4]) {
     if (!d || !stats) return fail(XQ_ERR_INVALID_ARGUMENT, "null");
-    unsigned long long h[4] = {0, 0, 0, 0};
-    if (d->scr_stats) {
-        XQ_HIP(hipDeviceSynchronize());
-        XQ_HIP(hipMemcpy(h, d->scr_stats, sizeof h, hipMemcpyDeviceToHost));
-    }
-    stats[0] = d->scr_host_steps; stats[1] = d->scr_host_samples; stats[2] = h[2]; stats[3] = h[3];
+    unsigned long long h[2] = {0, 0};
+    XQ_TRY(screen_stat_sums(d, h));
+    stats[0] = d->scr_host_steps; stats[1] = d->scr_host_samples; stats[2] = h[0]; stats[3] = h[1];
     return XQ_OK;
 }
 
@@ -2871,13 +2897,14 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         if (d->scr_guard_pending && d->scr_host_steps % kScreenCheckEvery == 0 && d->scr_host_steps != d->scr_guard_queued_at) {
             XQ_HIP(hipEventSynchronize(d->scr_guard_ev));
             d->scr_guard_pending = false;
-            const unsigned long long* h = d->scr_guard_host;
+            unsigned long long h[2];
+            screen_stat_sums_of(d, d->scr_guard_host, h);
             const double ds = (double)(d->scr_guard_samples - d->scr_seen[0]);
-            if (ds > 0 && ((double)(h[2] - d->scr_seen[1]) > kScreenMaxPairs * ds || (double)(h[3] - d->scr_seen[2]) > kScreenMaxWhole * ds)) {
+            if (ds > 0 && ((double)(h[0] - d->scr_seen[1]) > kScreenMaxPairs * ds || (double)(h[1] - d->scr_seen[2]) > kScreenMaxWhole * ds)) {
                 d->scr_hold = kScreenHoldSteps;
                 d->scr_fallbacks += 1;
             }
-            d->scr_seen[0] = d->scr_guard_samples; d->scr_seen[1] = h[2]; d->scr_seen[2] = h[3];
+            d->scr_seen[0] = d->scr_guard_samples; d->scr_seen[1] = h[0]; d->scr_seen[2] = h[1];
         }
         if (d->scr_hold > 0) { --d->scr_hold; screened = false; }
     }
@@ -2992,7 +3019,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         }
         d->scr_host_steps += 1; d->scr_host_samples += (unsigned long long)n;
         if (d->scr_host_steps % kScreenCheckEvery == 0 && !d->scr_guard_pending) {
-            XQ_HIP(hipMemcpyAsync(d->scr_guard_host, d->scr_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d->cur));
+            XQ_HIP(hipMemcpyAsync(d->scr_guard_host, d->scr_stats, (size_t)2 * d->scr_stat_blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, d->cur));
             XQ_HIP(hipEventRecord(d->scr_guard_ev, d->cur));
             d->scr_guard_pending = true;
             d->scr_guard_samples = d->scr_host_samples;
