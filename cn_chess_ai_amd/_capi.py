@@ -124,6 +124,7 @@ PROTOTYPES = {
     "xq_dqn_get_params": [_vp, _i, _pd, _pd],
     "xq_dqn_forward": [_vp, _i, _pd, _i, _pd],
     "xq_dqn_forward_boards_dev": [_vp, _i, _vp, _i, _i, _vp, _i],
+    "xq_dqn_select_q_dev": [_vp, _vp, _i, _vp],
     "xq_dqn_backpropagate": [_vp, _pd, _pd, _i, _d, _d, _i],
     "xq_dqn_update_target": [_vp],
     "xq_dqn_save_model": [_vp, C.c_char_p],

@@ -67,6 +67,12 @@ struct xq_dqn {
     float* sel_acts[XQ_MAX_LAYERS] = {nullptr};
     float* sel_q90 = nullptr;
     int sel_cap = 0;
+    // layer-0 sums of the select chain kept from ply to ply (xq_dqn_set_l0_derive, fp32 net): while the online weights do not change
+    // — the plies of one update — the next ply's sums are the kept ones minus the rows of the squares that changed plus the rows of
+    // what stands there now (l0_select_kernel); `sel_z1_boards` / `sel_z1_n` = whose boards the kept state belongs to
+    float* sel_z1 = nullptr;  uint32_t* sel_prev_boards = nullptr;  int sel_z1_cap = 0;
+    bool sel_z1_valid = false;  const uint32_t* sel_z1_boards = nullptr;  int sel_z1_n = 0;
+    int sel_calls = 0;  bool sel_keep_pays = false;       // select calls since the last parameter update; the last period had >= 2
     float* qh_slabs[2] = {nullptr, nullptr};    // k-slabs of the select head (handle stream / any other stream)
     size_t qh_cap[2] = {0, 0};
     bool small_tiles = false;                   // force 64x64 GEMM tiles (<= 80 VGPRs: fits beside the persistent GEMM)
@@ -483,6 +489,80 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
             if (out) out[(long long)b * H + col] = t;
         }
     }
+}
+
+// Layer 0 of the SELECT chain with its sums kept between plies (one wave per game, fp32): a_1 = tanh(z_1), z_1 = b_0 + sum of the rows of
+// the occupied squares.  derive != 0 and at most 8 squares differ from the board this game showed last time (a move changes two; a
+// game that ended shows the start position: dozens): z_1 = kept z_1 - rows of what stood on the changed squares + rows of what
+// stands there now, ascending square order — 4 row reads instead of ~25.  Otherwise the full sum in l0_forward_kernel's order.
+// Either way z_1 and the board are kept for the next ply.  The kept sums are only valid while W0 / b0 do not change (the host
+// drops them on every parameter update), i.e. across the plies of one update (bench --config 4: three of four plies).
+__global__ __launch_bounds__(256) void l0_select_kernel(const uint32_t* __restrict__ boards, uint32_t* __restrict__ prev_boards,
+                                                        const float* __restrict__ W0T, const float* __restrict__ b0, float* __restrict__ z1,
+                                                        float* __restrict__ out, int n, int H, int derive) {
+    __shared__ int rows[4][96];
+    __shared__ int dpair[4][8][2];
+    const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int b = (int)blockIdx.x * 4 + wid;
+    if (b >= n) return;
+    const uint32_t* bw = boards + (long long)b * kBoardWords;
+    uint32_t* pw = prev_boards + (long long)b * kBoardWords;
+    const int s0 = lane, s1 = 64 + lane;
+    const uint32_t n0 = (bw[s0 >> 3] >> (4 * (s0 & 7))) & 15u;
+    const uint32_t n1 = s1 < kSquares ? (bw[s1 >> 3] >> (4 * (s1 & 7))) & 15u : 0u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int nd = 99, cnt = 0;
+    if (derive) {
+        const uint32_t p0 = (pw[s0 >> 3] >> (4 * (s0 & 7))) & 15u;
+        const uint32_t p1 = s1 < kSquares ? (pw[s1 >> 3] >> (4 * (s1 & 7))) & 15u : 0u;
+        const unsigned long long d0 = __ballot(p0 != n0), d1 = __ballot(p1 != n1);
+        nd = __popcll(d0) + __popcll(d1);
+        if (nd <= 8) {
+            if (p0 != n0) { const int k = __popcll(d0 & below); dpair[wid][k][0] = p0 ? s0 * 14 + (int)p0 - 1 : -1; dpair[wid][k][1] = n0 ? s0 * 14 + (int)n0 - 1 : -1; }
+            if (p1 != n1) { const int k = __popcll(d0) + __popcll(d1 & below); dpair[wid][k][0] = p1 ? s1 * 14 + (int)p1 - 1 : -1; dpair[wid][k][1] = n1 ? s1 * 14 + (int)n1 - 1 : -1; }
+        }
+    }
+    if (nd > 8) {
+        const unsigned long long m0 = __ballot(n0 != 0), m1 = __ballot(n1 != 0);
+        const int c0 = __popcll(m0);
+        if (n0) rows[wid][__popcll(m0 & below)] = s0 * 14 + (int)n0 - 1;
+        if (n1) rows[wid][c0 + __popcll(m1 & below)] = s1 * 14 + (int)n1 - 1;
+        cnt = c0 + __popcll(m1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int col = lane * 4; col < H; col += 256) {
+        float4 acc;
+        if (nd <= 8) {
+            acc = *reinterpret_cast<const float4*>(z1 + (long long)b * H + col);
+            for (int k = 0; k < nd; ++k) {            // wave-uniform
+                const int ro = dpair[wid][k][0], ri = dpair[wid][k][1];
+                if (ro >= 0) { const float4 w = *reinterpret_cast<const float4*>(W0T + (long long)ro * H + col); acc.x -= w.x; acc.y -= w.y; acc.z -= w.z; acc.w -= w.w; }
+                if (ri >= 0) { const float4 w = *reinterpret_cast<const float4*>(W0T + (long long)ri * H + col); acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w; }
+            }
+        } else {
+            acc = *reinterpret_cast<const float4*>(b0 + col);
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {
+                const float4 w0 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i] * H + col);
+                const float4 w1 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i + 1] * H + col);
+                const float4 w2 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i + 2] * H + col);
+                const float4 w3 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i + 3] * H + col);
+                acc.x = ((acc.x + w0.x) + w1.x) + w2.x + w3.x;
+                acc.y = ((acc.y + w0.y) + w1.y) + w2.y + w3.y;
+                acc.z = ((acc.z + w0.z) + w1.z) + w2.z + w3.z;
+                acc.w = ((acc.w + w0.w) + w1.w) + w2.w + w3.w;
+            }
+            for (; i < cnt; ++i) {
+                const float4 w = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i] * H + col);
+                acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
+            }
+        }
+        *reinterpret_cast<float4*>(z1 + (long long)b * H + col) = acc;
+        *reinterpret_cast<float4*>(out + (long long)b * H + col) = make_float4(tanhf(acc.x), tanhf(acc.y), tanhf(acc.z), tanhf(acc.w));
+    }
+    if (lane < kBoardWords) pw[lane] = bw[lane];
 }
 
 // block -> square: the squares of the start position first.  A block's run time grows with the number of samples that have a piece on
@@ -1834,12 +1914,21 @@ struct ChainJob {
     bool last_bf_frag;          //   ... written in MFMA B-fragment order (scr_afrag_index) for screen_top2_kernel
     float* head_slabs;          // fp32 net, one chain, >= 2 hidden layers: != nullptr => the select head's k-slabs [hlast / 64][n][96] come
                                 //   out of the last hidden product (EPI_HEAD); the last activations are stored only if outs[nl-2] != nullptr
+    int sel_keep;               // fp32 net, one chain: 1 = layer 0 through l0_select_kernel (sums kept in d->sel_z1 for the next ply),
+                                //   2 = ... and derived from the sums kept last time
 };
 // Up to three chains run in the same launches: one gather grid with blockIdx.y = chain, grouped GEMMs with blockIdx.z = chain.
 static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src, int n, const ShadowJob* shadow = nullptr) {
     if (d->L[0] != kStateSize) return fail(XQ_ERR_INVALID_ARGUMENT, "board input needs layer_sizes[0] == 1260 (got %d)", d->L[0]);
     if (njobs < 1 || njobs > kMaxChains) return fail(XQ_ERR_INVALID_ARGUMENT, "1..3 forward chains per launch group");
     const bool bf = d->bf16();
+    if (njobs == 1 && jobs[0].sel_keep && !bf && !shadow && !src.implicit && !src.slots) {
+        const int H = d->L[1];
+        ProfScope ps(d, "l0_forward_gather", 2.0 * n * 32 * H, (double)n * (96 + (jobs[0].sel_keep == 2 ? 4.0 : 32.0) * H * 4 + H * 12));
+        hipLaunchKernelGGL(l0_select_kernel, dim3((n + 3) / 4), dim3(256), 0, d->cur, jobs[0].boards, d->sel_prev_boards, d->w0t(jobs[0].net),
+                           d->bl(jobs[0].net, 0), d->sel_z1, jobs[0].outs[0], n, H, jobs[0].sel_keep == 2 ? 1 : 0);
+        XQ_HIP(hipGetLastError());
+    } else
     {
         const int H = d->L[1];
         L0Jobs J; memset(&J, 0, sizeof J);
@@ -2028,6 +2117,22 @@ int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev
         q = d->q90;
     }
     ChainJob job{XQ_NET_ONLINE, boards_dev, outs, outs_bf, nullptr};
+    // layer-0 sums kept from ply to ply (xq_dqn_set_l0_derive) — when that pays: keeping costs 16 MB of stores per call, deriving saves
+    // ~20 row reads per board, so it is used from the second call of an update period on and, once a period had several calls, from
+    // its first (one ply per update, the headline: never; bench --config 4, four plies: 0.976 -> 0.964 ms)
+    d->sel_calls += 1;
+    if (d->l0_derive && !bf && (d->L[1] & 3) == 0 && (d->sel_keep_pays || d->sel_calls >= 2)) {
+        if (n > d->sel_z1_cap) {
+            XQ_HIP(hipDeviceSynchronize());
+            if (d->sel_z1) XQ_HIP(hipFree(d->sel_z1));
+            if (d->sel_prev_boards) XQ_HIP(hipFree(d->sel_prev_boards));
+            XQ_HIP(hipMalloc(&d->sel_z1, (size_t)n * d->L[1] * sizeof(float)));
+            XQ_HIP(hipMalloc(&d->sel_prev_boards, (size_t)n * kBoardWords * sizeof(uint32_t)));
+            d->sel_z1_cap = n; d->sel_z1_valid = false;
+        }
+        job.sel_keep = (d->sel_z1_valid && d->sel_z1_boards == boards_dev && d->sel_z1_n == n) ? 2 : 1;
+        d->sel_z1_valid = true; d->sel_z1_boards = boards_dev; d->sel_z1_n = n;
+    }
     // fp32 net with >= 2 hidden layers, whole 64 x 64 tiles, the batch sizes q_head splits into k-slabs: the head rides on the last hidden
     // product (same slabs, same bits) — its operand never goes to HBM and back (2 x 17 MB at 8192 x 512), one launch fewer per ply
     const int Hl = d->hlast();
@@ -2387,7 +2492,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     hipStreamSynchronize(d->stream);
     for (int i = 0; i < 2; ++i) { hipFree(d->params[i]); hipFree(d->tacts[i]); }
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts[l]); hipFree(d->deltas[l]); hipFree(d->sel_acts[l]); }
-    hipFree(d->gboards); hipFree(d->dsc); hipFree(d->act_mb); hipFree(d->q90); hipFree(d->sel_q90); hipFree(d->partial); hipFree(d->zmax); hipFree(d->zidx); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
+    hipFree(d->gboards); hipFree(d->dsc); hipFree(d->act_mb); hipFree(d->q90); hipFree(d->sel_q90); hipFree(d->sel_z1); hipFree(d->sel_prev_boards); hipFree(d->partial); hipFree(d->zmax); hipFree(d->zidx); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
     hipFree(d->grads_td); hipFree(d->grads_full); hipFree(d->slabs); hipFree(d->bias_work); hipFree(d->xdense); hipFree(d->qfull); hipFree(d->tfull);
     hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
     d->prof.collect();
@@ -2431,6 +2536,7 @@ int xq_dqn_set_params(xq_dqn* d, int net, const double* w, const double* b) {
     XQ_HIP(hipStreamSynchronize(d->stream));
     XQ_HIP(hipMemcpy(d->params[net], p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
     if (d->scr_static_net == net) d->scr_static_net = -1;       // screening shadow: rows >= 96 are no longer what it holds
+    if (net == XQ_NET_ONLINE) d->sel_z1_valid = false;          // kept layer-0 sums of the select chain belong to the old weights
     return refresh_shadow(d, net);
 }
 
@@ -2467,6 +2573,7 @@ static int refresh_shadow(xq_dqn* d, int net) {
 }
 
 int xq_dqn_set_l0_derive(xq_dqn* d, int on) {
+    if (d) d->sel_z1_valid = false;
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
     d->l0_derive = on != 0;
     return XQ_OK;
@@ -2583,6 +2690,15 @@ int xq_dqn_forward_boards_dev(xq_dqn* d, int net, const uint32_t* boards_dev, in
                   d->bf16() ? outs_bf[d->nl - 2] : nullptr);
 }
 
+int xq_dqn_select_q_dev(xq_dqn* d, const uint32_t* boards_dev, int n, float* q_dev) {
+    if (!d || !boards_dev || !q_dev || n <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_select_q_dev: bad argument");
+    float* q = nullptr;
+    int stride = 0;
+    XQ_TRY(dqn_q90_boards(d, boards_dev, n, &q, &stride, nullptr, nullptr));
+    XQ_HIP(hipMemcpyAsync(q_dev, q, (size_t)n * 96 * sizeof(float), hipMemcpyDeviceToDevice, d->stream));
+    return XQ_OK;
+}
+
 int xq_dqn_backpropagate(xq_dqn* d, const double* states, const double* targets, int n, double lr, double grad_scale, int mode) {
     if (!d || !states || !targets || n <= 0) return fail(XQ_ERR_INVALID_ARGUMENT, "Input size does not match network input layer size.");
     if (mode != XQ_BACKPROP_REFERENCE && mode != XQ_BACKPROP_TEXTBOOK) return fail(XQ_ERR_INVALID_ARGUMENT, "bad backprop mode");
@@ -2631,6 +2747,7 @@ int xq_dqn_backpropagate(xq_dqn* d, const double* states, const double* targets,
     XQ_TRY(sgd_apply(d, t, lr * grad_scale));
     XQ_TRY(refresh_shadow(d, XQ_NET_ONLINE));          // bf16 Q-net: every later bf16 forward must see the updated weights
     if (d->scr_static_net == XQ_NET_ONLINE) d->scr_static_net = -1;    // dense update: every output row changed (screening shadow)
+    d->sel_z1_valid = false;
     XQ_HIP(hipStreamSynchronize(d->stream));
     return XQ_OK;
 }
@@ -3205,6 +3322,8 @@ int xq_dqn_apply_grads(xq_dqn* d, double lr, double grad_scale) {
     t.dst[k] = d->bl(0, 0); t.src[k] = G + d->g_bh[0]; t.len[k] = (long long)(d->bo[d->nl - 1]); take(d->pend_bh); ++k;
     t.dst[k] = d->bl(0, d->nl - 1); t.src[k] = G + d->g_bout; t.len[k] = 96; take(d->pend_bout); ++k;
     t.nseg = k;
+    d->sel_z1_valid = false;                          // W0 / b0 change: the select chain's kept layer-0 sums are stale
+    d->sel_keep_pays = d->sel_calls >= 2; d->sel_calls = 0;
     return sgd_apply(d, t, lr * grad_scale);
 }
 

@@ -138,6 +138,15 @@ class DQN:
         torch.cuda.synchronize()
         return q
 
+    def select_q(self, env):
+        """Q(s)[0..95] of every board of a VecEnv through the select chain of the self-play loop (xq_dqn_select_q_dev)."""
+        import torch
+        q = torch.empty((env.n_games, 96), dtype=torch.float32, device="cuda")
+        call("xq_dqn_select_q_dev", self._h, C.c_void_p(env.boards_dev()), env.n_games, C.c_void_p(q.data_ptr()))
+        call("xq_stream_synchronize", None)
+        torch.cuda.synchronize()
+        return q
+
     def td_grads_replay(self, replay, batch, td_net=_capi.TD_ONLINE_NET, mode=_capi.BACKPROP_REFERENCE):
         """Gradients of one TD minibatch taken from a replay ring (batch = 0: the whole filled ring, in order)."""
         call("xq_dqn_td_grads_replay", self._h, replay.handle, int(batch), int(td_net), int(mode))

@@ -216,7 +216,10 @@ int xq_dqn_set_precision(xq_dqn* d, int precision);
  * scratch, dqn.cu:199-260).  0 (default): the sum over the occupied squares of s' in ascending square order, the reference's
  * i-ascending accumulation with the zeros skipped.  1: z1(s') = z1(s) - rows of the squares that changed + rows of what stands there
  * now (two squares for a move; boards more than 8 squares apart are gathered in full): one gather instead of two, a DIFFERENT
- * summation order (differences ~1e-7 on the activations, far inside the 1e-4 budget on Q).  bench.py switches it on. */
+ * summation order (differences ~1e-7 on the activations, far inside the 1e-4 budget on Q).  bench.py switches it on.
+ * The same switch covers the select chain of the self-play loop (xq_dqn_select_q_dev / xq_trainer_collect, fp32 net): its layer-0
+ * sums are kept per game, and while the online parameters do not change — the plies of one update — the next ply's sums are
+ * derived from the kept ones the same way (used when an update period has several plies; a game that ended is summed in full). */
 int xq_dqn_set_l0_derive(xq_dqn* d, int on);
 /* How the gradient half of xq_dqn_td_grads is queued (no upstream analogue: dqn.cu:323-467 launches one kernel per layer and waits
  * for each).  1 (default): as fused launches on the handle's stream — per hidden layer below the top one ONE grid that holds the blocks
@@ -249,6 +252,13 @@ int xq_dqn_forward(xq_dqn* d, int which_net, const double* states_host, int n, d
  * q_dev: [n][ldq] fp32, first `n_out` outputs per row (n_out <= layer_sizes[last]). */
 int xq_dqn_forward_boards_dev(xq_dqn* d, int which_net, const uint32_t* boards_dev, int n, int n_out,
                               float* q_dev, int ldq);
+/* Q(s)[0..95] of the online net for n packed boards in HBM, through the SELECT chain of the self-play loop (what xq_trainer_collect
+ * feeds the env kernel; DQN::selectAction reads q[action.to] only, dqn.cpp:47) -> q_dev [n][96] fp32.  Differs from
+ * xq_dqn_forward_boards_dev(.., n_out = 96, ..) only in how it gets there: from 2048 boards on the head rides on the last hidden
+ * product, and with xq_dqn_set_l0_derive the layer-0 sums of these boards are KEPT — while the online parameters do not change
+ * (the plies of one update), the next call for the same board array derives them from the kept ones (rows of the squares that
+ * changed out, rows of what stands there now in; boards more than 8 squares apart are summed in full). */
+int xq_dqn_select_q_dev(xq_dqn* d, const uint32_t* boards_dev, int n, float* q_dev);
 /* DQN::backpropagate(state, target, lr) / NeuralNetwork::backpropagate (dqn.cpp:59-62, dqn.cu:323-467) for a batch of
  * n (state, target) pairs: gradients of all n samples are taken at the pre-update weights, summed, scaled by
  * grad_scale and applied once (n = 1, grad_scale = 1 is exactly the upstream call).  mode = XQ_BACKPROP_*. */

@@ -713,3 +713,42 @@ def test_td_tail_launches_equal_the_two_stream_path_bitwise(xq, sizes, mode, n, 
     wi, bi = xo.init_weights(sizes, 31)
     assert np.abs(w1 - wi).max() > 0                # ... and the updates did move the weights
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes,n", [(CFG2_NET, 2048), ((1260, 512, 512, 512, 8100), 2048), (REF_NET, 300)])
+def test_select_chain_layer0_sums_kept_between_plies(xq, sizes, n):
+    """xq_dqn_set_l0_derive also covers the select chain (xq_dqn_select_q_dev = what xq_trainer_collect runs): its layer-0 sums are kept
+    per game, and while the online parameters do not change the next call derives them from the kept ones (two squares per move; a
+    game that ended shows the start position and is summed in full).  First call and every call after a parameter update: the
+    full sum in the direct gather's order => the same bits as xq_dqn_forward_boards_dev.  Derived calls: a different summation
+    order, ~1e-7.  Several plies in a row (the rounding of successive derivations adds up), games that end in between, a parameter
+    update in between."""
+    env = xq.VecEnv(n, seed=17)
+    for _ in range(140):                            # mid-game: some games end (and reset) during the plies below
+        env.selfplay_step(None)
+    d, w, b = make_net(xq, sizes, seed=5)
+    d.set_l0_derive(True)
+    q_full = d.q_boards(env, 96).cpu().numpy()
+    q_sel = d.select_q(env).cpu().numpy()
+    assert np.array_equal(q_sel, q_full)            # nothing kept yet: full sums
+    worst = 0.0
+    for ply in range(6):
+        env.selfplay_step(None)
+        q_full = d.q_boards(env, 96).cpu().numpy()
+        q_sel = d.select_q(env).cpu().numpy()       # derived from the sums kept by the previous call
+        worst = max(worst, float(np.abs(q_sel - q_full).max()))
+        assert np.abs(q_sel - q_full).max() < 2e-6, ply
+    assert worst > 0 or sizes is REF_NET            # ... and it really was the other summation order somewhere
+    S, _ = env.get_state()
+    for i in range(0, n, max(1, n // 9)):
+        want = xo.nn_forward(sizes, w, b, xo.state_repr(xo.board_from(S[i])))[:96]
+        assert np.abs(q_sel[i] - want).max() < 2e-5
+    # a parameter update drops the kept sums: the next call is a full sum again, bit-identical to the direct gather
+    res = env.selfplay_step(None)
+    S2, _ = env.get_state()
+    d.set_fused_apply(True)
+    d.td_update(S, S2, (res["action"] % 90).astype(np.int32), (res["reward"] / 100.0).astype(np.float32), res["done"], td_net=0, mode=0,
+                learning_rate=0.05, grad_scale=1.0 / n)
+    assert np.array_equal(d.select_q(env).cpu().numpy(), d.q_boards(env, 96).cpu().numpy())
+    env.close(); d.close()
