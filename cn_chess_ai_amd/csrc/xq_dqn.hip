@@ -832,6 +832,42 @@ __global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
             o.z = delta * vv.z * (1.f - av.z * av.z); o.w = delta * vv.w * (1.f - av.w * av.w);
         }
         *reinterpret_cast<float4*>(dtop + (long long)b * 256 + lane * 4) = o;
+    } else if (H == 512 && !X.wout_bf && !X.double_dqn && n_partial <= 4) {
+        // fp32 net, 512-wide last hidden layer (BASELINE configs[3]): the 256-wide path with two 16-byte pieces per lane and row
+        // (columns 4 lane + 256 v); per-lane partial = piece 0 + piece 1, then the same shuffle tree
+        const int ac = live ? a : 0;
+        const bool has_view = live && a < view_kmax;
+        float4 av[2], wv[2], vv[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            av[v] = *reinterpret_cast<const float4*>(ar + v * 256 + lane * 4);
+            wv[v] = *reinterpret_cast<const float4*>(w_out + (long long)ac * 512 + v * 256 + lane * 4);
+            vv[v] = has_view ? *reinterpret_cast<const float4*>(view + (long long)a * view_ld + v * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float zm = partial[b];
+#pragma unroll
+        for (int t = 1; t < 4; ++t) zm = fmaxf(zm, partial[(long long)min(t, n_partial - 1) * n + b]);
+        const float bo = b_out[ac], r = reward[s];
+        const bool dn = done[s] != 0;
+        const float isw = X.is_w ? X.is_w[b] / X.is_wmax[0] : 1.f;
+        float z = ((av[0].x * wv[0].x + av[0].y * wv[0].y) + (av[0].z * wv[0].z + av[0].w * wv[0].w)) +
+                  ((av[1].x * wv[1].x + av[1].y * wv[1].y) + (av[1].z * wv[1].z + av[1].w * wv[1].w));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+        if (live) {
+            q = tanhf(z + bo);
+            y = dn ? r : r + gamma * tanhf(zm);
+            delta = (q - y) * (1.f - q * q) * isw;
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has_view) {
+                o.x = delta * vv[v].x * (1.f - av[v].x * av[v].x); o.y = delta * vv[v].y * (1.f - av[v].y * av[v].y);
+                o.z = delta * vv[v].z * (1.f - av[v].z * av[v].z); o.w = delta * vv[v].w * (1.f - av[v].w * av[v].w);
+            }
+            *reinterpret_cast<float4*>(dtop + (long long)b * 512 + v * 256 + lane * 4) = o;
+        }
     } else if (H == 512 && X.wout_bf && n_partial <= 4 && (!X.double_dqn || X.wout_t_bf)) {
         // bf16 net, 512-wide last hidden layer (BASELINE configs[4]): the same idea — every load that depends only on (b, s, a) issued up
         // front, 8 columns per lane as 16-byte loads; Double DQN adds ONE dependent round trip (the target net's row of the arg-max)
