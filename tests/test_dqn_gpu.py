@@ -752,3 +752,37 @@ def test_select_chain_layer0_sums_kept_between_plies(xq, sizes, n):
                 learning_rate=0.05, grad_scale=1.0 / n)
     assert np.array_equal(d.select_q(env).cpu().numpy(), d.q_boards(env, 96).cpu().numpy())
     env.close(); d.close()
+
+
+@pytest.mark.gpu
+def test_replay_draws_are_ordered_against_their_consumer_across_streams(xq):
+    """A ring with a stream of its own draws its slot list there; xq_dqn_td_grads_replay reads the list on the Q-net's stream.  Drawing
+    again while the previous TD step is still queued used to overwrite the list under it (found by the overlapped-trainer
+    composition once the step enqueued faster).  The library orders the two itself: a loop that never synchronises between an
+    update and the next draw must give the bits of the same loop with a device synchronisation after every update."""
+    import torch
+    sizes, n, cap, iters = CFG2_NET, 4096, 1 << 15, 8
+    env = xq.VecEnv(n, seed=3)
+    rp0 = xq.ReplayBuffer(cap, seed=11)
+    for _ in range(8):                                   # fill the ring with random plies
+        env.selfplay_step_dev(0, 96, 0.1, replay=rp0)
+    torch.cuda.synchronize()
+    rp0.close()
+    out = []
+    for sync in (True, False):
+        env2 = xq.VecEnv(n, seed=3)
+        rp = xq.ReplayBuffer(cap, seed=11)
+        for _ in range(8):
+            env2.selfplay_step_dev(0, 96, 0.1, replay=rp)
+        torch.cuda.synchronize()
+        d, w, b = make_net(xq, sizes, seed=2)
+        for it in range(iters):
+            rp.sample(n)                                 # own stream of the ring; the list is consumed on the Q-net's stream
+            d.td_grads_replay(rp, n, td_net=0, mode=0)
+            d.apply_grads(0.05, 1.0 / n)
+            if sync:
+                torch.cuda.synchronize()
+        out.append(d.get_params())
+        d.close(); rp.close(); env2.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    env.close()
