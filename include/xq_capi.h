@@ -12,6 +12,10 @@
  *   - pointers named *_host are caller-owned host memory, *_dev are device (HBM) pointers on the handle's device;
  *   - each handle runs on ONE hipStream_t (passed as void*; NULL = a stream the handle creates); calls are
  *     asynchronous on that stream unless they return data to the host, in which case they synchronise that stream;
+ *   - handles that exchange DEVICE data (an env writing a replay ring, a Q-net reading it, Q-values fed to an env) are ordered
+ *     by stream order when they were created on the same stream — what xq_trainer does, and the simplest way to use the ABI.
+ *     Handles on streams of their own are ordered against each other only where an entry point says so (xq_replay_sample);
+ *     otherwise the caller synchronises (xq_stream_synchronize) between producer and consumer;
  *   - handles are not thread-safe; one GPU per process (one rank per GPU under torch.distributed / RCCL).
  *
  * Encodings
