@@ -389,8 +389,10 @@ int env_selfplay_launch(xq_env* e, const float* q90_dev, int q_stride, uint32_t 
         P.rp_write_base = replay->write_pos;
     }
     const int blocks = (e->n + 3) / 4;
+    if (replay != nullptr) XQ_TRY(replay_writer_begin(replay, on ? on : e->stream));    // (no-ops when the ring shares this stream)
     hipLaunchKernelGGL(env_kernel<MODE_SELFPLAY>, dim3(blocks), dim3(256), 0, on ? on : e->stream, P);
     XQ_HIP(hipGetLastError());
+    if (replay != nullptr) XQ_TRY(replay_writer_end(replay, on ? on : e->stream));
     if (replay != nullptr) {
         replay->write_pos = (replay->write_pos + e->n) % replay->dev.capacity;
         replay->size = std::min(replay->dev.capacity, replay->size + e->n);

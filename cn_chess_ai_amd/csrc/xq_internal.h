@@ -41,6 +41,10 @@ struct xq_replay {
     // with the consumer (the trainer's) records nothing.
     hipEvent_t ev_sampled = nullptr, ev_consumed = nullptr;
     bool sampled_recorded = false, consumed_pending = false;
+    // the same for the prioritized-replay tree: an env step that writes transitions on a stream of its own reads the priority snapshot
+    // of the last rebuild (ev_rebuilt), and the next rebuild reads the priorities that step wrote (ev_written)
+    hipEvent_t ev_rebuilt = nullptr, ev_written = nullptr;
+    bool rebuilt_recorded = false, written_pending = false;
     // prioritized replay (build-defined, BASELINE configs[4]): radix-32 sum tree, level 0 = dev.prio
     struct Per {
         bool enabled = false;
@@ -174,6 +178,8 @@ int replay_before_draw(xq_replay* r, hipStream_t draw_stream);
 int replay_after_draw(xq_replay* r, hipStream_t draw_stream);
 int replay_consumer_begin(xq_replay* r, hipStream_t consumer);
 int replay_consumer_end(xq_replay* r, hipStream_t consumer);
+int replay_writer_begin(xq_replay* r, hipStream_t writer);       // env step that writes transitions into the ring
+int replay_writer_end(xq_replay* r, hipStream_t writer);
 // prioritized replay internals used by the trainer (xq_replay.hip)
 int replay_per_rebuild(xq_replay* r, int retire_start, int retire_count, hipStream_t on);
 int replay_per_sample(xq_replay* r, int batch, hipStream_t on);

@@ -152,6 +152,10 @@ static PerTree per_tree(const xq_replay* r) {
 int replay_per_rebuild(xq_replay* r, int retire_start, int retire_count, hipStream_t on) {
     if (!r || !r->per.enabled) return fail(XQ_ERR_INVALID_ARGUMENT, "prioritized replay is not enabled on this ring");
     hipStream_t s = on ? on : r->stream;
+    if (r->written_pending) {    // an env step on a stream of its own wrote the priorities of its transitions: read them behind it
+        XQ_HIP(hipStreamWaitEvent(s, r->ev_written, 0));
+        r->written_pending = false;
+    }
     if (retire_count > 0) {      // slots the next collects overwrite: out of the tree before anything samples them
         hipLaunchKernelGGL(per_fill_kernel, dim3((retire_count + 255) / 256), dim3(256), 0, s, r->dev.prio, retire_start, retire_count,
                            r->dev.capacity, nullptr, 0.f);
@@ -172,6 +176,12 @@ int replay_per_rebuild(xq_replay* r, int retire_start, int retire_count, hipStre
     hipLaunchKernelGGL(per_upper_kernel, dim3(1), dim3(1024), 0, s, T, r->per.scalars, n_counts ? r->per.wave_counts : nullptr, n_counts);
     XQ_HIP(hipGetLastError());
     r->per.wmax_clean = true;                                        // per_upper_kernel zeroed the batch-maximum slot
+    r->rebuilt_recorded = false;
+    if (r->own_stream && s == r->stream) {                           // writers on other streams read the snapshot behind this rebuild
+        if (!r->ev_rebuilt) XQ_HIP(hipEventCreateWithFlags(&r->ev_rebuilt, hipEventDisableTiming));
+        XQ_HIP(hipEventRecord(r->ev_rebuilt, s));
+        r->rebuilt_recorded = true;
+    }
     return XQ_OK;
 }
 
@@ -227,6 +237,18 @@ int replay_consumer_end(xq_replay* r, hipStream_t consumer) {
     if (!r->ev_consumed) XQ_HIP(hipEventCreateWithFlags(&r->ev_consumed, hipEventDisableTiming));
     XQ_HIP(hipEventRecord(r->ev_consumed, consumer));
     r->consumed_pending = true;
+    return XQ_OK;
+}
+
+int replay_writer_begin(xq_replay* r, hipStream_t writer) {
+    if (r->per.enabled && r->rebuilt_recorded && writer != r->stream) XQ_HIP(hipStreamWaitEvent(writer, r->ev_rebuilt, 0));
+    return XQ_OK;
+}
+int replay_writer_end(xq_replay* r, hipStream_t writer) {
+    if (!r->per.enabled || !r->own_stream || writer == r->stream) return XQ_OK;
+    if (!r->ev_written) XQ_HIP(hipEventCreateWithFlags(&r->ev_written, hipEventDisableTiming));
+    XQ_HIP(hipEventRecord(r->ev_written, writer));
+    r->written_pending = true;
     return XQ_OK;
 }
 
@@ -289,6 +311,8 @@ int xq_replay_destroy(xq_replay* r) {
     hipStreamSynchronize(r->stream);
     if (r->ev_sampled) hipEventDestroy(r->ev_sampled);
     if (r->ev_consumed) hipEventDestroy(r->ev_consumed);
+    if (r->ev_rebuilt) hipEventDestroy(r->ev_rebuilt);
+    if (r->ev_written) hipEventDestroy(r->ev_written);
     hipFree(r->dev.boards); hipFree(r->dev.next_boards); hipFree(r->dev.action_to); hipFree(r->dev.reward);
     hipFree(r->dev.done); hipFree(r->slots_dev);
     hipFree(r->dev.prio); hipFree(r->per.leaves); hipFree(r->per.upper); hipFree(r->per.scalars); hipFree(r->per.wave_counts); hipFree(r->per.is_w);

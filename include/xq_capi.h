@@ -14,7 +14,8 @@
  *     asynchronous on that stream unless they return data to the host, in which case they synchronise that stream;
  *   - handles that exchange DEVICE data (an env writing a replay ring, a Q-net reading it, Q-values fed to an env) are ordered
  *     by stream order when they were created on the same stream — what xq_trainer does, and the simplest way to use the ABI.
- *     Handles on streams of their own are ordered against each other only where an entry point says so (xq_replay_sample);
+ *     Handles on streams of their own are ordered against each other only where an entry point says so (xq_replay_sample*: the draw
+ *     against its consumer; xq_replay_per_rebuild against the env steps that write the ring's priorities, both directions);
  *     otherwise the caller synchronises (xq_stream_synchronize) between producer and consumer;
  *   - handles are not thread-safe; one GPU per process (one rank per GPU under torch.distributed / RCCL).
  *
