@@ -156,6 +156,9 @@ int replay_per_rebuild(xq_replay* r, int retire_start, int retire_count, hipStre
         XQ_HIP(hipStreamWaitEvent(s, r->ev_written, 0));
         r->written_pending = false;
     }
+    // ... and the TD step that consumed the last draw on the Q-net's stream writes the TD-error priorities of its samples (the next
+    // draw waits for the same event and clears the flag)
+    if (r->consumed_pending) XQ_HIP(hipStreamWaitEvent(s, r->ev_consumed, 0));
     if (retire_count > 0) {      // slots the next collects overwrite: out of the tree before anything samples them
         hipLaunchKernelGGL(per_fill_kernel, dim3((retire_count + 255) / 256), dim3(256), 0, s, r->dev.prio, retire_start, retire_count,
                            r->dev.capacity, nullptr, 0.f);
