@@ -19,6 +19,7 @@ BACKPROP_REFERENCE, BACKPROP_TEXTBOOK = 0, 1
 TD_ONLINE_NET, TD_TARGET_NET, TD_DOUBLE = 0, 1, 2
 PRECISION_F32, PRECISION_BF16, PRECISION_BF16_FULL = 0, 1, 2
 QMAX_FULL, QMAX_SCREENED = 0, 1
+ORDER_RING_CONTENTS, ORDER_RING_PRIORITIES, ORDER_RING_DRAW, ORDER_TRAINER_PARAMS, ORDER_ALL = 1, 2, 4, 8, 15
 
 STATUS_NAMES = {1: "XQ_ERR_INVALID_ARGUMENT", 2: "XQ_ERR_RUNTIME", 3: "XQ_ERR_NO_DEVICE", 4: "XQ_ERR_IO",
                 5: "XQ_ERR_UNDEFINED_UPSTREAM"}
@@ -75,6 +76,12 @@ PROTOTYPES = {
     "xq_device_count": [_pi],
     "xq_set_device": [_i],
     "xq_stream_synchronize": [_vp],
+    "xq_stream_wait_stream": [_vp, _vp],
+    "xq_debug_stream_delay": [_vp, _i],
+    "xq_debug_set_stream_ordering": [C.c_uint],
+    "xq_env_stream": [_vp, _pvp],
+    "xq_replay_stream": [_vp, _pvp],
+    "xq_dqn_stream": [_vp, _pvp],
     "xq_event_create": [_pvp],
     "xq_event_destroy": [_vp],
     "xq_event_record": [_vp, _vp],

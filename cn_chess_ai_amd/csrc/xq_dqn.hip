@@ -41,6 +41,7 @@ struct xq_dqn {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_delta = nullptr;
     hipEvent_t ev_qmax = nullptr;               // recorded behind the column-max GEMM of the last TD step (trainer: collect starts here)
     float* params[2] = {nullptr, nullptr};
+    uint64_t params_version = 0;                // ++ whenever an operation that rewrites parameters is queued (xq_trainer: is ev_params still current?)
     // bf16 Q-net (xq_dqn_set_precision): bf16 shadow of the WEIGHTS of both nets, same element order as params[] (biases stay fp32);
     // forward kernels read the shadow, the backward pass and the SGD step work on the fp32 master copy and refresh the shadow
     int precision = XQ_PRECISION_F32;
@@ -69,10 +70,15 @@ struct xq_dqn {
     int sel_cap = 0;
     // layer-0 sums of the select chain kept from ply to ply (xq_dqn_set_l0_derive, fp32 net): while the online weights do not change
     // — the plies of one update — the next ply's sums are the kept ones minus the rows of the squares that changed plus the rows of
-    // what stands there now (l0_select_kernel); `sel_z1_boards` / `sel_z1_n` = whose boards the kept state belongs to
-    float* sel_z1 = nullptr;  uint32_t* sel_prev_boards = nullptr;  int sel_z1_cap = 0;
-    bool sel_z1_valid = false;  const uint32_t* sel_z1_boards = nullptr;  int sel_z1_n = 0;
-    int sel_calls = 0;  bool sel_keep_pays = false;       // select calls since the last parameter update; the last period had >= 2
+    // what stands there now (l0_select_kernel); `boards` / `n` = whose boards the kept state belongs to.  One set per stream the chain
+    // runs on — [0] the handle's stream (xq_dqn_select_q_dev), [1] any other (the trainer's collect stream) — like qh_slabs: a query on
+    // the handle's stream neither races with collects in flight nor changes what their next ply derives from
+    struct SelKeep {
+        float* z1 = nullptr;  uint32_t* prev_boards = nullptr;  int cap = 0;
+        bool valid = false;  const uint32_t* boards = nullptr;  int n = 0;
+        int calls = 0;  bool pays = false;                // select calls since the last parameter update; the last period had >= 2
+    } sel_keep[2];
+    void sel_invalidate() { sel_keep[0].valid = sel_keep[1].valid = false; }
     float* qh_slabs[2] = {nullptr, nullptr};    // k-slabs of the select head (handle stream / any other stream)
     size_t qh_cap[2] = {0, 0};
     bool small_tiles = false;                   // force 64x64 GEMM tiles (<= 80 VGPRs: fits beside the persistent GEMM)
@@ -162,6 +168,7 @@ int dqn_fused_apply(const xq_dqn* d) { return d->fused_apply ? 1 : 0; }
 xq_comm* dqn_comm(const xq_dqn* d) { return d->comm; }
 hipStream_t dqn_stream(xq_dqn* d) { return d->stream; }
 hipEvent_t dqn_qmax_event(xq_dqn* d) { return d->ev_qmax; }
+uint64_t dqn_params_version(const xq_dqn* d) { return d->params_version; }
 
 struct ProfScope {
     Profiler& p; hipStream_t s; int h; double flops, bytes;
@@ -1950,7 +1957,7 @@ struct ChainJob {
     bool last_bf_frag;          //   ... written in MFMA B-fragment order (scr_afrag_index) for screen_top2_kernel
     float* head_slabs;          // fp32 net, one chain, >= 2 hidden layers: != nullptr => the select head's k-slabs [hlast / 64][n][96] come
                                 //   out of the last hidden product (EPI_HEAD); the last activations are stored only if outs[nl-2] != nullptr
-    int sel_keep;               // fp32 net, one chain: 1 = layer 0 through l0_select_kernel (sums kept in d->sel_z1 for the next ply),
+    int sel_keep;               // fp32 net, one chain: 1 = layer 0 through l0_select_kernel (sums kept in sel_state->z1 for the next ply),
                                 //   2 = ... and derived from the sums kept last time
 };
 // Up to three chains run in the same launches: one gather grid with blockIdx.y = chain, grouped GEMMs with blockIdx.z = chain.
@@ -1961,8 +1968,9 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
     if (njobs == 1 && jobs[0].sel_keep && !bf && !shadow && !src.implicit && !src.slots) {
         const int H = d->L[1];
         ProfScope ps(d, "l0_forward_gather", 2.0 * n * 32 * H, (double)n * (96 + (jobs[0].sel_keep == 2 ? 4.0 : 32.0) * H * 4 + H * 12));
-        hipLaunchKernelGGL(l0_select_kernel, dim3((n + 3) / 4), dim3(256), 0, d->cur, jobs[0].boards, d->sel_prev_boards, d->w0t(jobs[0].net),
-                           d->bl(jobs[0].net, 0), d->sel_z1, jobs[0].outs[0], n, H, jobs[0].sel_keep == 2 ? 1 : 0);
+        xq_dqn::SelKeep& K = d->sel_keep[d->cur == d->stream ? 0 : 1];
+        hipLaunchKernelGGL(l0_select_kernel, dim3((n + 3) / 4), dim3(256), 0, d->cur, jobs[0].boards, K.prev_boards, d->w0t(jobs[0].net),
+                           d->bl(jobs[0].net, 0), K.z1, jobs[0].outs[0], n, H, jobs[0].sel_keep == 2 ? 1 : 0);
         XQ_HIP(hipGetLastError());
     } else
     {
@@ -2156,18 +2164,22 @@ int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev
     // layer-0 sums kept from ply to ply (xq_dqn_set_l0_derive) — when that pays: keeping costs 16 MB of stores per call, deriving saves
     // ~20 row reads per board, so it is used from the second call of an update period on and, once a period had several calls, from
     // its first (one ply per update, the headline: never; bench --config 4, four plies: 0.976 -> 0.964 ms)
-    d->sel_calls += 1;
-    if (d->l0_derive && !bf && (d->L[1] & 3) == 0 && (d->sel_keep_pays || d->sel_calls >= 2)) {
-        if (n > d->sel_z1_cap) {
+    xq_dqn::SelKeep& K = d->sel_keep[on ? 1 : 0];
+    K.calls += 1;
+    bool kept = false;
+    if (d->l0_derive && !bf && (d->L[1] & 3) == 0 && (K.pays || K.calls >= 2)) {
+        if (n > K.cap) {
             XQ_HIP(hipDeviceSynchronize());
-            if (d->sel_z1) XQ_HIP(hipFree(d->sel_z1));
-            if (d->sel_prev_boards) XQ_HIP(hipFree(d->sel_prev_boards));
-            XQ_HIP(hipMalloc(&d->sel_z1, (size_t)n * d->L[1] * sizeof(float)));
-            XQ_HIP(hipMalloc(&d->sel_prev_boards, (size_t)n * kBoardWords * sizeof(uint32_t)));
-            d->sel_z1_cap = n; d->sel_z1_valid = false;
+            if (K.z1) XQ_HIP(hipFree(K.z1));
+            if (K.prev_boards) XQ_HIP(hipFree(K.prev_boards));
+            K.z1 = nullptr; K.prev_boards = nullptr; K.cap = 0; K.valid = false;
+            XQ_HIP(hipMalloc(&K.z1, (size_t)n * d->L[1] * sizeof(float)));
+            XQ_HIP(hipMalloc(&K.prev_boards, (size_t)n * kBoardWords * sizeof(uint32_t)));
+            K.cap = n;
         }
-        job.sel_keep = (d->sel_z1_valid && d->sel_z1_boards == boards_dev && d->sel_z1_n == n) ? 2 : 1;
-        d->sel_z1_valid = true; d->sel_z1_boards = boards_dev; d->sel_z1_n = n;
+        job.sel_keep = (K.valid && K.boards == boards_dev && K.n == n) ? 2 : 1;
+        K.valid = false;                   // true again once the launch that keeps the sums has been queued
+        kept = true;
     }
     // fp32 net with >= 2 hidden layers, whole 64 x 64 tiles, the batch sizes q_head splits into k-slabs: the head rides on the last hidden
     // product (same slabs, same bits) — its operand never goes to HBM and back (2 x 17 MB at 8192 x 512), one launch fewer per ply
@@ -2207,6 +2219,7 @@ int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev
     d->cur = d->stream;
     d->small_tiles = false;
     XQ_TRY(rc);
+    if (kept) { K.valid = true; K.boards = boards_dev; K.n = n; }
     *q90_dev = q;
     *q_stride = 96;
     return XQ_OK;
@@ -2526,9 +2539,10 @@ static int dqn_init(xq_dqn* d, const int* layer_sizes, int n_sizes, double learn
 int xq_dqn_destroy(xq_dqn* d) {
     if (!d) return XQ_OK;
     hipStreamSynchronize(d->stream);
+    if (d->own_stream) retire_stream(d->stream);
     for (int i = 0; i < 2; ++i) { hipFree(d->params[i]); hipFree(d->tacts[i]); }
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts[l]); hipFree(d->deltas[l]); hipFree(d->sel_acts[l]); }
-    hipFree(d->gboards); hipFree(d->dsc); hipFree(d->act_mb); hipFree(d->q90); hipFree(d->sel_q90); hipFree(d->sel_z1); hipFree(d->sel_prev_boards); hipFree(d->partial); hipFree(d->zmax); hipFree(d->zidx); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
+    hipFree(d->gboards); hipFree(d->dsc); hipFree(d->act_mb); hipFree(d->q90); hipFree(d->sel_q90); for (auto& K : d->sel_keep) { hipFree(K.z1); hipFree(K.prev_boards); } hipFree(d->partial); hipFree(d->zmax); hipFree(d->zidx); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
     hipFree(d->grads_td); hipFree(d->grads_full); hipFree(d->slabs); hipFree(d->bias_work); hipFree(d->xdense); hipFree(d->qfull); hipFree(d->tfull);
     hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
     d->prof.collect();
@@ -2554,6 +2568,12 @@ int xq_dqn_destroy(xq_dqn* d) {
     return XQ_OK;
 }
 
+int xq_dqn_stream(const xq_dqn* d, void** s) {
+    if (!d || !s) return fail(XQ_ERR_INVALID_ARGUMENT, "null pointer");
+    *s = (void*)d->stream;
+    return XQ_OK;
+}
+
 int xq_dqn_num_params(const xq_dqn* d, size_t* nw, size_t* nb) {
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
     if (nw) *nw = d->nw;
@@ -2572,8 +2592,11 @@ int xq_dqn_set_params(xq_dqn* d, int net, const double* w, const double* b) {
     XQ_HIP(hipStreamSynchronize(d->stream));
     XQ_HIP(hipMemcpy(d->params[net], p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
     if (d->scr_static_net == net) d->scr_static_net = -1;       // screening shadow: rows >= 96 are no longer what it holds
-    if (net == XQ_NET_ONLINE) d->sel_z1_valid = false;          // kept layer-0 sums of the select chain belong to the old weights
-    return refresh_shadow(d, net);
+    if (net == XQ_NET_ONLINE) d->sel_invalidate();              // kept layer-0 sums of the select chain belong to the old weights
+    d->params_version += 1;
+    XQ_TRY(refresh_shadow(d, net));
+    XQ_HIP(hipStreamSynchronize(d->stream));                    // a host-buffer entry point returns with the parameters in place
+    return XQ_OK;
 }
 
 int xq_dqn_get_params(xq_dqn* d, int net, double* w, double* b) {
@@ -2594,6 +2617,7 @@ int xq_dqn_get_params(xq_dqn* d, int net, double* w, double* b) {
 int xq_dqn_update_target(xq_dqn* d) {
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
     ProfScope ps(d, "target_sync_copy", 0, 8.0 * (d->nw + d->nb));
+    d->params_version += 1;
     XQ_HIP(hipMemcpyAsync(d->params[1], d->params[0], (d->nw + d->nb) * sizeof(float), hipMemcpyDeviceToDevice, d->stream));
     if (d->scr_static_net == XQ_NET_TARGET) d->scr_static_net = -1;     // screening shadow: every row of the target net changed
     if (d->bf16())
@@ -2609,7 +2633,7 @@ static int refresh_shadow(xq_dqn* d, int net) {
 }
 
 int xq_dqn_set_l0_derive(xq_dqn* d, int on) {
-    if (d) d->sel_z1_valid = false;
+    if (d) d->sel_invalidate();
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
     d->l0_derive = on != 0;
     return XQ_OK;
@@ -2661,6 +2685,7 @@ int xq_dqn_set_precision(xq_dqn* d, int precision) {
         }
     }
     d->precision = precision;
+    d->params_version += 1;
     XQ_TRY(refresh_shadow(d, 0));
     return refresh_shadow(d, 1);
 }
@@ -2780,10 +2805,11 @@ int xq_dqn_backpropagate(xq_dqn* d, const double* states, const double* targets,
     XQ_TRY(bias_grads(d, bj, n));
     SegTable t; memset(&t, 0, sizeof t);
     t.nseg = 1; t.dst[0] = d->params[0]; t.src[0] = d->grads_full; t.len[0] = (long long)(d->nw + d->nb);
+    d->params_version += 1;
     XQ_TRY(sgd_apply(d, t, lr * grad_scale));
     XQ_TRY(refresh_shadow(d, XQ_NET_ONLINE));          // bf16 Q-net: every later bf16 forward must see the updated weights
     if (d->scr_static_net == XQ_NET_ONLINE) d->scr_static_net = -1;    // dense update: every output row changed (screening shadow)
-    d->sel_z1_valid = false;
+    d->sel_invalidate();
     XQ_HIP(hipStreamSynchronize(d->stream));
     return XQ_OK;
 }
@@ -2928,8 +2954,10 @@ static int tail_gradients(xq_dqn* d, int n, float* const* outs, float* G, int mo
     d->force_defer = true;
     int rc = tail_gradients_impl(d, n, outs, G, mode);
     d->force_defer = false;
-    if (rc == XQ_OK && d->late_gate) {               // the select chain starts here, beside the exchange
-        if (hipEventRecord(d->ev_qmax, d->stream) != hipSuccess) rc = fail(XQ_ERR_RUNTIME, "hipEventRecord failed");
+    d->tail_open = false;                            // a failed assembly must not leave the launch helpers appending to a dead grid
+    if (d->late_gate) {                              // the select chain starts here, beside the exchange — also behind a failed step: a
+        // collect that waits for ev_qmax must find this step's record, not the previous one's
+        if (hipEventRecord(d->ev_qmax, d->stream) != hipSuccess && rc == XQ_OK) rc = fail(XQ_ERR_RUNTIME, "hipEventRecord failed");
     }
     if (rc == XQ_OK && !leave_pending) {
         rc = reduce_pending(d);
@@ -3358,8 +3386,9 @@ int xq_dqn_apply_grads(xq_dqn* d, double lr, double grad_scale) {
     t.dst[k] = d->bl(0, 0); t.src[k] = G + d->g_bh[0]; t.len[k] = (long long)(d->bo[d->nl - 1]); take(d->pend_bh); ++k;
     t.dst[k] = d->bl(0, d->nl - 1); t.src[k] = G + d->g_bout; t.len[k] = 96; take(d->pend_bout); ++k;
     t.nseg = k;
-    d->sel_z1_valid = false;                          // W0 / b0 change: the select chain's kept layer-0 sums are stale
-    d->sel_keep_pays = d->sel_calls >= 2; d->sel_calls = 0;
+    d->sel_invalidate();                              // W0 / b0 change: the select chain's kept layer-0 sums are stale
+    for (auto& K : d->sel_keep) { K.pays = K.calls >= 2; K.calls = 0; }
+    d->params_version += 1;
     return sgd_apply(d, t, lr * grad_scale);
 }
 
@@ -3402,14 +3431,11 @@ int xq_dqn_td_grads_replay(xq_dqn* d, xq_replay* r, int batch, int td_net, int m
         per.prio = r->dev.prio; per.pmax_live = r->per.scalars + 0;
         per.eps = r->per.eps; per.alpha = r->per.alpha;
     }
-    // a slot list drawn on the ring's own stream: this step starts behind the draw, and the next draw (which overwrites the list)
-    // behind this step
-    const bool listed = src.slots != nullptr;
-    if (listed) XQ_TRY(replay_consumer_begin(r, d->stream));
-    const int rc = td_grads_impl(d, r->dev.boards, r->dev.next_boards, r->dev.action_to, r->dev.reward, r->dev.done, src, batch, td_net,
-                                 mode, prioritized ? &per : nullptr);
-    if (listed && rc == XQ_OK) XQ_TRY(replay_consumer_end(r, d->stream));
-    return rc;
+    // ring, slot list and priorities may have been written on other streams (env steps, the draw, a rebuild): this step starts behind
+    // them, and whatever touches them next — the next draw overwrites the list, the next env step the slots — behind this step
+    XQ_TRY(replay_consumer_begin(r, d->stream, src.slots != nullptr, prioritized));
+    return td_grads_impl(d, r->dev.boards, r->dev.next_boards, r->dev.action_to, r->dev.reward, r->dev.done, src, batch, td_net,
+                         mode, prioritized ? &per : nullptr);
 }
 
 int xq_dqn_td_update_host(xq_dqn* d, int n, const uint8_t* boards90, const uint8_t* next_boards90, const int32_t* action_to,

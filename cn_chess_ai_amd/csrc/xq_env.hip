@@ -389,10 +389,9 @@ int env_selfplay_launch(xq_env* e, const float* q90_dev, int q_stride, uint32_t 
         P.rp_write_base = replay->write_pos;
     }
     const int blocks = (e->n + 3) / 4;
-    if (replay != nullptr) XQ_TRY(replay_writer_begin(replay, on ? on : e->stream));    // (no-ops when the ring shares this stream)
+    if (replay != nullptr) XQ_TRY(replay_writer_begin(replay, on ? on : e->stream));    // (costs nothing when the ring's users share this stream)
     hipLaunchKernelGGL(env_kernel<MODE_SELFPLAY>, dim3(blocks), dim3(256), 0, on ? on : e->stream, P);
     XQ_HIP(hipGetLastError());
-    if (replay != nullptr) XQ_TRY(replay_writer_end(replay, on ? on : e->stream));
     if (replay != nullptr) {
         replay->write_pos = (replay->write_pos + e->n) % replay->dev.capacity;
         replay->size = std::min(replay->dev.capacity, replay->size + e->n);
@@ -481,6 +480,7 @@ int xq_env_create(int n_games, uint64_t seed, uint32_t first_game_id, void* hip_
 int xq_env_destroy(xq_env* e) {
     if (!e) return XQ_OK;
     hipStreamSynchronize(e->stream);
+    if (e->own_stream) retire_stream(e->stream);
     hipFree(e->boards); hipFree(e->meta); hipFree(e->stats); hipFree(e->results); hipFree(e->codes);
     hipFree(e->counts); hipFree(e->actions); hipFree(e->q90); hipFree(e->validmat); hipFree(e->ep_ring);
     hipFree(e->ep_head);

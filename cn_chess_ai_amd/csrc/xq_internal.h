@@ -5,6 +5,40 @@
 
 #include <vector>
 
+namespace xq {
+
+// ---- ordering of device data shared between handles that run on different HIP streams ---------------------------------------------
+// Classes of ordering the library provides (include/xq_capi.h, "Stream ordering"); xq_debug_set_stream_ordering switches them off one
+// by one so that a test can show each of them is needed.
+enum : unsigned { ORD_RING_CONTENTS = 1u, ORD_RING_PRIORITIES = 2u, ORD_RING_DRAW = 4u, ORD_TRAINER_PARAMS = 8u, ORD_ALL = 15u };
+inline unsigned& order_mask() { static unsigned m = ORD_ALL; return m; }
+
+// One device resource and the streams that touched it last.  read(s) orders s behind the last write; write(s) orders s behind the
+// last write and behind every read since.  The event is recorded LAZILY — on the producer's stream at the moment a consumer on another
+// stream shows up (streams run in order, so a record made later still lies behind the producer's work) — because a record costs the
+// recording stream ~6 us and most producers are never waited for.  Streams the library destroys are struck
+// from every resource first (retire_stream); a caller-owned stream must outlive the handles that exchanged data through it.
+struct SharedResource {
+    unsigned cls;
+    bool has_writer = false;
+    hipStream_t writer = nullptr;
+    hipStream_t readers[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_readers = 0;
+    hipEvent_t ev = nullptr;
+    explicit SharedResource(unsigned c);
+    ~SharedResource();
+    SharedResource(const SharedResource&) = delete;
+    SharedResource& operator=(const SharedResource&) = delete;
+    int order_behind(hipStream_t waiter, hipStream_t producer);
+    int read(hipStream_t s);
+    int write(hipStream_t s);
+    void forget(hipStream_t s);        // s was synchronised and goes away
+    void host_synchronised() { has_writer = false; n_readers = 0; }     // the whole device was synchronised: nothing left to wait for
+};
+void retire_stream(hipStream_t s);     // after hipStreamSynchronize(s), before hipStreamDestroy(s)
+
+}  // namespace xq
+
 // replay ring in HBM: structure of arrays, states as packed boards (48 B) — never 1260 floats
 struct ReplayDev {
     uint32_t* boards = nullptr;       // [capacity][12]
@@ -35,16 +69,19 @@ struct xq_replay {
     int implicit_start = 0;           // windowed sample: slot = (start + philox % size) % capacity
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    // A ring with a stream of its own draws its samples there while the consumer (xq_dqn_td_grads_replay) reads the slot list on the
-    // Q-net's stream: `ev_sampled` (recorded behind every draw) orders the consumer behind the draw, `ev_consumed` (recorded behind
-    // the consumer's TD step) orders the NEXT draw — which overwrites the list — behind the consumer.  A ring that shares its stream
-    // with the consumer (the trainer's) records nothing.
-    hipEvent_t ev_sampled = nullptr, ev_consumed = nullptr;
-    bool sampled_recorded = false, consumed_pending = false;
-    // the same for the prioritized-replay tree: an env step that writes transitions on a stream of its own reads the priority snapshot
-    // of the last rebuild (ev_rebuilt), and the next rebuild reads the priorities that step wrote (ev_written)
-    hipEvent_t ev_rebuilt = nullptr, ev_written = nullptr;
-    bool rebuilt_recorded = false, written_pending = false;
+    // Device data of the ring that other handles read or write, possibly on streams of their own — each a SharedResource (above):
+    //   contents : boards / next_boards / action_to / reward / done   written by env steps (xq_env_selfplay_step) and push_host,
+    //              read by TD steps (xq_dqn_td_grads_replay)
+    //   prio     : live priority table + running maximum, and the tree / snapshot a rebuild makes of them
+    //              written by env steps (new transitions enter with the snapshot maximum), by TD steps (TD-error priorities) and by
+    //              a rebuild; every one of them also reads what the one before wrote, so they are all writers.  (Draws read the tree on
+    //              the stream the rebuild ran on — the ring's — and need no entry.)
+    //   draw     : slot list, importance weights, batch maximum          written by a draw, read by the TD step that consumes it
+    // Every access goes through read() / write(), which order the accessing stream behind the accesses it depends on when those ran
+    // on another stream; on one stream (the trainer's layout) they cost nothing.  `caller_orders`: the owner orders the accesses
+    // itself (xq_trainer: its collects write ring slots that the TD step running beside them never samples).
+    xq::SharedResource contents{xq::ORD_RING_CONTENTS}, prio_res{xq::ORD_RING_PRIORITIES}, draw{xq::ORD_RING_DRAW};
+    bool caller_orders = false;
     // prioritized replay (build-defined, BASELINE configs[4]): radix-32 sum tree, level 0 = dev.prio
     struct Per {
         bool enabled = false;
@@ -57,6 +94,7 @@ struct xq_replay {
                                           // [2] max raw importance weight of the last sample (float bits)  [3] eligible slots (p > 0)
         unsigned* wave_counts = nullptr;  // per-wave counts of non-zero leaves of the last rebuild (summed into scalars[3] by per_upper_kernel)
         bool wmax_clean = false;          // scalars[2] is zero (set by a rebuild, consumed by the next draw)
+        bool draw_unconsumed = false;     // a prioritized draw whose TD step has not been queued yet: a rebuild must leave scalars[2] alone
         float* is_w = nullptr;            // [slots_cap] raw importance weights of the last prioritized sample
         bool last_prioritized = false;
     } per;
@@ -167,19 +205,16 @@ struct QSource { const float* slabs; long long slab_stride; int nslabs; const fl
 int dqn_q90_boards(xq_dqn* d, const uint32_t* boards_dev, int n, float** q90_dev, int* q_stride, hipStream_t on = nullptr, QSource* qs = nullptr);
 hipStream_t dqn_stream(xq_dqn* d);
 hipEvent_t dqn_qmax_event(xq_dqn* d);      // recorded behind the column-max GEMM of the last xq_dqn_td_grads*
+uint64_t dqn_params_version(const xq_dqn* d);   // counts the operations that rewrote parameters (either net, fp32 or the bf16 shadow)
 
 // "virtual" replay sample: same slots as xq_replay_sample would write (Philox ctr = {i, 0, call, 1}, key = seed, % size),
 // but no kernel and no slot buffer — the consumer kernels recompute them.  Used by the trainer's hot loop.
 // (start, count) restricts the draw to `count` ring slots from `start` (count < 0: the whole filled part).
 int replay_sample_implicit(xq_replay* r, int batch, int start = 0, int count = -1);
 
-// ordering of a draw / its consumer across streams (see xq_replay::ev_sampled)
-int replay_before_draw(xq_replay* r, hipStream_t draw_stream);
-int replay_after_draw(xq_replay* r, hipStream_t draw_stream);
-int replay_consumer_begin(xq_replay* r, hipStream_t consumer);
-int replay_consumer_end(xq_replay* r, hipStream_t consumer);
-int replay_writer_begin(xq_replay* r, hipStream_t writer);       // env step that writes transitions into the ring
-int replay_writer_end(xq_replay* r, hipStream_t writer);
+// cross-stream ordering of the ring's users (SharedResource; no-ops on one stream or when the owner orders: xq_replay::caller_orders)
+int replay_consumer_begin(xq_replay* r, hipStream_t consumer, bool listed, bool prioritized);   // a TD step that reads the ring
+int replay_writer_begin(xq_replay* r, hipStream_t writer);                                      // an env step that writes it
 // prioritized replay internals used by the trainer (xq_replay.hip)
 int replay_per_rebuild(xq_replay* r, int retire_start, int retire_count, hipStream_t on);
 int replay_per_sample(xq_replay* r, int batch, hipStream_t on);

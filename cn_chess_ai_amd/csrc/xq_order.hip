@@ -1,0 +1,127 @@
+// xq_order.hip — ordering of device data that handles on different HIP streams hand to each other (SharedResource, xq_internal.h),
+// the stream utilities of the C ABI, and the two diagnostics the ordering tests use (a delay kernel, a switch per ordering class).
+//
+// No upstream analogue: the reference runs one stream and calls cudaDeviceSynchronize() after every launch (dqn.cu:233-236, 359-362).
+#include "xq_internal.h"
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+namespace xq {
+
+namespace {
+std::mutex& registry_mutex() { static std::mutex m; return m; }
+std::vector<SharedResource*>& registry() { static std::vector<SharedResource*> v; return v; }
+}  // namespace
+
+SharedResource::SharedResource(unsigned c) : cls(c) {
+    std::lock_guard<std::mutex> lock(registry_mutex());
+    registry().push_back(this);
+}
+SharedResource::~SharedResource() {
+    {
+        std::lock_guard<std::mutex> lock(registry_mutex());
+        auto& v = registry();
+        v.erase(std::remove(v.begin(), v.end(), this), v.end());
+    }
+    if (ev) (void)hipEventDestroy(ev);
+}
+
+int SharedResource::order_behind(hipStream_t waiter, hipStream_t producer) {
+    if (waiter == producer || !(order_mask() & cls)) return XQ_OK;
+    if (!ev) XQ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    XQ_HIP(hipEventRecord(ev, producer));            // lazily: behind everything the producer's stream holds by now
+    XQ_HIP(hipStreamWaitEvent(waiter, ev, 0));
+    return XQ_OK;
+}
+
+int SharedResource::read(hipStream_t s) {
+    for (int i = 0; i < n_readers; ++i)
+        if (readers[i] == s) return XQ_OK;           // already ordered behind the last write
+    if (has_writer) XQ_TRY(order_behind(s, writer));
+    if (n_readers == 4) {                            // a fifth reading stream takes the place of the fourth and waits for it, so that a
+        XQ_TRY(order_behind(s, readers[3]));         // later writer that waits for s is behind both
+        readers[3] = s;
+    } else {
+        readers[n_readers++] = s;
+    }
+    return XQ_OK;
+}
+
+int SharedResource::write(hipStream_t s) {
+    bool waited = false;
+    for (int i = 0; i < n_readers; ++i)
+        if (readers[i] != s) { XQ_TRY(order_behind(s, readers[i])); waited = true; }
+    // (every reader is itself behind the last writer: waiting for one of them covers it)
+    if (has_writer && writer != s && !waited) XQ_TRY(order_behind(s, writer));
+    has_writer = true; writer = s; n_readers = 0;
+    return XQ_OK;
+}
+
+void SharedResource::forget(hipStream_t s) {
+    if (has_writer && writer == s) has_writer = false;
+    int k = 0;
+    for (int i = 0; i < n_readers; ++i)
+        if (readers[i] != s) readers[k++] = readers[i];
+    n_readers = k;
+}
+
+void retire_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(registry_mutex());
+    for (SharedResource* r : registry()) r->forget(s);
+}
+
+// spins until `ticks` of the 100 MHz wall clock have passed (s_memrealtime): bounded by construction, one wave
+__global__ void delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+}  // namespace xq
+
+using namespace xq;
+
+extern "C" {
+
+int xq_stream_wait_stream(void* waiting_stream, void* producer_stream) {
+    if (waiting_stream == producer_stream) return XQ_OK;
+    hipEvent_t ev = nullptr;
+    XQ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)producer_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiting_stream, ev, 0);
+    (void)hipEventDestroy(ev);                       // released once the wait has passed
+    if (e != hipSuccess) return fail(XQ_ERR_RUNTIME, "xq_stream_wait_stream: %s", hipGetErrorString(e));
+    return XQ_OK;
+}
+
+int xq_debug_stream_delay(void* hip_stream, int microseconds) {
+    if (microseconds < 0 || microseconds > 200000) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_debug_stream_delay: 0..200000 us");
+    if (microseconds == 0) return XQ_OK;
+    int rate_khz = 0;
+    unsigned long long per_us = 100;                 // s_memrealtime: 100 MHz on gfx9
+    if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, 0) == hipSuccess && rate_khz > 0)
+        per_us = std::max(1ull, (unsigned long long)rate_khz / 1000ull);
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, per_us * (unsigned long long)microseconds);
+    XQ_HIP(hipGetLastError());
+    return XQ_OK;
+}
+
+int xq_debug_set_stream_ordering(unsigned mask) {
+    order_mask() = mask & ORD_ALL;
+    return XQ_OK;
+}
+
+}  // extern "C"
+
+// the stream a handle runs on (its own when it was created with NULL): what a caller needs for xq_stream_wait_stream
+extern "C" int xq_env_stream(const xq_env* e, void** s) {
+    if (!e || !s) return fail(XQ_ERR_INVALID_ARGUMENT, "null pointer");
+    *s = (void*)e->stream;
+    return XQ_OK;
+}
+extern "C" int xq_replay_stream(const xq_replay* r, void** s) {
+    if (!r || !s) return fail(XQ_ERR_INVALID_ARGUMENT, "null pointer");
+    *s = (void*)r->stream;
+    return XQ_OK;
+}

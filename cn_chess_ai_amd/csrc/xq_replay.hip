@@ -61,8 +61,10 @@ struct PerTree {
     long long off[8];
 };
 // levels 2.. in one block (they hold <= a few thousand nodes), then the snapshot of the running maximum priority, the number of eligible
-// slots (sum of per_level_kernel's per-wave counts) and a clean batch-maximum slot for the next draw
-__global__ __launch_bounds__(1024) void per_upper_kernel(PerTree T, unsigned* scalars, const unsigned* __restrict__ wave_counts, int n_counts) {
+// slots (sum of per_level_kernel's per-wave counts) and — unless a prioritized draw is still waiting for its TD step, which reads the
+// slot — a clean batch-maximum slot for the next draw
+__global__ __launch_bounds__(1024) void per_upper_kernel(PerTree T, unsigned* scalars, const unsigned* __restrict__ wave_counts, int n_counts,
+                                                         int zero_wmax) {
     __shared__ unsigned csum[16];
     unsigned c = 0;
     for (int i = (int)threadIdx.x; i < n_counts; i += (int)blockDim.x) c += wave_counts[i];
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(1024) void per_upper_kernel(PerTree T, unsigned* sc
         unsigned t = 0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += csum[w];
         if (wave_counts) scalars[3] = t;
-        scalars[2] = 0u;
+        if (zero_wmax) scalars[2] = 0u;
     }
     for (int lv = 2; lv < T.nlv; ++lv) {
         const float* child = T.upper + T.off[lv - 1];
@@ -152,13 +154,16 @@ static PerTree per_tree(const xq_replay* r) {
 int replay_per_rebuild(xq_replay* r, int retire_start, int retire_count, hipStream_t on) {
     if (!r || !r->per.enabled) return fail(XQ_ERR_INVALID_ARGUMENT, "prioritized replay is not enabled on this ring");
     hipStream_t s = on ? on : r->stream;
-    if (r->written_pending) {    // an env step on a stream of its own wrote the priorities of its transitions: read them behind it
-        XQ_HIP(hipStreamWaitEvent(s, r->ev_written, 0));
-        r->written_pending = false;
+    // the batch-maximum slot belongs to the last draw until its TD step has been queued (sample -> rebuild -> td_grads must
+    // not divide by a zeroed maximum); the next draw then clears it itself
+    const bool zero_wmax = !r->per.draw_unconsumed;
+    if (!r->caller_orders) {
+        // reads the priorities env steps and TD steps wrote on their own streams, retires slots in the same table, and snapshots the
+        // maximum the next env steps read
+        XQ_TRY(r->prio_res.write(s));
+        // (the batch-maximum slot it may zero is read only by a prioritized TD step, which also WRITES priorities: the line above already
+        // waits for it)
     }
-    // ... and the TD step that consumed the last draw on the Q-net's stream writes the TD-error priorities of its samples (the next
-    // draw waits for the same event and clears the flag)
-    if (r->consumed_pending) XQ_HIP(hipStreamWaitEvent(s, r->ev_consumed, 0));
     if (retire_count > 0) {      // slots the next collects overwrite: out of the tree before anything samples them
         hipLaunchKernelGGL(per_fill_kernel, dim3((retire_count + 255) / 256), dim3(256), 0, s, r->dev.prio, retire_start, retire_count,
                            r->dev.capacity, nullptr, 0.f);
@@ -176,15 +181,10 @@ int replay_per_rebuild(xq_replay* r, int retire_start, int retire_count, hipStre
         XQ_HIP(hipMemsetAsync(r->per.scalars + 3, 0, sizeof(unsigned), s));        // (a ring of <= 32 slots: counted by the sampler's callers)
         XQ_HIP(hipMemcpyAsync(r->per.leaves, r->dev.prio, 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    hipLaunchKernelGGL(per_upper_kernel, dim3(1), dim3(1024), 0, s, T, r->per.scalars, n_counts ? r->per.wave_counts : nullptr, n_counts);
+    hipLaunchKernelGGL(per_upper_kernel, dim3(1), dim3(1024), 0, s, T, r->per.scalars, n_counts ? r->per.wave_counts : nullptr, n_counts,
+                       zero_wmax ? 1 : 0);
     XQ_HIP(hipGetLastError());
-    r->per.wmax_clean = true;                                        // per_upper_kernel zeroed the batch-maximum slot
-    r->rebuilt_recorded = false;
-    if (r->own_stream && s == r->stream) {                           // writers on other streams read the snapshot behind this rebuild
-        if (!r->ev_rebuilt) XQ_HIP(hipEventCreateWithFlags(&r->ev_rebuilt, hipEventDisableTiming));
-        XQ_HIP(hipEventRecord(r->ev_rebuilt, s));
-        r->rebuilt_recorded = true;
-    }
+    r->per.wmax_clean = zero_wmax;
     return XQ_OK;
 }
 
@@ -201,57 +201,39 @@ int replay_per_sample(xq_replay* r, int batch, hipStream_t on) {
         r->slots_cap = batch;
     }
     if (!r->per.is_w) XQ_HIP(hipMalloc(&r->per.is_w, (size_t)r->slots_cap * sizeof(float)));
-    XQ_TRY(replay_before_draw(r, s));
+    if (!r->caller_orders) {
+        XQ_TRY(r->draw.write(s));        // the TD step that still reads the previous list / weights / batch maximum (its own stream) first
+    }
     if (!r->per.wmax_clean) XQ_HIP(hipMemsetAsync(r->per.scalars + 2, 0, sizeof(unsigned), s));     // a second draw from the same tree
     r->per.wmax_clean = false;
     hipLaunchKernelGGL(per_sample_kernel, dim3((batch + 255) / 256), dim3(256), 0, s, per_tree(r), batch, (uint32_t)r->sample_calls,
                        (uint32_t)r->seed, (uint32_t)(r->seed >> 32), r->per.beta, r->per.scalars, r->slots_dev, r->per.is_w);
     XQ_HIP(hipGetLastError());
-    XQ_TRY(replay_after_draw(r, s));
     r->sample_calls++;
     r->last_batch = batch;
     r->implicit = false;
     r->per.last_prioritized = true;
+    r->per.draw_unconsumed = true;
     return XQ_OK;
 }
 
-// ---- a draw on one stream, its consumer on another (xq_replay::ev_sampled in xq_internal.h) ------------------------------------
-int replay_before_draw(xq_replay* r, hipStream_t draw_stream) {
-    if (r->consumed_pending) {                    // the last consumer may still be reading the list this draw overwrites
-        XQ_HIP(hipStreamWaitEvent(draw_stream, r->ev_consumed, 0));
-        r->consumed_pending = false;
-    }
+// ---- a TD step that takes its minibatch from the ring (xq_dqn_td_grads_replay, on the Q-net's stream) ------------------------------
+int replay_consumer_begin(xq_replay* r, hipStream_t consumer, bool listed, bool prioritized) {
+    r->per.draw_unconsumed = false;
+    if (r->caller_orders) return XQ_OK;
+    XQ_TRY(r->contents.read(consumer));                      // behind the env steps that wrote the transitions
+    if (listed) XQ_TRY(r->draw.read(consumer));              // behind the draw; the next draw waits for this step in turn
+    if (prioritized) XQ_TRY(r->prio_res.write(consumer));    // it writes the TD-error priorities of its samples: the next rebuild waits
     return XQ_OK;
 }
-int replay_after_draw(xq_replay* r, hipStream_t draw_stream) {
-    r->sampled_recorded = false;
-    if (!r->own_stream || draw_stream != r->stream) return XQ_OK;      // the ring runs on its owner's stream: stream order does it
-    if (!r->ev_sampled) XQ_HIP(hipEventCreateWithFlags(&r->ev_sampled, hipEventDisableTiming));
-    XQ_HIP(hipEventRecord(r->ev_sampled, draw_stream));
-    r->sampled_recorded = true;
-    return XQ_OK;
-}
-int replay_consumer_begin(xq_replay* r, hipStream_t consumer) {
-    if (r->sampled_recorded && consumer != r->stream) XQ_HIP(hipStreamWaitEvent(consumer, r->ev_sampled, 0));
-    return XQ_OK;
-}
-int replay_consumer_end(xq_replay* r, hipStream_t consumer) {
-    if (!r->sampled_recorded || consumer == r->stream) return XQ_OK;
-    if (!r->ev_consumed) XQ_HIP(hipEventCreateWithFlags(&r->ev_consumed, hipEventDisableTiming));
-    XQ_HIP(hipEventRecord(r->ev_consumed, consumer));
-    r->consumed_pending = true;
-    return XQ_OK;
-}
-
+// ---- an env step that writes its transitions into the ring (xq_env_selfplay_step, on the env's stream) -----------------------------
 int replay_writer_begin(xq_replay* r, hipStream_t writer) {
-    if (r->per.enabled && r->rebuilt_recorded && writer != r->stream) XQ_HIP(hipStreamWaitEvent(writer, r->ev_rebuilt, 0));
-    return XQ_OK;
-}
-int replay_writer_end(xq_replay* r, hipStream_t writer) {
-    if (!r->per.enabled || !r->own_stream || writer == r->stream) return XQ_OK;
-    if (!r->ev_written) XQ_HIP(hipEventCreateWithFlags(&r->ev_written, hipEventDisableTiming));
-    XQ_HIP(hipEventRecord(r->ev_written, writer));
-    r->written_pending = true;
+    if (r->caller_orders) return XQ_OK;
+    XQ_TRY(r->contents.write(writer));                       // behind the TD steps that still read the slots it overwrites
+    if (r->per.enabled) {
+        XQ_TRY(r->prio_res.write(writer));                   // new transitions enter with the maximum the last rebuild snapshot (behind
+                                                             // it), and the next rebuild reads their priorities (behind this step)
+    }
     return XQ_OK;
 }
 
@@ -262,6 +244,7 @@ int replay_sample_implicit(xq_replay* r, int batch, int start, int count) {
         return fail(XQ_ERR_RUNTIME, "xq_replay_sample: buffer is empty");
     r->implicit = true;
     r->per.last_prioritized = false;
+    r->per.draw_unconsumed = false;
     r->implicit_call = (uint32_t)r->sample_calls;
     r->implicit_size = count;
     r->implicit_start = start;
@@ -312,10 +295,7 @@ static int replay_init(xq_replay* r, int capacity, uint64_t seed, void* hip_stre
 int xq_replay_destroy(xq_replay* r) {
     if (!r) return XQ_OK;
     hipStreamSynchronize(r->stream);
-    if (r->ev_sampled) hipEventDestroy(r->ev_sampled);
-    if (r->ev_consumed) hipEventDestroy(r->ev_consumed);
-    if (r->ev_rebuilt) hipEventDestroy(r->ev_rebuilt);
-    if (r->ev_written) hipEventDestroy(r->ev_written);
+    if (r->own_stream) retire_stream(r->stream);
     hipFree(r->dev.boards); hipFree(r->dev.next_boards); hipFree(r->dev.action_to); hipFree(r->dev.reward);
     hipFree(r->dev.done); hipFree(r->slots_dev);
     hipFree(r->dev.prio); hipFree(r->per.leaves); hipFree(r->per.upper); hipFree(r->per.scalars); hipFree(r->per.wave_counts); hipFree(r->per.is_w);
@@ -340,7 +320,8 @@ int xq_replay_push_host(xq_replay* r, int n, const uint8_t* boards90, const int3
     for (size_t i = 0; i < (size_t)n * 90; ++i)       // code 15 would index one-hot plane 14 of 14 in the layer-0 kernels
         if (boards90[i] > 14 || next_boards90[i] > 14) return fail(XQ_ERR_INVALID_ARGUMENT, "piece code > 14");
     uint32_t w[kBoardWords], nw[kBoardWords];
-    XQ_HIP(hipStreamSynchronize(r->stream));
+    XQ_HIP(hipDeviceSynchronize());              // host-side writes: nothing may still be reading or writing the ring on any stream
+    r->contents.host_synchronised(); r->prio_res.host_synchronised();
     for (int i = 0; i < n; ++i) {
         const int slot = r->write_pos;
         pack_board(boards90 + (size_t)i * 90, w);
@@ -404,7 +385,8 @@ int xq_replay_set_priorities(xq_replay* r, int first, int n, const float* prio_h
         return fail(XQ_ERR_INVALID_ARGUMENT, "xq_replay_set_priorities: bad argument (is prioritized replay enabled?)");
     for (int i = 0; i < n; ++i)
         if (!(prio_host[i] >= 0.f)) return fail(XQ_ERR_INVALID_ARGUMENT, "priorities must be >= 0");
-    XQ_HIP(hipStreamSynchronize(r->stream));
+    XQ_HIP(hipDeviceSynchronize());              // (a TD step or an env step on another stream may be writing the table)
+    r->prio_res.host_synchronised();
     XQ_HIP(hipMemcpy(r->dev.prio + first, prio_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     float mx = 0.f;
     for (int i = 0; i < n; ++i) mx = std::max(mx, prio_host[i]);
@@ -476,15 +458,15 @@ int xq_replay_sample_window(xq_replay* r, int batch, int start, int count, int32
         XQ_HIP(hipMalloc(&r->slots_dev, (size_t)batch * sizeof(int32_t)));
         r->slots_cap = batch;
     }
-    XQ_TRY(replay_before_draw(r, r->stream));
+    if (!r->caller_orders) XQ_TRY(r->draw.write(r->stream));     // the TD step that still reads the previous list (its own stream) first
     hipLaunchKernelGGL(replay_sample_kernel, dim3((batch + 255) / 256), dim3(256), 0, r->stream, r->slots_dev, batch,
                        (uint32_t)start, (uint32_t)count, (uint32_t)r->dev.capacity, (uint32_t)r->sample_calls, (uint32_t)r->seed, (uint32_t)(r->seed >> 32));
     XQ_HIP(hipGetLastError());
-    XQ_TRY(replay_after_draw(r, r->stream));
     r->sample_calls++;
     r->last_batch = batch;
     r->implicit = false;
     r->per.last_prioritized = false;
+    r->per.draw_unconsumed = false;
     if (slots_host) {
         XQ_HIP(hipMemcpyAsync(slots_host, r->slots_dev, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
         XQ_HIP(hipStreamSynchronize(r->stream));
@@ -496,6 +478,8 @@ int xq_replay_get(xq_replay* r, int slot, uint8_t* board90, int32_t* action_to, 
                   uint8_t* next_board90) {
     if (!r || slot < 0 || slot >= r->dev.capacity) return fail(XQ_ERR_INVALID_ARGUMENT, "bad slot");
     uint32_t w[kBoardWords];
+    if (!r->caller_orders) XQ_TRY(r->contents.read(r->stream));      // behind an env step that wrote the slot on a stream of its own
+    else XQ_HIP(hipDeviceSynchronize());
     XQ_HIP(hipStreamSynchronize(r->stream));
     if (board90) {
         XQ_HIP(hipMemcpy(w, r->dev.boards + (size_t)slot * kBoardWords, sizeof w, hipMemcpyDeviceToHost));

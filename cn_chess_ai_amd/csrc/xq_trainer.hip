@@ -39,6 +39,9 @@ struct xq_trainer {
     bool params_event_stale = true;         // ev_params has not been recorded since the last parameter update
     bool grads_event_stale = true;          // ev_grads has not been recorded since the queued learn_grads
     bool early_collect = false;             // collects_per_update > 1: collects start behind the previous parameter update (see collect_impl)
+    uint64_t params_version = 0;            // dqn_params_version() when ev_params was last recorded: anything that rewrote parameters on the
+                                            // handle's stream since (set_params on a bf16 net, an apply_grads of the caller's own) lies
+                                            // BEHIND that record, and the select chain must not start in front of it
 };
 
 using namespace xq;
@@ -75,6 +78,7 @@ static int trainer_init(xq_trainer* t, const xq_trainer_config* cfg, void* hip_s
                          t->stream, &t->dqn));
     const int cap = cfg->replay_capacity > 0 ? cfg->replay_capacity : cfg->n_games;
     XQ_TRY(xq_replay_create(cap, cfg->seed + 0x1234567ull + cfg->first_game_id, t->stream, &t->replay));
+    t->replay->caller_orders = true;         // env, ring and Q-net share t->stream; the collect stream is ordered below, by hand
     if (cfg->precision != XQ_PRECISION_F32) XQ_TRY(xq_dqn_set_precision(t->dqn, cfg->precision));
     if (cfg->prioritized) {
         if (cfg->replay_capacity == 0) return fail(XQ_ERR_INVALID_ARGUMENT, "prioritized replay needs a replay ring (replay_capacity > 0)");
@@ -98,6 +102,7 @@ static int trainer_init(xq_trainer* t, const xq_trainer_config* cfg, void* hip_s
         XQ_HIP(hipEventCreateWithFlags(&t->ev_grads, hipEventDisableTiming));
         XQ_HIP(hipEventRecord(t->ev_params, t->stream));      // orders the first collect after the handles' initialisation
         t->params_event_stale = false;
+        t->params_version = dqn_params_version(t->dqn);
         t->early_collect = cfg->collects_per_update > 1;
     }
     return XQ_OK;
@@ -111,6 +116,7 @@ int xq_trainer_destroy(xq_trainer* t) {
     if (t->ev_params) hipEventDestroy(t->ev_params);
     if (t->ev_collect) hipEventDestroy(t->ev_collect);
     if (t->ev_grads) hipEventDestroy(t->ev_grads);
+    if (t->own_stream) retire_stream(t->stream);
     xq_env_destroy(t->env);
     xq_dqn_destroy(t->dqn);
     xq_replay_destroy(t->replay);
@@ -136,16 +142,25 @@ static int collect_impl(xq_trainer* t) {
     hipStream_t on = nullptr;
     if (t->cstream) {
         on = t->cstream;
+        // has anything rewritten parameters on the handle's stream since ev_params was recorded?  (ORD_TRAINER_PARAMS off: the round-3
+        // behaviour, for the test that shows the check is needed)
+        const bool params_moved = (order_mask() & ORD_TRAINER_PARAMS) && dqn_params_version(t->dqn) != t->params_version;
         if (t->grads_queued && !t->early_collect) {
             // queued behind the column-max GEMM (which wants the chip to itself); that event lies behind every parameter update
             if (t->inflight == 0) XQ_HIP(hipStreamWaitEvent(on, dqn_qmax_event(t->dqn), 0));
         } else if (t->grads_queued) {
             // several plies per update: the collect chain is the long pole of the iteration (each ply waits for the move of the one
-            // before) — it starts behind the previous parameter update, recorded there (learn_apply), and runs beside the whole TD step
-            if (t->inflight == 0 && !t->params_event_stale) XQ_HIP(hipStreamWaitEvent(on, t->ev_params, 0));
+            // before) — it starts behind the previous parameter update, recorded there (learn_apply), and runs beside the whole TD step.
+            // If parameters were rewritten behind that record, the event of the queued TD step (behind everything on the handle's
+            // stream) takes its place.
+            if (t->inflight == 0 && !t->params_event_stale && !params_moved) XQ_HIP(hipStreamWaitEvent(on, t->ev_params, 0));
             else if (t->inflight == 0) XQ_HIP(hipStreamWaitEvent(on, dqn_qmax_event(t->dqn), 0));     // (no record yet: first iteration)
         } else if (t->inflight == 0) {
-            if (t->params_event_stale) { XQ_HIP(hipEventRecord(t->ev_params, t->stream)); t->params_event_stale = false; }
+            if (t->params_event_stale || params_moved) {
+                XQ_HIP(hipEventRecord(t->ev_params, t->stream));
+                t->params_event_stale = false;
+                t->params_version = dqn_params_version(t->dqn);
+            }
             XQ_HIP(hipStreamWaitEvent(on, t->ev_params, 0));
         }
         // more plies than the queued learn_grads excluded from its minibatch (caller mixed the orders): these slots may be
@@ -290,6 +305,7 @@ int xq_trainer_learn_apply(xq_trainer* t, int world_size) {
     if (t->cstream && t->early_collect) {       // the next iteration's collects start here, whatever the caller queues first
         XQ_HIP(hipEventRecord(t->ev_params, t->stream));
         t->params_event_stale = false;
+        t->params_version = dqn_params_version(t->dqn);
     }
     t->inflight = 0;
     t->grads_queued = false;

@@ -46,6 +46,11 @@ class DQN:
     def handle(self):
         return self._h
 
+    def stream(self):
+        s = C.c_void_p()
+        call("xq_dqn_stream", self._h, C.byref(s))
+        return s.value
+
     # ---- parameters in the reference flat layout (host_weights / host_biases, dqn.h:47-50) ----
     def set_params(self, weights, biases, net=_capi.NET_ONLINE):
         w = np.ascontiguousarray(weights, dtype=np.float64).reshape(self.n_weights)

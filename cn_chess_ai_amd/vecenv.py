@@ -65,6 +65,12 @@ class ReplayBuffer:
     def handle(self):
         return self._h
 
+    def stream(self):
+        """The HIP stream the ring runs on (its own when created without one), as an int."""
+        s = C.c_void_p()
+        call("xq_replay_stream", self._h, C.byref(s))
+        return s.value
+
     def stats(self):
         size, cap, tot = C.c_int32(), C.c_int32(), C.c_uint64()
         call("xq_replay_size", self._h, C.byref(size), C.byref(cap), C.byref(tot))
@@ -83,13 +89,20 @@ class ReplayBuffer:
         call("xq_replay_push_host", self._h, n, _ptr(boards, C.c_uint8), _ptr(a, C.c_int32), _ptr(r, C.c_float),
              _ptr(d, C.c_uint8), _ptr(next_boards, C.c_uint8))
 
-    def sample(self, batch):
+    def sample(self, batch, host=True):
+        """host=False: the draw is only queued (no copy of the slots back, no synchronisation)."""
+        if not host:
+            call("xq_replay_sample", self._h, int(batch), None)
+            return None
         slots = np.zeros(batch, dtype=np.int32)
         call("xq_replay_sample", self._h, int(batch), _ptr(slots, C.c_int32))
         return slots
 
-    def sample_window(self, batch, start, count):
+    def sample_window(self, batch, start, count, host=True):
         """sample(B) from the `count` ring slots that start at `start` (wrapping)."""
+        if not host:
+            call("xq_replay_sample_window", self._h, int(batch), int(start), int(count), None)
+            return None
         slots = np.zeros(batch, dtype=np.int32)
         call("xq_replay_sample_window", self._h, int(batch), int(start), int(count), _ptr(slots, C.c_int32))
         return slots
@@ -101,8 +114,11 @@ class ReplayBuffer:
     def per_rebuild(self, retire_start=0, retire_count=0):
         call("xq_replay_per_rebuild", self._h, int(retire_start), int(retire_count))
 
-    def sample_prioritized(self, batch):
+    def sample_prioritized(self, batch, host=True):
         """(slots, normalised importance weights) of a stratified proportional draw from the tree as of the last rebuild."""
+        if not host:
+            call("xq_replay_sample_prioritized", self._h, int(batch), None, None)
+            return None
         slots = np.zeros(batch, dtype=np.int32)
         w = np.zeros(batch, dtype=np.float32)
         call("xq_replay_sample_prioritized", self._h, int(batch), _ptr(slots, C.c_int32), _ptr(w, C.c_float))
@@ -157,6 +173,11 @@ class VecEnv:
     @property
     def handle(self):
         return self._h
+
+    def stream(self):
+        s = C.c_void_p()
+        call("xq_env_stream", self._h, C.byref(s))
+        return s.value
 
     def reset(self):
         call("xq_env_reset", self._h)

@@ -12,12 +12,37 @@
  *   - pointers named *_host are caller-owned host memory, *_dev are device (HBM) pointers on the handle's device;
  *   - each handle runs on ONE hipStream_t (passed as void*; NULL = a stream the handle creates); calls are
  *     asynchronous on that stream unless they return data to the host, in which case they synchronise that stream;
- *   - handles that exchange DEVICE data (an env writing a replay ring, a Q-net reading it, Q-values fed to an env) are ordered
- *     by stream order when they were created on the same stream — what xq_trainer does, and the simplest way to use the ABI.
- *     Handles on streams of their own are ordered against each other only where an entry point says so (xq_replay_sample*: the draw
- *     against its consumer; xq_replay_per_rebuild against the env steps that write the ring's priorities, both directions);
- *     otherwise the caller synchronises (xq_stream_synchronize) between producer and consumer;
+ *   - handles that exchange DEVICE data are ordered by stream order when they were created on the same stream — what xq_trainer
+ *     does, and the simplest way to use the ABI.  For handles on streams of their own see "Stream ordering" below: whatever is passed
+ *     as a HANDLE the library orders itself, whatever is passed as a raw device pointer is the caller's to order;
  *   - handles are not thread-safe; one GPU per process (one rank per GPU under torch.distributed / RCCL).
+ *
+ * Stream ordering (no upstream analogue: the reference has one stream and a cudaDeviceSynchronize() after every launch).  Every pair of
+ * entry points through which two handles hand each other device data, and what orders the consumer behind the producer when the two
+ * handles run on different streams (same stream: stream order, nothing recorded).  "library" = the ring keeps, per resource, the
+ * stream of the last write and of the reads since, and the consumer's stream waits on an event recorded on the producer's stream
+ * (cn_chess_ai_amd/csrc/xq_internal.h, SharedResource); each class can be switched off with xq_debug_set_stream_ordering for the test
+ * that shows it is needed (tests/test_stream_order_gpu.py: every row below has a sync-vs-nosync case that goes red without it).
+ *
+ *   producer -> consumer                                         device data                       ordered by
+ *   xq_env_selfplay_step(replay) -> xq_dqn_td_grads_replay        ring slots (s, a, r, s', done)    library: XQ_ORDER_RING_CONTENTS
+ *   xq_dqn_td_grads_replay -> xq_env_selfplay_step(replay)        the slots that step still reads   library: XQ_ORDER_RING_CONTENTS
+ *   xq_env_selfplay_step(replay) -> xq_replay_get                 ring slots                        library: XQ_ORDER_RING_CONTENTS
+ *   xq_env_selfplay_step(replay) -> xq_replay_per_rebuild         priorities of new transitions     library: XQ_ORDER_RING_PRIORITIES
+ *   xq_dqn_td_grads_replay (prioritized) -> xq_replay_per_rebuild TD-error priorities               library: XQ_ORDER_RING_PRIORITIES
+ *   xq_replay_per_rebuild -> xq_env_selfplay_step(replay)         maximum-priority snapshot         library: XQ_ORDER_RING_PRIORITIES
+ *   xq_replay_per_rebuild -> xq_replay_sample_prioritized         sum tree                          one stream (the ring's): stream order
+ *   xq_replay_sample* -> xq_dqn_td_grads_replay                   slot list, importance weights     library: XQ_ORDER_RING_DRAW
+ *   xq_dqn_td_grads_replay -> next xq_replay_sample*              the list that step still reads    library: XQ_ORDER_RING_DRAW
+ *   xq_dqn_apply_grads / set_params / load_model / update_target
+ *     -> xq_dqn_forward* / select_q_dev / td_grads*               parameters                        one handle, one stream: stream order
+ *     -> xq_trainer_collect (collect stream of overlap_collect)   parameters                        library: XQ_ORDER_TRAINER_PARAMS
+ *   xq_dqn_select_q_dev / forward_boards_dev -> xq_env_selfplay_step   q90_dev (raw pointer)        CALLER: xq_stream_wait_stream(env stream, Q-net stream)
+ *   xq_env_*step* -> xq_dqn_select_q_dev / forward_boards_dev / td_grads(boards_dev)  boards (raw pointer)   CALLER: xq_stream_wait_stream(Q-net stream, env stream)
+ *   xq_env_selfplay_step(results_dev) / legal_moves_dev -> anything    raw pointers                 CALLER
+ *   xq_comm_allreduce(buf_dev, stream), xq_allreduce_grads        caller's buffer / gradient buffer on the stream given / the handle's: stream order
+ *   host-buffer entry points (*_host, set_state, get_*, push_host, set_priorities, set_params, backpropagate)   synchronise before they return
+ * A stream handed to a handle must outlive every handle that exchanged data with it (events are recorded on it lazily).
  *
  * Encodings
  *   - square  s = row*9 + col, rows 0..9 (Red home rows 0-4, Red moves +row: chessboard.cpp:12-28), cols 0..8;
@@ -53,6 +78,15 @@ int xq_version(void);
 int xq_device_count(int* n);
 int xq_set_device(int device);
 int xq_stream_synchronize(void* hip_stream);
+/* Orders everything queued on waiting_stream from now on behind everything queued on producer_stream so far (one event record + one
+ * wait; no host synchronisation) — for the device pointers the caller hands from one handle to another ("Stream ordering" above). */
+int xq_stream_wait_stream(void* waiting_stream, void* producer_stream);
+/* Diagnostics of the ordering tests.  xq_debug_stream_delay queues a kernel that spins for `microseconds` (<= 200000) on hip_stream, so
+ * that a producer queued behind it is certainly still running when an unordered consumer starts.  xq_debug_set_stream_ordering: bit mask
+ * of the ordering classes the library provides (default XQ_ORDER_ALL); process-wide. */
+enum { XQ_ORDER_RING_CONTENTS = 1, XQ_ORDER_RING_PRIORITIES = 2, XQ_ORDER_RING_DRAW = 4, XQ_ORDER_TRAINER_PARAMS = 8, XQ_ORDER_ALL = 15 };
+int xq_debug_stream_delay(void* hip_stream, int microseconds);
+int xq_debug_set_stream_ordering(unsigned mask);
 /* HIP-event timing on a given stream, for bench.py's roofline leg (ms between the two records). */
 int xq_event_create(void** ev);
 int xq_event_destroy(void* ev);
@@ -70,6 +104,7 @@ typedef struct xq_env xq_env;
 int xq_env_create(int n_games, uint64_t seed, uint32_t first_game_id, void* hip_stream, xq_env** out);
 int xq_env_destroy(xq_env* env);
 int xq_env_num_games(const xq_env* env, int* n);
+int xq_env_stream(const xq_env* env, void** hip_stream);      /* the stream the handle runs on (its own when it was created with NULL) */
 /* ChessBoard::reset() on every game (chessboard.cpp:95-102); also zeroes the RNG counters and episode counts. */
 int xq_env_reset(xq_env* env);
 /* Test/interop access to the state (no upstream analogue: upstream board is private).  boards90: [n][90] piece codes;
@@ -149,15 +184,17 @@ const uint32_t* xq_env_meta_dev(const xq_env* env);     /* [n_games][4] */
 int xq_replay_create(int capacity, uint64_t seed, void* hip_stream, xq_replay** out);
 int xq_replay_destroy(xq_replay* r);
 int xq_replay_size(xq_replay* r, int* size, int* capacity, uint64_t* total_pushed);
+int xq_replay_stream(const xq_replay* r, void** hip_stream);
 /* push(s, a, r, s', done) for n transitions given as 90-byte boards on the host (tests / interop). */
 int xq_replay_push_host(xq_replay* r, int n, const uint8_t* boards90, const int32_t* action_to, const float* reward,
                         const uint8_t* done, const uint8_t* next_boards90);
 /* sample(B): uniform with replacement, Philox(ctr = {draw, 0, sample call #, 1}, key = seed) % size.
  * Returns the chosen slots; xq_dqn_td_grads_replay consumes them on device.  Streams: the draw runs on the ring's stream, the
- * consumer on the Q-net's.  When those differ the library orders them itself — the TD step waits for the draw, and the next draw
- * (it overwrites the slot list) waits for the TD step that still reads it — so a caller may draw, queue the step and draw again
- * without synchronising.  The CONTENTS of the ring are the caller's to order: a ply that writes slots a queued step still reads
- * must wait for that step (the trainer draws from the ring minus the slots its collects write, xq_replay_sample_window). */
+ * consumer on the Q-net's, env steps that fill the ring on the env's.  When those differ the library orders them itself ("Stream
+ * ordering" at the top) — the TD step waits for the draw and for the env steps that wrote the ring, the next draw (it overwrites the
+ * slot list) and the next env step (it overwrites slots) wait for the TD step that still reads them — so a caller may draw, queue the
+ * step, play and draw again without synchronising.  (xq_trainer orders its own ring by hand: its collects write slots that the TD
+ * step running beside them never samples, xq_replay_sample_window.) */
 int xq_replay_sample(xq_replay* r, int batch, int32_t* slots_host /* optional */);
 /* sample(B) restricted to the `count` ring slots that start at `start` (wrapping): slot = (start + Philox % count) % capacity.
  * The overlapped trainer uses it to leave out the slots a concurrent collect is writing; (0, size) == xq_replay_sample. */
@@ -174,7 +211,9 @@ int xq_replay_get(xq_replay* r, int slot, uint8_t* board90, int32_t* action_to, 
  *                               overwritten), rebuilds the tree from the priority table and snapshots the running maximum
  *   xq_replay_sample_prioritized: draws `batch` slots from the tree as of the last rebuild; xq_dqn_td_grads_replay then applies the
  *                               importance weights and writes the new priorities of the sampled slots back
- *   set/get_priorities, per_stats: tests / interop */
+ *   set/get_priorities, per_stats: tests / interop
+ * Call order: rebuild -> sample_prioritized -> td_grads_replay.  A rebuild between a draw and its TD step is allowed (the batch maximum
+ * of the draw's importance weights is left alone until the step has been queued). */
 int xq_replay_enable_per(xq_replay* r, double alpha, double beta, double eps);
 int xq_replay_per_rebuild(xq_replay* r, int retire_start, int retire_count);
 int xq_replay_sample_prioritized(xq_replay* r, int batch, int32_t* slots_host /* optional */, float* weights_host /* optional, normalised */);
@@ -214,6 +253,7 @@ enum { XQ_QMAX_FULL = 0,           /* max_a' Q(s',a') of the TD target (chessai.
 int xq_dqn_create(const int* layer_sizes, int n_sizes, double learning_rate, double gamma, uint64_t seed,
                   void* hip_stream, xq_dqn** out);
 int xq_dqn_destroy(xq_dqn* d);
+int xq_dqn_stream(const xq_dqn* d, void** hip_stream);
 /* XQ_PRECISION_*: arithmetic of the forward passes on packed boards (action select, TD targets, Q(s,a)).  The dense-state entry
  * points (xq_dqn_forward / xq_dqn_backpropagate: the reference's std::vector<double> API) always compute in fp32. */
 int xq_dqn_set_precision(xq_dqn* d, int precision);
@@ -229,12 +269,14 @@ int xq_dqn_set_l0_derive(xq_dqn* d, int on);
 /* How the gradient half of xq_dqn_td_grads is queued (no upstream analogue: dqn.cu:323-467 launches one kernel per layer and waits
  * for each).  1 (default): as fused launches on the handle's stream — per hidden layer below the top one ONE grid that holds the blocks
  * of the delta product, of the weight-gradient product above it and (first time) of the output-layer sums, then ONE grid with the
- * layer-0 sums and the bias column sums; taken when the net is fp32, its backward products fit 64 x 64 tiles, no communicator is
- * attached and xq_dqn_set_fused_apply is on.  0, or any other case: the same kernels one by one on two streams (critical chain +
- * side stream, three event records and a join).  The same switch covers the other fusion of the step's second half: with exact
- * screening on a net whose last hidden layer is 256 wide (uniform replay), the TD target / output delta / top hidden delta are
- * computed inside the blocks of the kernel that re-evaluates the screened maxima instead of by a launch of their own.
- * Results are bitwise identical either way. */
+ * layer-0 sums and the bias column sums.  Taken for every fp32 net whose backward products fit 64 x 64 tiles (all BASELINE nets at
+ * 8192-16384 samples); bf16 nets and larger products run the same kernels one by one on two streams (critical chain + side stream,
+ * three event records and a join), as does 0.  What happens to the partial sums the fused launches leave: with
+ * xq_dqn_set_fused_apply on and no communicator they stay pending and xq_dqn_apply_grads adds them; otherwise ONE launch reduces them
+ * into the gradient buffer on the handle's stream, and an attached communicator all-reduces that buffer in ONE collective behind it
+ * (xq_dqn_set_comm).  The same switch covers the other fusion of the step's second half: with exact screening on a net whose last
+ * hidden layer is 256 wide (uniform replay), the TD target / output delta / top hidden delta are computed inside the blocks of the
+ * kernel that re-evaluates the screened maxima instead of by a launch of their own.  Results are bitwise identical either way. */
 int xq_dqn_set_td_tail(xq_dqn* d, int on);
 /* XQ_QMAX_*: how the TD step finds max_a' Q(s',a').  XQ_QMAX_SCREENED applies to fp32 nets with XQ_TD_ONLINE_NET / XQ_TD_TARGET_NET
  * whose last hidden width is a multiple of 64 and whose product is large enough for the persistent GEMM (>= 512 tiles of 128 x 128);
