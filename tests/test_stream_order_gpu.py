@@ -38,9 +38,9 @@ def dsync():
 class Rig:
     """env + ring + Q-net, each on a stream of its own; the ring pre-filled with two random plies."""
 
-    def __init__(self, xq, per=False, cap=CAP, n=N, prefill=2):
+    def __init__(self, xq, per=False, cap=CAP, n=N, prefill=2, env_stream=None):
         self.xq = xq
-        self.env = xq.VecEnv(n, seed=3)
+        self.env = xq.VecEnv(n, seed=3, stream=env_stream)
         self.rp = xq.ReplayBuffer(cap, seed=11)
         if per:
             self.rp.enable_per(0.6, 0.4, 1e-3)
@@ -52,6 +52,19 @@ class Rig:
         if per:
             self.rp.per_rebuild()
             dsync()
+        if prefill:
+            # first calls allocate workspaces (hipMalloc / hipFree synchronise): make them now, so that the sequences under test only
+            # ever queue work.  A TD step with learning rate 0 changes no parameter (its priorities, with `per`, equally in every leg).
+            if per:
+                self.rp.sample_prioritized(n, host=False)
+            else:
+                self.rp.sample_window(n, 0, n, host=False)
+            self.d.td_grads_replay(self.rp, n, td_net=0, mode=0)
+            self.d.apply_grads(0.0, 1.0)
+            dsync()
+            if per:
+                self.rp.per_rebuild()
+                dsync()
 
     def delay(self, stream):
         self.xq._capi.call("xq_debug_stream_delay", C.c_void_p(stream), DELAY_US)
@@ -121,9 +134,14 @@ def test_td_step_then_env_step_overwrites_its_slots(xq):
 
 
 def test_env_step_then_replay_get(xq):
-    """xq_env_selfplay_step(replay) -> xq_replay_get of a slot it wrote (host read on the ring's stream)."""
+    """xq_env_selfplay_step(replay) -> xq_replay_get of a slot it wrote (host read on the ring's stream).  The env runs on a NON-BLOCKING
+    stream here (a torch side stream): a stream created with default flags is ordered against the null-stream copy of the host read by
+    the runtime itself."""
+    import torch
+    side = torch.cuda.Stream()
+
     def body(sync):
-        r = Rig(xq)
+        r = Rig(xq, env_stream=C.c_void_p(side.cuda_stream))
         r.delay(r.env.stream())
         r.env.selfplay_step_dev(0, 96, 0.1, replay=r.rp)
         if sync:
@@ -175,9 +193,9 @@ def test_rebuild_then_env_step_reads_the_maximum_snapshot(xq):
     """xq_replay_per_rebuild snapshots the running maximum -> xq_env_selfplay_step gives it to the new transitions."""
     def body(sync):
         r = Rig(xq, per=True)
-        r.rp.set_priorities(np.full(8, 7.5, np.float32), first=0)       # raises the running maximum (host call, synchronous)
+        r.rp.set_priorities(np.full(8, 50.0, np.float32), first=0)       # raises the running maximum (host call, synchronous)
         r.delay(r.rp.stream())
-        r.rp.per_rebuild()                                              # snapshot: 7.5
+        r.rp.per_rebuild()                                              # snapshot: 50
         if sync:
             dsync()
         r.env.selfplay_step_dev(0, 96, 0.1, replay=r.rp)                # new slots [2N, 3N) enter with the snapshot
@@ -186,7 +204,7 @@ def test_rebuild_then_env_step_reads_the_maximum_snapshot(xq):
         return out
     res = legs(xq, xq._capi.ORDER_RING_PRIORITIES, body)
     check(res)
-    assert (res[0][res[0] > 0] == np.float32(7.5)).all()
+    assert (res[0][res[0] > 0] == np.float32(50.0)).all()
 
 
 def test_rebuild_between_a_draw_and_its_td_step_keeps_the_batch_maximum(xq):
@@ -251,6 +269,8 @@ def test_parameters_rewritten_between_trainer_iterations(xq):
         t = xq.Trainer(cfg)
         t.step(3)
         dsync()
+        t.replay.sample(256, host=False)                                # (allocates the slot list: not inside the sequence under test)
+        dsync()
         stream = t.dqn.stream()
         for _ in range(2):
             xq._capi.call("xq_debug_stream_delay", C.c_void_p(stream), DELAY_US)
@@ -280,6 +300,9 @@ def test_stream_wait_stream_orders_raw_pointer_exchanges(xq, direction):
     def body(mode):                      # "sync" | "wait" | "nothing"
         r = Rig(xq, prefill=0)
         q = torch.zeros((N, 96), dtype=torch.float32, device="cuda")
+        xq._capi.call("xq_dqn_select_q_dev", r.d.handle, C.c_void_p(r.env.boards_dev()), N, C.c_void_p(q.data_ptr()))   # allocates
+        dsync()
+        q.zero_()
         dsync()
         es, ds = r.env.stream(), r.d.stream()
         if direction == "q_to_env":
