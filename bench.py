@@ -41,6 +41,10 @@ CONFIGS = {
                      "minibatch 8192, one update per ply",
             games=8192, layers=(1260, 256, 256, 8100), replay=1 << 20, minibatch=8192, plies=1, td="online", dtype="f32",
             prioritized=0, bf16=False),
+    3: dict(workload="BASELINE configs[2]: 8192 self-play games per GPU, N GPUs as INDEPENDENT shards (own games, own replay ring, own "
+                     "replica; no gradient all-reduce) — the embarrassingly-parallel env scaling curve; per GPU the same work as configs[1]",
+            games=8192, layers=(1260, 256, 256, 8100), replay=1 << 20, minibatch=8192, plies=1, td="online", dtype="f32",
+            prioritized=0, bf16=False, independent=True),
     4: dict(workload="BASELINE configs[3], per-GPU share (65536 games / 8): 8192 games, DQN 1260-512-512-512-8100 fp32, one update "
                      "(gradient all-reduce when N > 1) per 4 env steps, replay 1M, minibatch 8192",
             games=8192, layers=(1260, 512, 512, 512, 8100), replay=1 << 20, minibatch=8192, plies=4, td="online", dtype="f32",
@@ -52,10 +56,8 @@ CONFIGS = {
             games=16384, layers=(1260, 512, 512, 512, 8100), replay=1 << 20, minibatch=16384, plies=1, td="double", dtype="bf16",
             prioritized=1, bf16=True),
 }
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (the 5 PF headline figure includes 2:1 sparsity)
-PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
-ENV_BYTES_PER_GAME = 2 * (48 + 16) + 360 + 105   # board+meta r/w, Q row, transition record
+from cn_chess_ai_amd.workmodel import (PEAK_F32_MFMA_TFLOPS, PEAK_BF16_MFMA_TFLOPS, PEAK_HBM_GBS, ENV_BYTES_PER_GAME,   # noqa: E402
+                                        ROCPROF_NAMES, step_work, price)   # (no torch, no HIP: plain arithmetic)
 
 
 def cpu_train_loop(seconds, net=(1260, 128, 8100)):
@@ -139,19 +141,31 @@ def pmc_traffic(kernel_substring, config=2):
     return None, None
 
 
-def env_instruction_mix():
-    """Wave-instructions per board of env_kernel<SELFPLAY> from the newest committed PMC summary (profiles/*env_kernel_instruction*.json,
-    tools/env_pmc.sh: SQ_INSTS_* of the env-only launch at 8192 boards).  None if absent."""
+def env_instruction_mix(config=2, n_boards=8192):
+    """Wave-instructions per board of env_kernel<SELFPLAY> AS THE TRAINING LOOP RUNS IT (Q-policy launch: reads the select head's
+    slabs, sums them, tanh) from the SQ_INSTS_* counters of the newest committed PMC summary of this configuration — the same file
+    `traffic` comes from, i.e. the same build and the same bench command as the newest kernel-stats set (the round-2
+    env-only profile priced a kernel that no longer runs).  None when that summary has no instruction counters for the kernel."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*env_kernel_instruction*.json")))
+    if config == 2:
+        files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")) if "_config" not in os.path.basename(f))
+    else:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_config%d_pmc_hbm_traffic.json" % config)))
     if not files:
         return None
     try:
         d = json.load(open(files[-1]))
-        m = d.get("after", d)["instruction_mix_per_launch_8192_boards"]
-        return {"total": m["wave_instructions_per_board"], "valu": m["SQ_INSTS_VALU_per_board"], "salu": m["SQ_INSTS_SALU_per_board"],
-                "lds": m["SQ_INSTS_LDS_per_board"], "smem": m["SQ_INSTS_SMEM_per_board"], "vmem": m["SQ_INSTS_VMEM_per_board"],
-                "source": os.path.relpath(files[-1], ROOT)}
+        sq = next(v["sq"] for k, v in d.items() if "env_kernel<2>" in k)
+        per = {k: sq.get("SQ_INSTS_" + k.upper(), 0.0) / n_boards for k in ("valu", "salu", "lds", "smem", "vmem")}
+        if per["valu"] <= 0 or per["salu"] <= 0:
+            return None
+        out = dict(per)
+        out["total"] = sum(per.values())
+        out["smem_counted"] = "SQ_INSTS_SMEM" in sq
+        if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_WAIT_ANY") is not None:
+            out["wait_any_frac_of_wave_cycles"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+        out["source"] = os.path.relpath(files[-1], ROOT)
+        return out
     except Exception:
         return None
 
@@ -177,6 +191,134 @@ def env_only(args, xq, tstream):
                       "games": args.games, "steps": args.steps, "us_per_launch": ms * 1e3,
                       "algorithmic_GBps": bytes_per / (ms * 1e-3) / 1e9, "episodes_finished": c["episodes"]}), flush=True)
     env.close()
+
+
+def greedy_match(xq, dqn, stream, n=2048, greedy_colour=0, seed=0xC0FFEE):
+    """n fresh games, `greedy_colour` (0 Red, 1 Black) plays the net's greedy move (epsilon 0: first strict maximum of q[action.to],
+    dqn.cpp:36-52), the other side uniformly at random; every game counts until its FIRST end.  Move-cap endings with both generals
+    alive are draws here (ChessBoard::getWinner() calls them Red, SURVEY E16)."""
+    import numpy as np
+    env = xq.VecEnv(n, seed=seed, stream=C.c_void_p(stream))
+    open_ = np.ones(n, bool)
+    wins = {"greedy": 0, "random": 0, "draw_move_cap": 0}
+    plies_sum = 0
+    for ply in range(200):
+        if (ply & 1) == greedy_colour:
+            q = dqn.q_boards(env, 96).cpu().numpy()[:, :90]
+            res = env.selfplay_step(q, eps=0.0)
+        else:
+            res = env.selfplay_step(None)
+        ended = open_ & (res["terminated"] != 0)
+        for i in np.nonzero(ended)[0]:
+            r = res[i]
+            if r["move_count"] >= 200 and r["red_score"] < 1000 and r["black_score"] < 1000:
+                wins["draw_move_cap"] += 1
+            elif int(r["winner"]) == greedy_colour:
+                wins["greedy"] += 1
+            else:
+                wins["random"] += 1
+            plies_sum += int(r["move_count"])
+        open_ &= ~ended
+        if not open_.any():
+            break
+    env.close()
+    done = n - int(open_.sum())
+    return {"games": n, "greedy_colour": "Red" if greedy_colour == 0 else "Black", "finished": done, **wins,
+            "greedy_win_rate": wins["greedy"] / max(done, 1), "random_win_rate": wins["random"] / max(done, 1),
+            "mean_plies": plies_sum / max(done, 1)}
+
+
+def sustain_mode(args, xq, t, one_step, stream, n_games, minibatch, plies, CFG):
+    """--sustain N: the headline loop for N updates from a random initialisation, reference-scale rewards (evaluateBoard's raw
+    integers, +-1000s, against tanh outputs — chessai.cpp:311-345 / dqn.cu:184-195), as a real train() spends its life.  At update
+    0, 10^2, 10^3, 10^4, 2*10^4 (those <= N) and N: step time over a 200-step window, candidate statistics of the screened maximum,
+    guard fallbacks, loss, saturation of the outputs; then a greedy-vs-random match.  One JSON line."""
+    import numpy as np
+    import torch
+    marks = sorted({m for m in (0, 100, 1000, 10000, 20000, args.sustain) if m <= args.sustain})
+    window = 200
+    ck = []
+    u = 0
+
+    def run(k):
+        nonlocal u
+        for _ in range(k):
+            one_step()
+        u += k
+
+    t0_all = time.perf_counter()
+    for m in marks:
+        if m - u > window:
+            run(m - u - window if m >= window else 0)
+        torch.cuda.synchronize()
+        q0, g0 = t.dqn.qmax_stats(), t.dqn.qmax_guard()
+        k = min(window, max(m - u, 0)) if m > 0 else 0
+        ms = None
+        if k > 0:
+            a = time.perf_counter()
+            run(k)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - a) / k
+        q1, g1 = t.dqn.qmax_stats(), t.dqn.qmax_guard()
+        loss = t.dqn.last_loss() / minibatch if u > 0 else None
+        qall = t.dqn.q_boards(t.env, 8100)                      # tanh outputs of every action for the current boards of all games
+        sat = float((qall.abs() > 0.999).float().mean().item())
+        sat90 = float((qall[:, :90].abs() > 0.999).float().mean().item())
+        mean_abs = float(qall.abs().mean().item())
+        spread = float((qall.max(dim=1).values - qall.min(dim=1).values).mean().item())
+        del qall
+        c = t.counters()
+        _, meta = t.env.get_state()
+        ck.append({"updates": u, "ms_per_step": ms, "window_steps": k,
+                   "candidate_groups_per_sample": (q1[2] - q0[2]) / max(q1[1] - q0[1], 1) if q1[1] > q0[1] else None,
+                   "whole_groups_per_sample": (q1[3] - q0[3]) / max(q1[1] - q0[1], 1) if q1[1] > q0[1] else None,
+                   "screened_steps_in_window": q1[0] - q0[0], "guard_fallbacks_total": g1[0], "guard_hold_steps_left": g1[1],
+                   "mean_td_loss_per_sample": loss, "frac_outputs_saturated": sat, "frac_select_outputs_saturated": sat90,
+                   "mean_abs_q": mean_abs, "mean_q_spread_per_board": spread, "episodes": c["episodes"], "mean_ply": float(np.mean(meta[:, 0]))})
+        print("[sustain] " + json.dumps(ck[-1]), file=sys.stderr, flush=True)
+    total_s = time.perf_counter() - t0_all
+    times = [c["ms_per_step"] for c in ck if c["ms_per_step"]]
+    match = [greedy_match(xq, t.dqn, stream, 2048, 0), greedy_match(xq, t.dqn, stream, 2048, 1)]
+    out = {"mode": "sustain", "metric": "headline loop (BASELINE configs[%d]) sustained for %d updates" % (args.config - 1, args.sustain),
+           "workload": CFG["workload"], "updates": u, "env_steps": u * n_games * plies, "wall_seconds_including_checkpoints": total_s,
+           "rewards": "raw evaluateBoard integers (reference scale)", "qmax": args.qmax, "checkpoints": ck,
+           "ms_per_step_min": min(times) if times else None, "ms_per_step_max": max(times) if times else None,
+           "slowest_over_fastest": max(times) / min(times) if times else None,
+           "greedy_vs_random": match}
+    print(json.dumps(out), flush=True)
+
+
+def facade_leg(n_games, layers, replay, minibatch, episodes, derive, prefill):
+    """The drop-in entry point itself: examples/train_selfplay.cpp = what the reference's Worker::process() does
+    (include/mainwindow.h:140-150 -> ChessAI::train(n), chessai.cpp:85) through include/xq/xq.hpp, as a process of its own, with the
+    replay ring and the throughput schedule switched on (xq::ChessAI::setReplay).  Built with plain g++ when missing.  Returns the
+    child's JSON (counters + wall seconds of the loop inside train()) or {"error": ...}; never raises."""
+    import tempfile
+    try:
+        exe = os.path.join(ROOT, "examples", "_build", "train_selfplay")
+        src = os.path.join(ROOT, "examples", "train_selfplay.cpp")
+        hdr = os.path.join(ROOT, "include", "xq", "xq.hpp")
+        lib = os.path.join(ROOT, "cn_chess_ai_amd", "libxqhip.so")
+        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(lib)):
+            os.makedirs(os.path.dirname(exe), exist_ok=True)
+            pkg = os.path.join(ROOT, "cn_chess_ai_amd")
+            subprocess.check_call(["g++", "-std=c++17", "-O2", src, "-o", exe, "-I" + os.path.join(ROOT, "include"), "-L" + pkg, "-lxqhip",
+                                   "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"], timeout=300)
+        with tempfile.TemporaryDirectory() as tmp:          # the facade opens game_log.txt in its working directory (chessai.cpp:17)
+            cmd = [exe, str(episodes), os.path.join(tmp, "model.bin"), str(n_games), "--replay", str(replay), "--minibatch", str(minibatch),
+                   "--hidden", ",".join(str(x) for x in layers[1:-1]), "--save-every", "0", "--prefill", str(prefill), "--seed", "0x5EED",
+                   "--json"] + (["--derive"] if derive else [])
+            t0 = time.perf_counter()
+            out = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp, timeout=600)
+            wall = time.perf_counter() - t0
+        if out.returncode != 0:
+            return {"error": "train_selfplay exited with %d: %s" % (out.returncode, out.stderr.strip()[-300:])}
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        d["process_wall_seconds"] = wall
+        d["command"] = " ".join(["examples/_build/train_selfplay"] + cmd[1:2] + ["<tmp>/model.bin"] + cmd[3:])
+        return d
+    except Exception as e:
+        return {"error": str(e)[:300]}
 
 
 def self_launch(n_ranks, argv):
@@ -235,7 +377,8 @@ def main():
     ap.add_argument("--independent", action="store_true",
                     help="BASELINE configs[2]: N > 1 ranks train independent replicas on their own game shards, no gradient all-reduce")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
-                    help="BASELINE.json configs entry, 1-based: 2 = configs[1] (headline, default), 4 = configs[3] share, 5 = configs[4] share")
+                    help="BASELINE.json configs entry, 1-based: 2 = configs[1] (headline, default), 3 = configs[2] (independent shards, no "
+                         "all-reduce), 4 = configs[3] share, 5 = configs[4] share")
     ap.add_argument("--prefill-plies", type=int, default=300,
                     help="uniform-random plies played in every game before anything is timed (spreads the games over all phases)")
     ap.add_argument("--no-fill", action="store_true", help="diagnostic: do not fill the replay ring before timing")
@@ -262,6 +405,16 @@ def main():
                          "back; ms_per_step / value are the MEDIAN repetition, all of them are listed in ms_per_step_samples")
     ap.add_argument("--settle-steps", type=int, default=100,
                     help="untimed training steps between the W warm-up steps and the timed region (reported in config.steady_state)")
+    ap.add_argument("--strict-rccl", action="store_true",
+                    help="N > 1: exit non-zero instead of falling back to torch.distributed when the RCCL communicator behind the C ABI "
+                         "cannot be created on every rank")
+    ap.add_argument("--no-chain", action="store_true", help="skip the per-kernel leg (roofline_chain): A/B runs")
+    ap.add_argument("--chain-steps", type=int, default=10, help="untimed steps per kernel in the per-kernel leg (one bracketed kernel at a time)")
+    ap.add_argument("--no-facade", action="store_true", help="skip the C++ facade leg (examples/train_selfplay through xq::ChessAI::train)")
+    ap.add_argument("--facade-episodes", type=int, default=400000, help="episodes the facade leg trains for (~1.5 s of GPU at 8192 games)")
+    ap.add_argument("--sustain", type=int, default=0,
+                    help="sustained-run mode: N updates of the headline loop with checkpoints (step time, screening statistics, loss, "
+                         "saturation) and a greedy-vs-random match at the end; prints ONE JSON line of its own (profiles/*_sustain.json)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="queue collect and learn on one stream (collect -> learn -> apply) instead of running collect beside learn_grads")
     args = ap.parse_args()
@@ -299,6 +452,8 @@ def main():
     global LAYERS, REPLAY
     CFG = CONFIGS[args.config]
     LAYERS, REPLAY = CFG["layers"], CFG["replay"]
+    if CFG.get("independent"):
+        args.independent = True
     n_games = args.games if args.games != N_GAMES or args.config == 2 else CFG["games"]
     minibatch = args.minibatch or (CFG["minibatch"] if n_games == CFG["games"] else n_games)
     if args.td_net is None:
@@ -321,16 +476,19 @@ def main():
     if args.no_td_tail: t.dqn.set_td_tail(False)  # A/B: the gradient kernels one by one on two streams (library default: fused launches)
     if args.exchange_overlap >= 0: t.dqn.set_exchange_overlap(args.exchange_overlap)
     grads, comm, comm_error = None, None, ""
+    exchange = "none (one GPU)" if world == 1 else "none (independent shards)" if args.independent else None
     if world == 1 and os.environ.get("XQ_BENCH_COMM1"):
         # rehearsal on one GPU: a one-rank communicator attached, so that the whole N > 1 code path of the library runs (one launch
         # that reduces the partial sums, the all-reduce behind it, unfused SGD) — shows what that path costs besides the wire time
         comm = xd.Comm(rank=0, world=1)
         t.set_comm(comm)
+        exchange = "RCCL behind the C ABI (one-rank rehearsal)"
     elif world == 1 or args.independent:
         t.dqn.set_fused_apply(True)          # nothing reads the gradient buffer between td_grads and apply_grads
     elif args.torch_allreduce or backend != "nccl":   # diagnostic / one-GPU gloo rehearsal: the exchange through torch.distributed
         ptr, n = t.dqn.grad_buffer()
         grads = xd.wrap_device_floats(ptr, n)
+        exchange = "torch.distributed (%s)" % ("--torch-allreduce" if args.torch_allreduce else "backend %s: one-GPU rehearsal" % backend)
     else:
         # the exchange step lives behind the C ABI: learn_grads all-reduces the gradient buffer over RCCL itself, right behind the
         # launch that produces it (xq_dqn_set_comm); torch.distributed only carries the 128-byte id and barriers
@@ -347,10 +505,15 @@ def main():
                 t.set_comm(None)
                 comm.close()
                 comm = None
+            if args.strict_rccl:
+                raise SystemExit(f"[rank {rank}] --strict-rccl: C-ABI communicator unavailable ({comm_error or 'another rank failed'})")
             ptr, n = t.dqn.grad_buffer()
             grads = xd.wrap_device_floats(ptr, n)
+            exchange = "torch.distributed (fallback)"
             print(f"[rank {rank}] C-ABI communicator unavailable ({comm_error or 'another rank failed'}): all-reduce through torch.distributed",
                   file=sys.stderr)
+        else:
+            exchange = "RCCL behind the C ABI"
 
     def one_step():
         if args.no_overlap:
@@ -371,12 +534,51 @@ def main():
     fill_collects = 0 if args.no_fill else (cap + n_games - 1) // n_games
     for _ in range(fill_collects):
         t.collect()                          # epsilon-greedy plies on the initial net, transitions into the ring
+    if args.sustain > 0:
+        if world != 1:
+            raise SystemExit("--sustain is a one-GPU diagnostic")
+        t.dqn.kernel_stats(enable=0)
+        sustain_mode(args, xq, t, one_step, stream, n_games, minibatch, plies, CFG)
+        t.close()
+        return
     # the HIP-event brackets of the roofline leg run during the warm-up too (the library's event pool is then filled before anything is
     # timed), and `--settle-steps` more untimed steps follow the W warm-up steps: with the driver's short windows (W = 5, K = 20: 5 ms)
     # the first repetitions otherwise still see the chip ramping up from the host-side preparation (0.2056, 0.2028, 0.1981, 0.1922,
     # 0.1921 ms per step over five repetitions on one run)
-    t.dqn.kernel_stats(enable=2 if args.profile_all else 3 if args.bracket_all else 4)
+    live_mode = 2 if args.profile_all else 3 if args.bracket_all else 4
+    t.dqn.kernel_stats(enable=live_mode)
     for _ in range(args.warmup + args.settle_steps):
+        one_step()
+    torch.cuda.synchronize()
+
+    # ---- per-kernel leg (untimed): every kernel of the step measured IN the loop with only its own HIP-event bracket in it -----------
+    # (a bracket costs its stream ~6-10 us, so bracketing everything at once — --profile-all — stretches the step by a third; one
+    # kernel at a time leaves the co-scheduling of the two chains as it is in the timed region).  Names: 3 steps with every bracket
+    # on; then `--chain-steps` steps per name.  The kernel with the largest share of the step becomes `roofline` and is the one
+    # bracketed (every 4th launch) inside the timed region.
+    chain = {}
+    if not args.no_chain and not args.profile_all:
+        t.dqn.kernel_stats(enable=2)
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        names = [k["name"] for k in t.dqn.kernel_stats(enable=0) if k["launches"]]
+        for nm in names:
+            t.dqn.kernel_filter([nm])
+            t.dqn.kernel_stats(enable=3)
+            for _ in range(args.chain_steps):
+                one_step()
+            torch.cuda.synchronize()
+            for k in t.dqn.kernel_stats(enable=0):
+                if k["name"] == nm and k["launches"]:
+                    chain[nm] = dict(avg_us=1e3 * k["ms"] / k["launches"], launches_per_step=k["launches"] / args.chain_steps)
+        torch.cuda.synchronize()
+    per_step_us = {k: v["avg_us"] * v["launches_per_step"] for k, v in chain.items()
+                   if v["launches_per_step"] >= 0.5 and k != "rccl_allreduce_grads"}       # (a target sync every 10th step is not a step kernel)
+    dominant = max(per_step_us, key=per_step_us.get) if per_step_us else None
+    live_names = [n for n in (dominant, "gemm_qmax_screen", "gemm_qmax_rowmax", "env_selfplay_step", "rccl_allreduce_grads") if n]
+    t.dqn.kernel_filter(sorted(set(live_names)) if dominant else None)
+    for _ in range(8):                       # back to the sparse live brackets
         one_step()
     torch.cuda.synchronize()
     c0 = t.counters()
@@ -404,12 +606,13 @@ def main():
         return runs[mid][0], runs[mid][1], [r[0] for r in runs]
 
     qstat0 = t.dqn.qmax_stats()
-    # the dominant GEMM is bracketed with HIP events on every 4th launch of the timed region (--bracket-all: every launch): a
-    # bracket is two event records, and a record drains the recording queue — ~10 us each time on a 250-us step
-    t.dqn.kernel_stats(enable=2 if args.profile_all else 3 if args.bracket_all else 4)
+    # the priced kernels are bracketed with HIP events on every 4th launch of the timed region (--bracket-all: every launch): a
+    # bracket is two event records, and a record drains the recording queue — ~10 us each time on a 190-us step
+    t.dqn.kernel_stats(enable=live_mode)
     elapsed, host_enqueue, samples = timed(args.steps)
     stats = {s["name"]: s for s in t.dqn.kernel_stats(enable=0)}
     c1 = t.counters()
+    comm_info = comm.info() if comm is not None else None
     # the other TD rule on the same trainer, same steady state, timed the same way (reported beside the headline)
     other, el_other = None, None
     if args.config == 2 and args.td_net in ("online", "target") and not args.no_variants:
@@ -565,7 +768,109 @@ def main():
         g = stats.get("gemm_qmax_screen") or stats.get("gemm_qmax_rowmax")
         if g and g["launches"]:
             scr = "gemm_qmax_screen" in stats
-            line["roofline"] = gemm_roofline(g, iso.get("gemm_qmax_screen" if scr else "gemm_qmax_rowmax"), scr)
+            # the matrix-pipe kernel of the TD target (rounds 1-3 reported it as `roofline`; it is no longer the longest kernel)
+            line["roofline_qmax"] = gemm_roofline(g, iso.get("gemm_qmax_screen" if scr else "gemm_qmax_rowmax"), scr)
+        # ---- every kernel of the step priced against its own bound ------------------------------------------------
+        work = step_work(LAYERS, minibatch, n_games, plies, bf16=CFG["bf16"], bf16_bwd=CFG["bf16"] and not args.bf16_fp32_backward,
+                         td=args.td_net, screened=screened_live, derive=not args.no_derive, prioritized=bool(CFG["prioritized"]))
+
+        def rocprof_kernel(name):
+            """substring of the kernel name rocprofv3 prints for a bracket name (None: several instances share the bracket)"""
+            Hl, dbl = LAYERS[-2], args.td_net == "double"
+            if name == "gemm_qmax_screen" or (name == "gemm_qmax_rowmax" and CFG["bf16"] and Hl in (256, 512)):
+                ku = Hl // 256
+                return "screen_top2_kernel<%d, %d, %d, 0>" % (ku, 2 // ku, 0 if name == "gemm_qmax_screen" else 1 if dbl else 2)
+            if name == "gemm_qmax_rowmax":
+                return "gemm_colmax_persistent_kernel<2, 2, %d, %d>" % (1 if CFG["bf16"] else 0, 1 if dbl else 0)
+            if name == "gemm_hidden_fwd" and not CFG["bf16"]:
+                chains = 3 if dbl else 2
+                big = ((minibatch + 127) // 128) * ((LAYERS[2] + 127) // 128) * chains >= 512
+                return "gemm_f32_kernel<0, 0, 1, %s, 0>" % ("2, 2" if big else "1, 1")
+            if name == "gemm_hidden_fwd@select" and not CFG["bf16"] and len(LAYERS) == 4:
+                return "gemm_f32_kernel<0, 0, 4, 1, 1, 0>"      # one hidden product per ply, the select head riding on it
+            if name == "qmax_refine":
+                return "qmax_refine2_kernel<" if Hl in (256, 512) else "qmax_refine_kernel<"
+            return ROCPROF_NAMES.get(name)
+
+        def chain_entry(name, avg_us, lps, live=None):
+            e = {"kernel": name, "avg_us": avg_us, "launches_per_step": lps,
+                 "stream": "collect (select chain)" if name.endswith("@select") or name == "env_selfplay_step" else "handle (TD step)"}
+            wk = work.get(name)
+            if wk:
+                ach, frac = price(wk, avg_us)
+                e.update(bound=wk["bound"], achieved=ach, peak=wk["peak"], unit=wk["peak_unit"], frac=frac, flops_per_launch=wk["flops"],
+                         hbm_bytes_per_launch=wk["hbm_bytes"], what=wk["what"])
+            rk = rocprof_kernel(name)
+            e["rocprof_kernel"] = rk
+            if rk:
+                tr, src = pmc_traffic(rk, args.config)
+                e["traffic"] = tr
+                e["traffic_source"] = src
+                if tr and wk and wk["hbm_bytes"]:
+                    e["traffic_over_algorithmic"] = tr / wk["hbm_bytes"]
+            if live:
+                e.update(live)
+            return e
+
+        if chain:
+            step_us = 1e3 * line["ms_per_step"]
+            entries = [chain_entry(k, v["avg_us"], v["launches_per_step"]) for k, v in chain.items()]
+            crit = [e for e in entries if e["stream"].startswith("handle") and e["launches_per_step"] >= 0.5]
+            sel = [e for e in entries if e["stream"].startswith("collect")]
+            rare = [e for e in entries if e["stream"].startswith("handle") and e["launches_per_step"] < 0.5]
+            crit_us = sum(e["avg_us"] * e["launches_per_step"] for e in crit)
+            sel_us = sum(e["avg_us"] * e["launches_per_step"] for e in sel)
+            for e in entries:
+                e["share_of_step"] = e["avg_us"] * e["launches_per_step"] / step_us
+            line["roofline_chain"] = {
+                "how": "each kernel measured IN the training loop with only its own HIP-event bracket in it (%d untimed steps per kernel, "
+                       "between the settle steps and the timed region); a bracket reads ~%.1f us more than the kernel itself "
+                       "(hip_event_bracket_of_an_empty_kernel_us); algorithmic FLOPs / compulsory HBM bytes: cn_chess_ai_amd/workmodel.py = "
+                       "DESIGN.md section 5; traffic: rocprofv3 PMC of the same command (profiles/)" % (args.chain_steps, 1e3 * bracket_ms),
+                "hip_event_bracket_of_an_empty_kernel_us": 1e3 * bracket_ms,
+                "step_us": step_us,
+                "handle_stream": crit, "handle_stream_sum_us": crit_us,
+                "handle_stream_unaccounted_us": step_us - crit_us,
+                "handle_stream_unaccounted_note": "step time minus the sum of the kernels queued on the handle's stream: cross-stream waits "
+                                                  "(collect fork / join), kernel boundaries, minus the bracket overhead contained in every avg_us",
+                "collect_stream": sel, "collect_stream_sum_us": sel_us,
+                "collect_stream_note": "runs beside the TD step (one ply per update: ends before the gradients do) — or IS the long pole of "
+                                       "the step when an update has several plies",
+                "less_than_once_per_step": rare,
+            }
+            if dominant:
+                dom = next(e for e in entries if e["kernel"] == dominant)
+                st = stats.get(dominant)
+                r = {"kernel": "%s = %s (%s)" % (dominant, dom.get("rocprof_kernel"), dom.get("what", "")),
+                     "why_this_kernel": "largest share of the timed step among all kernels of both streams (%.0f %%); rounds 1-3 priced the "
+                                        "max_a' Q(s',a') product here, now `roofline_qmax`" % (100 * dom["share_of_step"]),
+                     "bound": dom.get("bound"), "peak": dom.get("peak"), "unit": dom.get("unit"), "traffic": dom.get("traffic"),
+                     "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, offline)", "traffic_source": dom.get("traffic_source"),
+                     "share_of_step": dom["share_of_step"], "launches_per_step": dom["launches_per_step"]}
+                wk = work.get(dominant)
+                if st and st["launches"] and wk:         # measured live inside the timed region (every 4th launch)
+                    ms = st["ms"] / st["launches"]
+                    ach, frac = price(wk, 1e3 * ms)
+                    r.update(achieved=ach, frac=frac, avg_launch_ms=ms, launches=st["launches"],
+                             launches_note="HIP-event brackets inside the timed region, on " +
+                                           ("every launch" if args.bracket_all or args.profile_all else "every 4th launch"),
+                             flops_per_launch=wk["flops"], hbm_bytes_per_launch=wk["hbm_bytes"],
+                             hip_event_bracket_of_an_empty_kernel_ms=bracket_ms)
+                elif wk:
+                    r.update(achieved=dom.get("achieved"), frac=dom.get("frac"), avg_launch_ms=1e-3 * dom["avg_us"],
+                             launches_note="from the per-kernel leg (no live bracket landed in the timed region)")
+                if "achieved" in r:
+                    line["roofline"] = r
+        if "roofline" not in line and "roofline_qmax" in line:       # --no-chain / --profile-all: the matrix-pipe kernel as before
+            line["roofline"] = line["roofline_qmax"]
+        a = stats.get("rccl_allreduce_grads")
+        line["exchange"] = {"path": exchange, "rccl_behind_c_abi": comm is not None, "comm": comm_info,
+                            "gradient_buffer_bytes": 4 * t.dqn.grad_buffer()[1]}
+        if a and a["launches"]:
+            line["exchange"]["allreduce_avg_ms"] = a["ms"] / a["launches"]
+            line["exchange"]["allreduce_launches_bracketed"] = a["launches"]
+            line["exchange"]["allreduce_note"] = ("HIP-event bracket around the collective on the handle's stream, every 4th step of the timed "
+                                                  "region: queueing + wire time as the TD step sees it")
         if qmax_info is not None:
             line["config"]["qmax"] = qmax_info
         if full_variant is not None:
@@ -588,7 +893,7 @@ def main():
                                     "launches_note": "HIP-event brackets on " + ("every launch" if args.bracket_all or args.profile_all else
                                                      "every 5th launch (the brackets sit on the collect stream: ~12 us per ply, which "
                                                      "is the critical chain when an update has several plies)")}
-            mix = env_instruction_mix() if args.config == 2 else None
+            mix = env_instruction_mix(args.config, n_games) if n_games == CFG["games"] else None
             if mix:
                 # the bound that actually applies: instruction issue.  Floor = the larger of the VALU issue time (a wave64 VALU
                 # instruction occupies its SIMD-32 for 2 cycles; 4 SIMDs per CU) and the scalar issue time (one scalar unit per
@@ -599,10 +904,12 @@ def main():
                 line["roofline_env"]["issue"] = {
                     "bound": "issue", "wave_instructions_per_board": mix["total"], "valu": mix["valu"], "salu": mix["salu"],
                     "lds": mix["lds"], "smem": mix["smem"], "vmem": mix["vmem"], "source": mix["source"],
+                    "wait_any_frac_of_wave_cycles": mix.get("wait_any_frac_of_wave_cycles"),
                     "floor_us": floor_us, "valu_issue_us": valu_us, "scalar_issue_us": salu_us,
                     "frac": floor_us / (ms * 1e3),
                     "note": "one wavefront per board: ~%d wave-instructions per board-ply (move generation alone ~400); BASELINE's "
-                            ">= 40 %% of HBM peak would need ~100 — the HBM figure above is reported, but it is not the bound of this kernel"
+                            ">= 40 %% of HBM peak would need ~100 — the HBM figure above is reported, but it is not the bound of this kernel; "
+                            "wait_any_frac_of_wave_cycles says how much of a wave's life is dependent latency rather than issue"
                             % round(mix["total"])}
             ei = iso.get("env_selfplay_step")
             if ei and ei["launches"]:
@@ -614,6 +921,15 @@ def main():
         if args.profile_all:
             line["kernels"] = {k: {"ms_per_launch": v["ms"] / max(v["launches"], 1), "launches": v["launches"]}
                                for k, v in stats.items()}
+        if world == 1 and not args.no_facade and args.config == 2 and n_games == CFG["games"]:
+            # the trainer of this process is idle now (everything synchronised); the facade process gets the GPU to itself
+            f = facade_leg(n_games, LAYERS, max(REPLAY, n_games), minibatch, args.facade_episodes, not args.no_derive, args.prefill_plies)
+            if "env_steps_per_s" in f:
+                f["vs_headline"] = f["env_steps_per_s"] / line["value"]
+                f["note"] = ("the C++ entry point a maintainer calls (mainwindow.h:140-150 -> ChessAI::train) on the same schedule as the "
+                             "ctypes loop above; its clock starts with an EMPTY ring and includes the ring fill, the episode drains (one device "
+                             "synchronisation per 64 iterations) and a gameCompleted callback per episode")
+            line["facade"] = f
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline() if args.config == 2 else cpu_baseline(6.0)

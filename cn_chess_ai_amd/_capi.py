@@ -126,6 +126,7 @@ PROTOTYPES = {
     "xq_dqn_set_td_tail": [_vp, _i],
     "xq_dqn_set_exchange_overlap": [_vp, _i],
     "xq_dqn_qmax_stats": [_vp, C.POINTER(C.c_uint64)],
+    "xq_dqn_qmax_guard": [_vp, _pu64, _pi],
     "xq_dqn_num_params": [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "xq_dqn_set_params": [_vp, _i, _pd, _pd],
     "xq_dqn_get_params": [_vp, _i, _pd, _pd],
@@ -144,6 +145,7 @@ PROTOTYPES = {
     "xq_dqn_last_loss": [_vp, _pd],
     "xq_dqn_kernel_stats": [_vp, _i, C.POINTER(KernelStat), _i, _pi],
     "xq_dqn_set_fused_apply": [_vp, _i],
+    "xq_dqn_kernel_filter": [_vp, C.c_char_p],
     "xq_dqn_kernel_timeline": [_vp, C.POINTER(KernelSpan), _i, _pi],
     "xq_comm_unique_id": [_pu8],
     "xq_comm_create": [_i, _i, _pu8, _pvp],

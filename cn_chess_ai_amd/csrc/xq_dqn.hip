@@ -173,7 +173,19 @@ uint64_t dqn_params_version(const xq_dqn* d) { return d->params_version; }
 struct ProfScope {
     Profiler& p; hipStream_t s; int h; double flops, bytes;
     // (while a fused tail launch is being assembled nothing is launched, so nothing is bracketed: tail_launch has its own scope)
-    ProfScope(xq_dqn* d, const char* name, double fl, double by) : p(d->prof), s(d->cur), flops(fl), bytes(by) { h = d->tail_open ? -1 : p.begin(name, s); }
+    // A launch on a stream that is neither the handle's nor its side stream belongs to the select chain of the self-play loop (the
+    // trainer's collect stream): same kernels, other shapes, off the critical path — bracketed under "<name>@select".
+    ProfScope(xq_dqn* d, const char* name, double fl, double by) : p(d->prof), s(d->cur), flops(fl), bytes(by) {
+        h = -1;
+        if (d->tail_open || !p.enabled) return;
+        if (d->cur != d->stream && d->cur != d->side) {
+            char nm[48];
+            snprintf(nm, sizeof nm, "%s@select", name);
+            h = p.begin(nm, s);
+        } else {
+            h = p.begin(name, s);
+        }
+    }
     ~ProfScope() { p.end(h, s, flops, bytes); }
 };
 
@@ -2666,6 +2678,13 @@ int xq_dqn_qmax_stats(xq_dqn* d, uint64_t stats[4]) {
     return XQ_OK;
 }
 
+int xq_dqn_qmax_guard(xq_dqn* d, uint64_t* fallbacks, int* hold_steps_left) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    if (fallbacks) *fallbacks = d->scr_fallbacks;
+    if (hold_steps_left) *hold_steps_left = d->scr_hold;
+    return XQ_OK;
+}
+
 int xq_dqn_set_precision(xq_dqn* d, int precision) {
     if (!d || (precision != XQ_PRECISION_F32 && precision != XQ_PRECISION_BF16 && precision != XQ_PRECISION_BF16_FULL))
         return fail(XQ_ERR_INVALID_ARGUMENT, "bad precision");
@@ -2962,7 +2981,10 @@ static int tail_gradients(xq_dqn* d, int n, float* const* outs, float* G, int mo
     if (rc == XQ_OK && !leave_pending) {
         rc = reduce_pending(d);
         // data-parallel step: the whole buffer in one collective on the handle's stream, right behind its last producer
-        if (rc == XQ_OK && d->comm) rc = comm_allreduce_on(d->comm, G, d->n_grads_td, d->stream);
+        if (rc == XQ_OK && d->comm) {
+            ProfScope ps(d, "rccl_allreduce_grads", 0, 4.0 * d->n_grads_td);
+            rc = comm_allreduce_on(d->comm, G, d->n_grads_td, d->stream);
+        }
     }
     return rc;
 }
@@ -3502,8 +3524,14 @@ int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_st
         d->prof.enabled = enable != 0;
         d->prof.roofline_only = enable == 3 || enable == 4;
         d->prof.sample_period = enable == 4 ? 4 : 1;
-        d->prof.sample_phase = 0; d->prof.sample_phase_env = 0;
+        for (auto& o : d->prof.only) o.phase = 0;
     }
+    return XQ_OK;
+}
+
+int xq_dqn_kernel_filter(xq_dqn* d, const char* names_csv) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    d->prof.set_only(names_csv && *names_csv ? names_csv : "gemm_qmax_rowmax,gemm_qmax_screen,env_selfplay_step");
     return XQ_OK;
 }
 

@@ -130,10 +130,25 @@ struct Profiler {
     struct Span { char name[48]; float start_ms, end_ms; };      // relative to the first bracket of the batch (live timeline)
     std::vector<Span> spans;
     bool enabled = false;
-    bool roofline_only = false;   // bracket only the two kernels bench.py prices (keeps the timed region undisturbed)
-    int sample_period = 1;        // roofline_only: bracket every sample_period-th launch of a priced kernel (an event record drains
-    int sample_phase_env = 0;
-    int sample_phase = 0;         // the recording queue: ~10 us per bracket on a stream of 10-50 us kernels, tools/sync_probe.hip)
+    bool roofline_only = false;   // bracket only the kernels named in `only` (keeps the timed region undisturbed)
+    int sample_period = 1;        // roofline_only: bracket every sample_period-th launch of a named kernel (an event record drains
+                                  // the recording queue: ~10 us per bracket on a stream of 10-50 us kernels, tools/sync_probe.hip)
+    struct Only { char name[48]; int phase; int period_add; };
+    std::vector<Only> only;       // xq_dqn_kernel_filter; default = the three kernels bench.py priced in rounds 1-3
+    void set_only(const char* csv) {
+        only.clear();
+        for (const char* p = csv; p && *p;) {
+            const char* q = strchr(p, ',');
+            const size_t len = q ? (size_t)(q - p) : strlen(p);
+            Only o; memset(&o, 0, sizeof o);
+            memcpy(o.name, p, len < sizeof o.name - 1 ? len : sizeof o.name - 1);
+            // the env kernel on a period of its own, sample_period + 1: with 4 plies per update a shared period of 4 would always
+            // pick the same ply
+            o.period_add = strncmp(o.name, "env_selfplay_step", 17) == 0 ? 1 : 0;
+            if (len) only.push_back(o);
+            p = q ? q + 1 : nullptr;
+        }
+    }
     std::vector<Cat> cats;
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -149,13 +164,13 @@ struct Profiler {
     }
     int begin(const char* name, hipStream_t s) {
         if (!enabled) return -1;
-        if (roofline_only && strcmp(name, "gemm_qmax_rowmax") != 0 && strcmp(name, "gemm_qmax_screen") != 0 &&
-            strcmp(name, "env_selfplay_step") != 0) return -1;
-        // (the env kernel on a counter and a period of its own, sample_period + 1: with 4 plies per update a shared counter would
-        // never pick the GEMM, and period 4 always the same ply)
-        if (roofline_only && sample_period > 1) {
-            const bool env = strcmp(name, "env_selfplay_step") == 0;
-            if (env ? (sample_phase_env++ % (sample_period + 1)) != 0 : (sample_phase++ % sample_period) != 0) return -1;
+        if (roofline_only) {
+            if (only.empty()) set_only("gemm_qmax_rowmax,gemm_qmax_screen,env_selfplay_step");
+            Only* o = nullptr;
+            for (auto& x : only) if (!strcmp(x.name, name)) { o = &x; break; }
+            if (!o) return -1;
+            const int period = sample_period > 1 ? sample_period + o->period_add : 1;
+            if (period > 1 && (o->phase++ % period) != 0) return -1;
         }
         Rec r; r.cat = cat_id(name); r.a = get_event(); r.b = get_event();
         (void)hipEventRecord(r.a, s);

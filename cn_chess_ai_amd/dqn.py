@@ -179,6 +179,14 @@ class DQN:
                      bytes=arr[i].bytes) for i in range(n.value)]
 
 
+def _kernel_filter(self, names=None):
+    """Which launches kernel_stats(enable=3 / 4) brackets: an iterable of bracket names (None = the default three)."""
+    call("xq_dqn_kernel_filter", self._h, ",".join(names).encode() if names else None)
+
+
+DQN.kernel_filter = _kernel_filter
+
+
 def _set_precision(self, precision):
     """_capi.PRECISION_F32 / PRECISION_BF16: arithmetic of the forward passes on packed boards (bf16 MFMA Q-net)."""
     call("xq_dqn_set_precision", self._h, int(precision))
@@ -223,8 +231,16 @@ def _qmax_stats(self):
     return tuple(int(x) for x in st)
 
 
+def _qmax_guard(self):
+    """(fallbacks to the full product so far, TD steps of the current fallback still to run)."""
+    f, h = C.c_uint64(), C.c_int32()
+    call("xq_dqn_qmax_guard", self._h, C.byref(f), C.byref(h))
+    return f.value, h.value
+
+
 DQN.set_qmax_mode = _set_qmax_mode
 DQN.qmax_stats = _qmax_stats
+DQN.qmax_guard = _qmax_guard
 
 
 def _set_comm(self, comm):

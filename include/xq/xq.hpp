@@ -9,6 +9,7 @@
 // this header only marshals arguments (and keeps a host copy of the 90 board bytes for getPieceAt()).
 #pragma once
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <ctime>
@@ -452,7 +453,10 @@ public:
         if (parallelGames_ <= 1) {
             for (int e = 0; e < numEpisodes; ++e) {
                 trainEpisode();
-                if (episodes_ % 100 == 0) saveModel("model_after_" + std::to_string(episodes_) + "_games.bin");   // :165
+                if (saveInterval_ > 0 && episodes_ % saveInterval_ == 0) {                                       // :165
+                    saveModel("model_after_" + std::to_string(episodes_) + "_games.bin");
+                    savedMark_ = episodes_ / saveInterval_;
+                }
             }
         } else {
             trainBatched(numEpisodes);
@@ -487,6 +491,24 @@ public:
 
     // ---- beyond the reference surface ----
     void setParallelGames(int n) { parallelGames_ = n; }
+    // Replay ring of the batched train() — the ReplayBuffer of SURVEY section 8b ("New"; element = the arguments of DQN::train,
+    // dqn.cpp:157): `capacity` transitions in HBM, `minibatch` of them per update.  With a ring, train() runs the throughput schedule
+    // of INTEGRATION.md section 4 — the ply of iteration t on a stream of its own beside the TD step of iteration t, both on the
+    // parameters of t, the minibatch drawn from the ring minus the slots that ply writes — which is what bench.py measures.
+    // capacity 0 (default): on-policy like the reference, every update learns on the plies just played.
+    void setReplay(int capacity, int minibatch) { replayCapacity_ = capacity; replayMinibatch_ = minibatch; }
+    // "Save model every certain number of games" (chessai.cpp:164-167): model_after_<N>_games.bin every `episodes` finished episodes
+    // (default 100, the reference's literal; 0 = never).  The batched loop finishes episodes in bursts and saves ONCE per drain, under
+    // the name of the last multiple crossed.
+    void setSaveInterval(int episodes) { saveInterval_ = episodes; }
+    // layer-0 sums of s' derived from those of s in the batched TD step (xq_dqn_set_l0_derive: another summation order, ~1e-7)
+    void setLayer0Derive(bool on) { l0Derive_ = on; }
+    // uniform-random plies played in every game before the batched loop starts (spreads the games over all phases; 0 = from the opening)
+    void setPrefillRandomPlies(int n) { prefillPlies_ = n; }
+    // what the last batched train() did: plies played by this process, updates, episodes finished, wall seconds of the loop
+    // (from the first iteration queued to the last one finished, model saves included)
+    struct TrainStats { uint64_t envSteps = 0, updates = 0, episodes = 0; double seconds = 0; };
+    TrainStats lastTrainStats() const { return stats_; }
     // data-parallel train(): this process is rank comm->rank() of comm->world(); its batched games take the id range
     // [rank * parallelGames, (rank + 1) * parallelGames) and every update all-reduces the gradients over RCCL (nullptr = off)
     void setCommunicator(Comm* comm) { comm_ = comm; }
@@ -512,8 +534,15 @@ private:
         cfg.n_sizes = (int)ls.size();
         for (size_t i = 0; i < ls.size(); ++i) cfg.layer_sizes[i] = ls[i];
         cfg.learning_rate = learningRate; cfg.gamma = gamma; cfg.epsilon = 0.1;
-        cfg.replay_capacity = 0;                 // on-policy, like the reference: learn on the plies just played
-        cfg.minibatch = cfg.n_games;
+        const bool ring = replayCapacity_ > 0;
+        if (ring) {                              // setReplay(): the throughput schedule
+            cfg.replay_capacity = replayCapacity_ > cfg.n_games ? replayCapacity_ : cfg.n_games;
+            cfg.minibatch = replayMinibatch_ > 0 ? replayMinibatch_ : cfg.n_games;
+            cfg.overlap_collect = 1;             // xq_trainer_step then queues learn_grads -> collect -> learn_apply
+        } else {
+            cfg.replay_capacity = 0;             // on-policy, like the reference: learn on the plies just played
+            cfg.minibatch = cfg.n_games;
+        }
         cfg.td_net = XQ_TD_ONLINE_NET;           // chessai.cpp:126 uses the online net
         cfg.backprop_mode = XQ_BACKPROP_REFERENCE;
         cfg.target_sync_interval = 100; cfg.mean_gradient = 1;
@@ -529,15 +558,23 @@ private:
         check(xq_dqn_set_params(td, XQ_NET_ONLINE, w.data(), b.data()));
         check(xq_dqn_update_target(td));
         check(xq_dqn_set_qmax_mode(td, XQ_QMAX_SCREENED));    // same max_a' Q(s',a'), found by exact screening (large batches only)
+        check(xq_dqn_set_l0_derive(td, l0Derive_ ? 1 : 0));
         if (comm_) check(xq_trainer_set_comm(t, comm_->handle()));
+        if (prefillPlies_ > 0) check(xq_trainer_random_plies(t, prefillPlies_));
         std::vector<xq_episode_record> rec(4096);
         // Every rank must run the same number of iterations (each carries a collective): the loop ends when the episodes
         // finished on ALL ranks together reach numEpisodes per rank; a rank reports at most its own numEpisodes.
         const uint64_t quota = (uint64_t)numEpisodes * (uint64_t)(comm_ ? comm_->world() : 1);
         int finished = 0;
         uint64_t localDone = 0;
+        stats_ = TrainStats();
+        const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
-            check(xq_trainer_step(t, 8));
+            // iterations per drain: a drain synchronises the device (a pipeline bubble), so far from the end the loop runs 64
+            // iterations between two of them; close to it 8, so that few plies are played beyond the last episode asked for
+            // (the episode ring holds max(4096, 4 n_games) records: 64 iterations finish ~0.3 n_games episodes)
+            const long long left = (long long)numEpisodes - finished;
+            check(xq_trainer_step(t, left > (long long)cfg.n_games ? 64 : 8));
             int n = 0; uint64_t total = 0;
             do {
                 check(xq_env_drain_episodes(te, rec.data(), (int)rec.size(), &n, &total));
@@ -546,12 +583,20 @@ private:
                     if (gameCompleted) gameCompleted(episodes_, rec[i].red_score, rec[i].black_score);
                 }
             } while (n == (int)rec.size());
+            if (saveInterval_ > 0 && episodes_ / saveInterval_ > savedMark_) {          // chessai.cpp:164-167
+                savedMark_ = episodes_ / saveInterval_;
+                check(xq_dqn_save_model(td, ("model_after_" + std::to_string(savedMark_ * saveInterval_) + "_games.bin").c_str()));
+            }
             localDone = total;
             uint64_t global = localDone;
             if (comm_) check(xq_comm_sum_u64(comm_->handle(), &global));
             if (comm_ ? global >= quota : finished >= numEpisodes) break;
         }
-        check(xq_dqn_get_params(td, XQ_NET_ONLINE, w.data(), b.data()));
+        check(xq_dqn_get_params(td, XQ_NET_ONLINE, w.data(), b.data()));      // (synchronises: the loop's last iteration has finished)
+        stats_.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        uint64_t eps = 0;
+        check(xq_trainer_counters(t, &stats_.envSteps, &stats_.updates, &eps));
+        stats_.episodes = eps;
         dqn->setParameters(w, b);
         dqn->updateTargetNetwork();
     }
@@ -564,6 +609,11 @@ private:
     int moveCount_ = 0;
     int episodes_ = 0;
     int parallelGames_ = 8192;
+    int replayCapacity_ = 0, replayMinibatch_ = 0;
+    int saveInterval_ = 100, savedMark_ = 0;
+    bool l0Derive_ = false;
+    int prefillPlies_ = 0;
+    TrainStats stats_;
     Comm* comm_ = nullptr;
     uint64_t batchSeed_ = 0;
 };

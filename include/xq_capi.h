@@ -287,6 +287,9 @@ int xq_dqn_set_td_tail(xq_dqn* d, int on);
  * pairs whose whole group was re-evaluated. */
 int xq_dqn_set_qmax_mode(xq_dqn* d, int mode);
 int xq_dqn_qmax_stats(xq_dqn* d, uint64_t stats[4]);
+/* The guard's own counters: how often it has switched a run of TD steps to the full product so far, and how many steps of the current
+ * run are left (0 = the screen is on).  No synchronisation. */
+int xq_dqn_qmax_guard(xq_dqn* d, uint64_t* fallbacks, int* hold_steps_left);
 int xq_dqn_num_params(const xq_dqn* d, size_t* n_weights, size_t* n_biases);
 /* host_weights / host_biases in the REFERENCE flat layout (row-major [out][in] per layer, layers concatenated,
  * dqn.cu:112-140), fp64 like upstream.  set = copyToDevice() (dqn.cu:480-485), get = copyFromDevice() (:487-492). */
@@ -350,6 +353,11 @@ int xq_dqn_last_loss(xq_dqn* d, double* loss);
  * drains the stream's queue: ~10 us per bracket). */
 typedef struct { char name[48]; float ms; int launches; double flops; double bytes; } xq_kernel_stat;
 int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_stats, int* n_stats);
+/* Which launches enable = 3 / 4 bracket: a comma-separated list of bracket names as xq_dqn_kernel_stats reports them (launches of the
+ * self-play loop's select chain on the trainer's collect stream carry the suffix "@select"; "rccl_allreduce_grads" = the gradient
+ * all-reduce of a data-parallel step).  NULL / "" = the default: gemm_qmax_rowmax, gemm_qmax_screen, env_selfplay_step.  bench.py
+ * walks the kernels of the step with it one at a time (roofline_chain), so that each is measured with only its own bracket in the loop. */
+int xq_dqn_kernel_filter(xq_dqn* d, const char* names_csv);
 /* Live timeline of the brackets gathered by the last xq_dqn_kernel_stats call (enable 1/2 sessions): start/end of every
  * bracketed launch in ms relative to the first one, across the handle's streams — what a kernel trace shows, without a
  * profiler attached.  Diagnostic. */

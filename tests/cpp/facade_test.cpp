@@ -159,6 +159,32 @@ int main() {
         CHECK(completed == 41);
         ai.saveModel("/tmp/xq_facade_model.bin");
         ai.loadModel("/tmp/xq_facade_model.bin");
+        // train() with a replay ring (setReplay: the throughput schedule bench.py measures) + the periodic save of chessai.cpp:164-167:
+        // episode 100 is crossed inside this call => model_after_100_games.bin in the reference's file format, loadable
+        std::remove("model_after_100_games.bin");
+        ai.setReplay(4096, 64);
+        std::vector<double> wb, bb2, wa, ba;
+        ai.network()->getParameters(wb, bb2);
+        ai.train(70);
+        CHECK(completed == 111);
+        const xq::ChessAI::TrainStats st = ai.lastTrainStats();
+        CHECK(st.updates > 0 && st.envSteps == st.updates * 64 && st.episodes >= 70 && st.seconds > 0);
+        {
+            FILE* f = std::fopen("model_after_100_games.bin", "rb");
+            CHECK(f != nullptr);
+            if (f) { std::fseek(f, 0, SEEK_END); CHECK(std::ftell(f) == 9650484L); std::fclose(f); }   // DQN::saveModel layout, {1260,128,8100}
+        }
+        ai.network()->getParameters(wa, ba);
+        double moved = 0; for (size_t i = 0; i < wa.size(); ++i) moved = std::fmax(moved, std::fabs(wa[i] - wb[i]));
+        CHECK(moved > 0);                                  // the ring loop trained the agent's own network
+        xq::DQN probe(std::vector<int>{1260, 128, 8100}, 0.001, 0.99, 7);
+        probe.loadModel("model_after_100_games.bin");
+        std::vector<double> wp, bp;
+        probe.getParameters(wp, bp);
+        bool finite = true; for (double v : wp) finite = finite && std::isfinite(v);
+        CHECK(finite);
+        ai.setSaveInterval(0);
+        ai.setReplay(0, 0);
     }
     // ---- getAIMove, the game_log.txt line, startSelfPlay — against the oracle's restatements ----
     {

@@ -138,6 +138,11 @@ def test_two_rank_independent_shards_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and "independent shards" in line["config"]["parallelism"]
+    assert line["exchange"]["path"] == "none (independent shards)" and line["exchange"]["rccl_behind_c_abi"] is False
+    out = _rehearse(["--config", "3"])                       # the same through --config 3 (BASELINE configs[2])
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["baseline_config"] == 3 and "independent shards" in line["config"]["parallelism"] and line["n_gpus"] == 2
 
 
 def test_two_rank_rehearsal_on_one_gpu():
@@ -164,6 +169,10 @@ def test_two_rank_rehearsal_on_one_gpu():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["parallelism"].startswith("dp2")
     assert len(line["ms_per_step_samples"]) == 5
+    # the line says which path carried the exchange: here gloo stands in, so NOT the RCCL communicator behind the C ABI
+    ex = line["exchange"]
+    assert ex["rccl_behind_c_abi"] is False and ex["path"].startswith("torch.distributed") and ex["comm"] is None
+    assert ex["gradient_buffer_bytes"] == 4 * (1260 * 256 + 256 * 256 + 96 * 256 + 96 + 512)
 
 
 def test_self_launch_reports_a_failed_rank():
