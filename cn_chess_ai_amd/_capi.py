@@ -77,6 +77,8 @@ PROTOTYPES = {
     "xq_set_device": [_i],
     "xq_stream_synchronize": [_vp],
     "xq_stream_wait_stream": [_vp, _vp],
+    "xq_stream_create": [_i, _i, _pvp],
+    "xq_stream_destroy": [_vp],
     "xq_debug_stream_delay": [_vp, _i],
     "xq_debug_set_stream_ordering": [C.c_uint],
     "xq_env_stream": [_vp, _pvp],
@@ -143,6 +145,7 @@ PROTOTYPES = {
     "xq_dqn_td_grads_replay": [_vp, _vp, _i, _i, _i],
     "xq_dqn_td_update_host": [_vp, _i, _pu8, _pu8, _pi, _pf, _pu8, _i, _i, _d, _d, _pf, _pf],
     "xq_dqn_last_loss": [_vp, _pd],
+    "xq_dqn_last_td_values": [_vp, _i, _pf, _pf],
     "xq_dqn_kernel_stats": [_vp, _i, C.POINTER(KernelStat), _i, _pi],
     "xq_dqn_set_fused_apply": [_vp, _i],
     "xq_dqn_kernel_filter": [_vp, C.c_char_p],

@@ -3505,6 +3505,14 @@ int xq_dqn_last_loss(xq_dqn* d, double* loss) {
     return XQ_OK;
 }
 
+int xq_dqn_last_td_values(xq_dqn* d, int n, float* q_sa_host, float* y_host) {
+    if (!d || n < 0 || n > d->last_n) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_last_td_values: n exceeds the last TD step's %d samples", d ? d->last_n : 0);
+    XQ_HIP(hipStreamSynchronize(d->stream));
+    if (q_sa_host && n) XQ_HIP(hipMemcpy(q_sa_host, d->qsa, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (y_host && n) XQ_HIP(hipMemcpy(y_host, d->yv, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return XQ_OK;
+}
+
 int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_stats, int* n_stats) {
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
     XQ_HIP(hipStreamSynchronize(d->stream));

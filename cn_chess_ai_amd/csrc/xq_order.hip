@@ -95,6 +95,25 @@ int xq_stream_wait_stream(void* waiting_stream, void* producer_stream) {
     return XQ_OK;
 }
 
+int xq_stream_create(int priority, int nonblocking, void** out) {
+    if (!out || priority < -1 || priority > 1) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_stream_create: priority -1 (urgent), 0 or 1 (background)");
+    int least = 0, greatest = 0;                     // numerically: greatest priority = the smaller number
+    XQ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int p = priority < 0 ? greatest : priority > 0 ? least : (least + greatest) / 2;
+    hipStream_t s = nullptr;
+    XQ_HIP(hipStreamCreateWithPriority(&s, nonblocking ? hipStreamNonBlocking : hipStreamDefault, p));
+    *out = (void*)s;
+    return XQ_OK;
+}
+
+int xq_stream_destroy(void* hip_stream) {
+    if (!hip_stream) return XQ_OK;
+    XQ_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+    retire_stream((hipStream_t)hip_stream);          // no handle's bookkeeping may name it afterwards
+    XQ_HIP(hipStreamDestroy((hipStream_t)hip_stream));
+    return XQ_OK;
+}
+
 int xq_debug_stream_delay(void* hip_stream, int microseconds) {
     if (microseconds < 0 || microseconds > 200000) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_debug_stream_delay: 0..200000 us");
     if (microseconds == 0) return XQ_OK;

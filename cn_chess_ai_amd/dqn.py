@@ -170,6 +170,12 @@ class DQN:
         call("xq_dqn_last_loss", self._h, C.byref(v))
         return v.value
 
+    def last_td_values(self, n):
+        """(Q(s,a), y) of the first n samples of the last TD step."""
+        q, y = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        call("xq_dqn_last_td_values", self._h, int(n), _ptr(q, C.c_float), _ptr(y, C.c_float))
+        return q, y
+
     def kernel_stats(self, enable=-1):
         """Returns the HIP-event timings collected so far; enable: 1 on, 0 off, 2 on + clear, -1 leave."""
         arr = (KernelStat * 64)()

@@ -78,6 +78,11 @@ int xq_version(void);
 int xq_device_count(int* n);
 int xq_set_device(int device);
 int xq_stream_synchronize(void* hip_stream);
+/* A HIP stream for callers that have no HIP headers of their own (the ctypes binding, the C++ facade): priority -1 urgent, 0 normal,
+ * 1 background (streams of different priority never share a hardware queue; streams of one priority may, and then run in submission
+ * order); nonblocking != 0: not ordered against the legacy null stream.  Destroy it after the handles that run on it. */
+int xq_stream_create(int priority, int nonblocking, void** hip_stream);
+int xq_stream_destroy(void* hip_stream);
 /* Orders everything queued on waiting_stream from now on behind everything queued on producer_stream so far (one event record + one
  * wait; no host synchronisation) — for the device pointers the caller hands from one handle to another ("Stream ordering" above). */
 int xq_stream_wait_stream(void* waiting_stream, void* producer_stream);
@@ -347,6 +352,9 @@ int xq_dqn_td_update_host(xq_dqn* d, int n, const uint8_t* boards90, const uint8
                           double learning_rate, double grad_scale, float* q_sa_out, float* y_out);
 /* Sum-of-squared TD error of the last xq_dqn_td_grads (synchronises). */
 int xq_dqn_last_loss(xq_dqn* d, double* loss);
+/* Q(s,a) and the TD target y of the first n samples of the last xq_dqn_td_grads* (tests / interop; synchronises).  Either pointer
+ * may be NULL. */
+int xq_dqn_last_td_values(xq_dqn* d, int n, float* q_sa_host, float* y_host);
 /* Per-kernel HIP-event timing on the handle stream, for bench.py (name -> summed ms, launches, algorithmic flops/bytes).
  * enable: -1 leave, 0 off, 1 on, 2 on + clear, 3 on + clear but bracket only the TD step's dominant GEMM (gemm_qmax_rowmax /
  * gemm_qmax_screen) and env_selfplay_step, 4 = 3 with the GEMM bracketed on every 4th launch only (a pair of event records

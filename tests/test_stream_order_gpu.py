@@ -15,7 +15,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from test_dqn_gpu import CFG2_NET, make_net
+import xqoracle as xo
+from test_dqn_gpu import CFG2_NET
 
 pytestmark = pytest.mark.gpu
 
@@ -36,15 +37,25 @@ def dsync():
 
 
 class Rig:
-    """env + ring + Q-net, each on a stream of its own; the ring pre-filled with two random plies."""
+    """env + ring + Q-net, each on a stream of its own — of three different PRIORITIES, so that no two of them share a hardware queue
+    (streams of one priority are multiplexed onto a few queues, and two streams that happen to share one run in submission order:
+    the unordered legs would then pass by accident, depending on how many streams earlier tests of the process created)."""
 
-    def __init__(self, xq, per=False, cap=CAP, n=N, prefill=2, env_stream=None):
+    def __init__(self, xq, per=False, cap=CAP, n=N, prefill=2, env_nonblocking=False):
         self.xq = xq
-        self.env = xq.VecEnv(n, seed=3, stream=env_stream)
-        self.rp = xq.ReplayBuffer(cap, seed=11)
+        self.streams = []
+        for prio, nb in ((-1, 1 if env_nonblocking else 0), (1, 0), (0, 0)):
+            h = C.c_void_p()
+            xq._capi.call("xq_stream_create", prio, nb, C.byref(h))
+            self.streams.append(h)
+        self.env = xq.VecEnv(n, seed=3, stream=self.streams[0])
+        self.rp = xq.ReplayBuffer(cap, seed=11, stream=self.streams[1])
         if per:
             self.rp.enable_per(0.6, 0.4, 1e-3)
-        self.d, _, _ = make_net(xq, CFG2_NET, seed=2)
+        self.d = xq.DQN(CFG2_NET, 0.001, 0.99, seed=1, stream=self.streams[2])
+        w, b = xo.init_weights(CFG2_NET, 2)
+        self.d.set_params(w, b)
+        self.d.updateTargetNetwork()
         assert len({self.env.stream(), self.rp.stream(), self.d.stream()}) == 3
         for _ in range(prefill):
             self.env.selfplay_step_dev(0, 96, 0.1, replay=self.rp)
@@ -72,6 +83,8 @@ class Rig:
     def close(self):
         dsync()
         self.d.close(); self.rp.close(); self.env.close()
+        for h in self.streams:
+            self.xq._capi.call("xq_stream_destroy", h)
 
 
 def legs(xq, cls, body):
@@ -135,13 +148,10 @@ def test_td_step_then_env_step_overwrites_its_slots(xq):
 
 def test_env_step_then_replay_get(xq):
     """xq_env_selfplay_step(replay) -> xq_replay_get of a slot it wrote (host read on the ring's stream).  The env runs on a NON-BLOCKING
-    stream here (a torch side stream): a stream created with default flags is ordered against the null-stream copy of the host read by
+    stream here: a stream created with default flags is ordered against the null-stream copy of the host read by
     the runtime itself."""
-    import torch
-    side = torch.cuda.Stream()
-
     def body(sync):
-        r = Rig(xq, env_stream=C.c_void_p(side.cuda_stream))
+        r = Rig(xq, env_nonblocking=True)
         r.delay(r.env.stream())
         r.env.selfplay_step_dev(0, 96, 0.1, replay=r.rp)
         if sync:

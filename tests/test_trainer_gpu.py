@@ -370,3 +370,80 @@ def test_select_head_riding_on_the_last_hidden_product(xq, sizes, mode):        
     assert np.array_equal(boards, tboards) and np.array_equal(meta, tmeta)
     assert np.array_equal(w, tw) and np.array_equal(b, tb)
     t.close(); env.close(); d.close(); rp.close()
+
+
+def test_bench_composition_against_the_oracle_directly(xq):
+    """the 8192-wide loop EXACTLY as bench.py configures it — 1 M-slot ring filled to capacity, collect overlapped on its
+    own stream, exact screening of max_a' Q(s',a'), layer 0 of s' derived, TD target inside the refine blocks, fused tail launches, slab
+    sums inside the SGD kernel — checked against the fp64 oracle itself, not through another HIP path: Q(s,a) and y of 64 transitions
+    of the last minibatch, and the update of one output row + bias (every sample of that action, ~90 backward passes in fp64).
+    The minibatch is re-derived on the host from the trainer's documented Philox stream and sampling window."""
+    from cn_chess_ai_amd import _capi
+    from test_dqn_gpu import QTOL, PTOL
+    n, cap, lr, seed = 8192, 1 << 20, 0.001, 0x5EED
+    cfg = xq.TrainerConfig(n_games=n, layer_sizes=CFG2_NET, learning_rate=lr, gamma=0.99, epsilon=0.1, replay_capacity=cap, minibatch=n,
+                           td_net=_capi.TD_ONLINE_NET, backprop_mode=_capi.BACKPROP_REFERENCE, target_sync_interval=10, mean_gradient=1,
+                           seed=seed, first_game_id=0, overlap_collect=1, collects_per_update=1)
+    t = xq.Trainer(cfg)
+    t.dqn.set_qmax_mode(_capi.QMAX_SCREENED)
+    t.dqn.set_l0_derive(True)
+    t.dqn.set_fused_apply(True)
+    t.random_plies(300)
+    for _ in range(cap // n):
+        t.collect()                                   # ring filled to capacity, as bench.py does before it times anything
+    for _ in range(2):
+        t.learn_grads(); t.collect(); t.learn_apply(1)
+    w2, b2 = t.dqn.get_params()                        # theta before the third update
+    size, _, total = t.replay.stats()
+    assert size == cap
+    wpos = total % cap
+    t.learn_grads(); t.collect(); t.learn_apply(1)
+    w3, b3 = t.dqn.get_params()
+    st = t.dqn.qmax_stats()
+    assert st[0] == 3 and st[1] == 3 * n               # all three steps took the screened route
+    qsa, y = t.dqn.last_td_values(n)
+    # the third minibatch: sample call #2 of the ring's stream, drawn from the ring minus the n slots that iteration's collect writes
+    rseed = seed + 0x1234567
+    key = (rseed & 0xFFFFFFFF, rseed >> 32)
+    start, count = (wpos + n) % cap, cap - n
+    slots = [(start + xo.philox((i, 0, 2, 1), key)[0] % count) % cap for i in range(n)]
+    assert not any(wpos <= s < wpos + n for s in slots)
+    rng = np.random.default_rng(4)
+    pick = rng.choice(n, 64, replace=False)
+    trans = {}
+
+    def transition(i):
+        if i not in trans:
+            trans[i] = t.replay.get(slots[i])          # (board, action.to, reward, done, next board): reference-scale rewards
+        return trans[i]
+
+    worst_q = worst_y = 0.0
+    for i in pick:
+        s, a, r, dn, s2 = transition(int(i))
+        assert a >= 0
+        x, x2 = xo.state_repr(xo.board_from(s)), xo.state_repr(xo.board_from(s2))
+        tq = xo.td_target(CFG2_NET, w2, b2, x, x2, int(a), float(r), int(dn), 0.99)
+        q = xo.nn_forward(CFG2_NET, w2, b2, x)[int(a)]
+        worst_q = max(worst_q, abs(float(qsa[i]) - q))
+        # y = r + gamma max Q(s'): |r| is in the thousands (chessai.cpp:311-345), so the budget on y is relative to its size in fp32
+        worst_y = max(worst_y, abs(float(y[i]) - tq[int(a)]) / max(1.0, abs(tq[int(a)])))
+    assert worst_q < QTOL and worst_y < 1e-6, (worst_q, worst_y)
+    # one output row: every sample of the minibatch whose action.to is a* contributes delta * a_last to W_out[a*] and delta to b_out[a*]
+    acts = np.array([transition(i)[1] for i in range(n)])
+    counts = np.bincount(acts[acts >= 0], minlength=90)
+    a_star = int(np.argsort(counts)[45])               # an action of middling popularity (~90 samples)
+    gw, gb = np.zeros_like(w2), np.zeros_like(b2)
+    for i in np.nonzero(acts == a_star)[0]:
+        s, a, r, dn, s2 = transition(int(i))
+        x, x2 = xo.state_repr(xo.board_from(s)), xo.state_repr(xo.board_from(s2))
+        tq = xo.td_target(CFG2_NET, w2, b2, x, x2, int(a), float(r), int(dn), 0.99)
+        xo.nn_accum_grad(CFG2_NET, w2, b2, x, tq, 0, gw, gb)
+    wo = 1260 * 256 + 256 * 256                        # W_out starts here in the reference flat layout
+    row = slice(wo + a_star * 256, wo + (a_star + 1) * 256)
+    want_w = w2[row] - lr / n * gw[row]
+    want_b = b2[512 + a_star] - lr / n * gb[512 + a_star]
+    assert np.abs(gw[row]).max() > 0
+    assert np.abs(w3[row] - want_w).max() < PTOL and abs(b3[512 + a_star] - want_b) < PTOL
+    # ... and the step was not a no-op on that row
+    assert np.abs(w3[row] - w2[row]).max() > 0
+    t.close()
