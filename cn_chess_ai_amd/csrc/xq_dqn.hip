@@ -2066,11 +2066,33 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
                 XQ_HIP(hipGetLastError());
                 continue;
             }
+            bool aligned = true;
             for (int k = 0; k < njobs; ++k) {
                 uint16_t* cb = (l == d->nl - 2) ? jobs[k].last_bf : nullptr;
                 if (cb && jobs[k].last_bf_frag) g.cb_frag = 1;
                 if (k == 0) { g.A = jobs[k].outs[l - 1]; g.B = d->wl(jobs[k].net, l); g.C = jobs[k].outs[l]; g.bias = d->bl(jobs[k].net, l); g.Cb = cb; }
                 else { g.Ax[k - 1] = jobs[k].outs[l - 1]; g.Bx[k - 1] = d->wl(jobs[k].net, l); g.Cx[k - 1] = jobs[k].outs[l]; g.biasx[k - 1] = d->bl(jobs[k].net, l); g.Cbx[k - 1] = cb; }
+                aligned = aligned && vec_ok(jobs[k].outs[l - 1], g.lda) && vec_ok(d->wl(jobs[k].net, l), g.ldb);
+            }
+            // whole 128-row x 128-column tiles on the handle's stream: the persistent walk (gemm_fwd_persistent_kernel; same bits as the
+            // tile kernel).  8192 x 512 x 512 x 2 chains: 90 -> 76 us (128 x 128 tiles, 2 blocks per CU walk 512 tiles); 8192 x 256 x
+            // 256 x 2: 27.5 -> 26.3 us (64 x 128 tiles) — tools/f32_fwd_probe.hip.  The select chain keeps the 64 x 64 tile kernel.
+            if (aligned && !d->small_tiles && !d->tail_open && (n % 128) == 0 && (g.N % 128) == 0 && (g.K % GBK) == 0) {
+                const int groups = njobs;
+                const int t128 = (n / 128) * (g.N / 128) * groups;
+                g.k_chunk = g.K; g.a_vec = g.b_vec = 1;
+                ProfScope ps(d, "gemm_hidden_fwd", 2.0 * n * (double)g.N * g.K * groups,
+                             4.0 * groups * ((double)n * g.K + (double)g.N * g.K + (double)n * g.N));
+                if (t128 >= 512) {
+                    hipLaunchKernelGGL((gemm_fwd_persistent_kernel<2, 2, 2>), dim3(std::min(t128, 2 * d->ncu)), dim3(256), 0, d->cur, g, n / 128,
+                                       g.N / 128, t128);
+                } else {
+                    const int total = (n / 64) * (g.N / 128) * groups;
+                    hipLaunchKernelGGL((gemm_fwd_persistent_kernel<1, 2, 2>), dim3(std::min(total, 2 * d->ncu)), dim3(256), 0, d->cur, g, n / 64,
+                                       g.N / 128, total);
+                }
+                XQ_HIP(hipGetLastError());
+                continue;
             }
             XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH>(d, g, 1, "gemm_hidden_fwd")));
         }
@@ -2096,6 +2118,7 @@ static int q_head(xq_dqn* d, int net, const float* a_last, int n, int n_out, flo
     g.A = a_last; g.lda = d->hlast();
     g.B = d->wl(net, d->nl - 1); g.ldb = d->hlast();
     g.bias = d->bl(net, d->nl - 1);
+    g.libm_tanh = 1;                     // the output layer's tanh stays libm's (as in q_head_finish_kernel / the env kernel / the TD kernels)
     // The select head (selectAction reads q[action.to] only, dqn.cpp:47): 8192 x 96 x K is two column tiles of 64 — 256 blocks, one per
     // CU, each walking all K / 32 k-tiles behind one another with nothing to hide the load latency behind (20 us at K = 256, 32 us at
     // K = 512 for 0.4 / 0.8 GFLOP).  Four k-slabs per tile put four blocks on every CU; a one-thread-per-output kernel adds the slabs in a

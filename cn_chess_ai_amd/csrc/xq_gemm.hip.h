@@ -38,6 +38,27 @@ __device__ __forceinline__ float bf16_to_float(uint16_t b) { return __builtin_bi
 // exp and reciprocal — absolute error ~1e-7, far below half a bf16 ulp except for |x| < 1e-4 where it cannot matter; tanhf costs
 // ~40 instructions per value, which the bf16 MFMA no longer hides (the fp32 epilogues keep tanhf)
 __device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+// tanh of the fp32 hidden layers (forward epilogues of the hidden products; NeuralNetwork::forward, dqn.cu:184-195, calls libm's tanh
+// in fp64).  libm's tanhf is ~40 VALU instructions per value and was 10-15 % of an 8192 x 512 x 512 product (tools/f32_fwd_probe.hip);
+// this is 1 - 2 / (e^{2|x|} + 1) on the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32), with the odd Taylor polynomial below
+// |x| = 0.05 where that form cancels: absolute error <= 3e-7, relative <= 6e-6 over the whole range (tests/test_dqn_gpu.py::
+// test_hidden_tanh_accuracy measures it through the GEMM) — two orders inside the 1e-4 the Q-values are held to.
+// XQ_FAST_TANH=0 restores tanhf (A/B builds).
+#ifndef XQ_FAST_TANH
+#define XQ_FAST_TANH 1
+#endif
+__device__ __forceinline__ float tanh_hidden(float x) {
+#if XQ_FAST_TANH
+    const float ax = fabsf(x);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);          // e^{2|x|}; overflows to +inf => r = 1
+    const float r = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    const float x2 = ax * ax;
+    const float p = ax * __builtin_fmaf(x2, __builtin_fmaf(x2, 0.13333334f, -0.33333334f), 1.f);
+    return __builtin_copysignf(ax < 0.05f ? p : r, x);
+#else
+    return tanhf(x);
+#endif
+}
 
 // element index (in bf16 units) of activation (sample, k) in B-fragment order: 32-sample group, k-step of 16, lane half, then the
 // 32 samples x 8 consecutive k of one MFMA operand wave-instruction (1 KB).  The screening pass (xq_screen.hip.h) loads its
@@ -85,6 +106,7 @@ struct GemmArgs {
     int prio_tiles;               // ... and own tiles [0, prio_tiles); the other blocks own [prio_tiles, total)
     // EPI_HEAD: first 128 rows of the output layer's weights (row stride head_ldw = N), the slabs [N / 64][M][head_ld]
     const float* head_W; long long head_ldw; float* head_slabs; long long head_slab_stride; int head_ld;
+    int libm_tanh;                // EPI_BIAS_TANH: libm's tanhf instead of tanh_hidden — the OUTPUT layer (the audited Q-values) keeps it
 };
 
 // ---- global -> register staging (4 x float4 per thread per operand) --------------------------------------------
@@ -380,7 +402,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g_in, int bx, int
         float v[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            v[q] = tanhf(acc[0][0][q] + bias);
+            v[q] = tanh_hidden(acc[0][0][q] + bias);
             if (g.C) g.C[(long long)(mb + (q & 3) + 8 * (q >> 2)) * g.ldc + n] = v[q];
         }
         f32x16 hacc[1][2];
@@ -488,7 +510,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g_in, int bx, int
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     float v = acc[i][j][q];
-                    if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
+                    if (EPI == EPI_BIAS_TANH) v = g.libm_tanh ? tanhf(v + bias) : tanh_hidden(v + bias);
                     if (EPI == EPI_DELTA) v = v * (1.f - hv[q] * hv[q]);
                     Cz[(long long)(mb + (q & 3) + 8 * (q >> 2)) * g.ldc + n] = v;
                     // fp32 net: a bf16 COPY of the exact activation beside it (operand of the screening pass)
@@ -513,7 +535,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g_in, int bx, int
                 const int m = m0 + wm * 32 * TM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                 if (m >= g.M) continue;
                 float v = acc[i][j][q];
-                if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias);
+                if (EPI == EPI_BIAS_TANH) v = g.libm_tanh ? tanhf(v + bias) : tanh_hidden(v + bias);
                 if (EPI == EPI_DELTA) {
                     const float a = g.H[(long long)m * g.ldh + n];
                     v = v * (1.f - a * a);
@@ -693,6 +715,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         if (tnext >= tend) break;
         t = tnext; tm = t % tiles_m; tn = t / tiles_m;
+    }
+}
+
+// Persistent forward product of the hidden layers: C_c = tanh(A_c W_c^T + b_c) for the 1..3 grouped chains of a launch (both operands
+// k-contiguous, whole (64 TM) x (64 TN) tiles, K % 32 == 0, 16-byte aligned).  gemm_f32_kernel gives every tile a block of its own:
+// with K = 256..512 a block is 8-16 k-steps long, and its prologue (first operand tile: one HBM / L2 round trip with nothing to
+// overlap), its epilogue and the launch's block rounds are paid per tile (PMC: matrix pipe 39 % busy at 8192 x 256 x 256 x 2).  Here
+// WPE blocks per SIMD walk the tile list — t, t + grid, ...; consecutive tiles share the row panel of A — with the register prefetch
+// running ACROSS tile boundaries, as gemm_colmax_persistent_kernel does: the next tile's first k-tile is in flight under the last
+// MFMAs and the epilogue of the current one.  Epilogue as EPI_BIAS_TANH of gemm_f32_block (same expression, same bits), incl. the
+// optional bf16 copy in row-major or MFMA B-fragment order (operand of the screening pass).
+template <int TM, int TN, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void gemm_fwd_persistent_kernel(const GemmArgs g, int tiles_m,
+                                                                                                            int tiles_n, int total) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    __shared__ __attribute__((aligned(16))) float As[g_tile_floats(BM)];
+    __shared__ __attribute__((aligned(16))) float Bs[g_tile_floats(BN)];
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int per_group = tiles_m * tiles_n;
+    int t = (int)blockIdx.x;
+    if (t >= total) return;
+    const int stride = (int)gridDim.x;
+    struct Tile { const float* A; const float* B; float* C; const float* bias; uint16_t* Cb; int m0, n0; };
+    auto decode = [&](int tt) {
+        const int grp = tt / per_group, rem = tt - grp * per_group;
+        Tile x;
+        x.A = grp == 0 ? g.A : g.Ax[grp - 1]; x.B = grp == 0 ? g.B : g.Bx[grp - 1]; x.C = grp == 0 ? g.C : g.Cx[grp - 1];
+        x.bias = grp == 0 ? g.bias : g.biasx[grp - 1]; x.Cb = grp == 0 ? g.Cb : g.Cbx[grp - 1];
+        x.m0 = (rem / tiles_n) * BM; x.n0 = (rem % tiles_n) * BN;
+        return x;
+    };
+    Tile cur = decode(t);
+    float4 va[BM / 32], vb[BN / 32];
+    stage_load<L_KCONTIG, BM, true>(g, cur.A, g.lda, 1, cur.m0, g.M, 0, g.K, va);
+    stage_load<L_KCONTIG, BN, true>(g, cur.B, g.ldb, 1, cur.n0, g.N, 0, g.K, vb);
+    for (;;) {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        const int tnext = t + stride;
+        Tile nxt = cur;
+        if (tnext < total) nxt = decode(tnext);
+        for (int k0 = 0; k0 < g.K; k0 += GBK) {
+            __syncthreads();
+            stage_store<L_KCONTIG, BM>(As, va);
+            stage_store<L_KCONTIG, BN>(Bs, vb);
+            __syncthreads();
+            if (k0 + GBK < g.K) {
+                stage_load<L_KCONTIG, BM, true>(g, cur.A, g.lda, 1, cur.m0, g.M, k0 + GBK, g.K, va);
+                stage_load<L_KCONTIG, BN, true>(g, cur.B, g.ldb, 1, cur.n0, g.N, k0 + GBK, g.K, vb);
+            } else if (tnext < total) {          // first k-tile of the NEXT output tile
+                stage_load<L_KCONTIG, BM, true>(g, nxt.A, g.lda, 1, nxt.m0, g.M, 0, g.K, va);
+                stage_load<L_KCONTIG, BN, true>(g, nxt.B, g.ldb, 1, nxt.n0, g.N, 0, g.K, vb);
+            }
+            tile_mma<L_KCONTIG, L_KCONTIG, BM, BN, TM, TN, DT_F32>(As, Bs, wm, wn, r, h, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = cur.n0 + wn * 32 * TN + j * 32 + r;
+                const int mb = cur.m0 + wm * 32 * TM + i * 32 + 4 * h;
+                const float bias = cur.bias[n];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = mb + (q & 3) + 8 * (q >> 2);
+                    const float v = tanh_hidden(acc[i][j][q] + bias);
+                    if (cur.C) cur.C[(long long)row * g.ldc + n] = v;
+                    if (cur.Cb) cur.Cb[g.cb_frag ? scr_afrag_index(row, n, g.N) : (long long)row * g.ldcb + n] = bf16_bits(v);
+                }
+            }
+        if (tnext >= total) break;
+        t = tnext; cur = nxt;
     }
 }
 

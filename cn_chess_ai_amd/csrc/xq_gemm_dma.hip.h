@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const Bf16GemmArgs g_in) 
                     stage[row * SW + 32 * j + r5] = __builtin_bit_cast(uint16_t, rb);
                     if (g.C) g.C[(long long)(mw + row) * g.ldc + n] = (float)rb;
                 } else if (EPI == BG_TANH) {                     // fp32 net: the exact activation, and (optionally) a bf16 COPY beside it
-                    v = tanhf(v + bias);
+                    v = tanh_hidden(v + bias);           // (as the fp32 tile kernel's hidden epilogue: same bits)
                     g.C[(long long)(mw + row) * g.ldc + n] = v;
                     if (g.Cb) stage[row * SW + 32 * j + r5] = bf16_bits(v);
                 } else {

@@ -6,6 +6,8 @@
 #include <cstring>
 #include <vector>
 #include <random>
+#include <algorithm>
+#include <cmath>
 #include "../cn_chess_ai_amd/csrc/xq_gemm.hip.h"
 using namespace xq;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -17,6 +19,22 @@ template <int TM, int TN, int EPI = EPI_BIAS_TANH> static void run(const char* n
     hipEventRecord(e0, 0); for (int i = 0; i < 20; ++i) fn(); hipEventRecord(e1, 0); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
     const double flop = 2.0 * g.M * g.N * g.K * (g.grouped ? g.grouped : 1);
     printf("  %-40s grid %4d x %d x %d: %7.2f us  %6.1f TFLOP/s = %.3f of 157.3\n", name, grid.x, grid.y, grid.z, ms * 50, flop / (ms / 20 * 1e-3) / 1e12, flop / (ms / 20 * 1e-3) / 157.3e12);
+}
+template <int TM, int TN, int WPE> static void run_persistent(const char* name, GemmArgs g, hipEvent_t e0, hipEvent_t e1) {
+    const int tiles_m = g.M / (64 * TM), tiles_n = g.N / (64 * TN), total = tiles_m * tiles_n * (g.grouped ? g.grouped : 1);
+    const int grid = std::min(total, 256 * WPE);
+    auto fn = [&] { hipLaunchKernelGGL((gemm_fwd_persistent_kernel<TM, TN, WPE>), dim3(grid), dim3(256), 0, 0, g, tiles_m, tiles_n, total); };
+    fn(); fn();
+    float ms = 0;
+    hipEventRecord(e0, 0); for (int i = 0; i < 20; ++i) fn(); hipEventRecord(e1, 0); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 2.0 * g.M * g.N * g.K * (g.grouped ? g.grouped : 1);
+    printf("  %-40s grid %4d (%d tiles)   : %7.2f us  %6.1f TFLOP/s = %.3f of 157.3\n", name, grid, total, ms * 50, flop / (ms / 20 * 1e-3) / 1e12, flop / (ms / 20 * 1e-3) / 157.3e12);
+}
+static double max_diff(const float* dX, const float* dY, size_t n) {
+    std::vector<float> x(n), y(n);
+    CK(hipMemcpy(x.data(), dX, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(y.data(), dY, n * 4, hipMemcpyDeviceToHost));
+    double m = 0; for (size_t i = 0; i < n; ++i) m = std::max(m, (double)fabsf(x[i] - y[i]));
+    return m;
 }
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 8192, H = argc > 2 ? atoi(argv[2]) : 512;
@@ -41,5 +59,24 @@ int main(int argc, char** argv) {
     run<1, 1>("two chains grouped, 64 x 64", g, e0, e1);
     run<2, 1>("two chains grouped, 128 x 64", g, e0, e1);
     run<2, 2>("two chains grouped, 128 x 128", g, e0, e1);
+    printf("persistent walk (XQ_FAST_TANH=%d):\n", (int)XQ_FAST_TANH);
+    run_persistent<1, 1, 2>("grouped persistent 64 x 64, 2 blocks/CU", g, e0, e1);
+    run_persistent<2, 1, 2>("grouped persistent 128 x 64, 2 blocks/CU", g, e0, e1);
+    run_persistent<1, 2, 2>("grouped persistent 64 x 128, 2 blocks/CU", g, e0, e1);
+    run_persistent<2, 2, 1>("grouped persistent 128 x 128, 1 block/CU", g, e0, e1);
+    run_persistent<2, 2, 2>("grouped persistent 128 x 128, 2 blocks/CU", g, e0, e1);
+    {   // same bits as the tile kernel
+        float* dC2; CK(hipMalloc(&dC2, a.size() * 4 * 2));
+        GemmArgs g2 = g; g2.C = dC2; g2.Cx[0] = dC2 + a.size();
+        CK(hipMemset(dC2, 0, a.size() * 8));
+        hipLaunchKernelGGL((gemm_f32_kernel<L_KCONTIG, L_KCONTIG, EPI_BIAS_TANH, 1, 1>), dim3(g.M / 64, g.N / 64, 2), dim3(256), 0, 0, g);
+        const int tm = g.M / 128, tn = g.N / 64;
+        hipLaunchKernelGGL((gemm_fwd_persistent_kernel<2, 1, 2>), dim3(std::min(tm * tn * 2, 512)), dim3(256), 0, 0, g2, tm, tn, tm * tn * 2);
+        CK(hipDeviceSynchronize());
+        printf("  persistent 128 x 64 against the 64 x 64 tile kernel: max |diff| %.3g (both chains)\n", max_diff(dC, dC2, a.size() * 2));
+    }
+    g.grouped = 0;
+    run_persistent<1, 1, 2>("one chain persistent 64 x 64", g, e0, e1);
+    run_persistent<2, 1, 2>("one chain persistent 128 x 64", g, e0, e1);
     return 0;
 }

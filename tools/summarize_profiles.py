@@ -55,8 +55,9 @@ def main(tag, dst=None):
     fetch = counter_means(os.path.join(src, "fetch", "**", "*_counter_collection.csv"))
     write = counter_means(os.path.join(src, "write", "**", "*_counter_collection.csv"))
     sq = counter_means(os.path.join(src, "sq", "**", "*_counter_collection.csv"))
-    for k, v in counter_means(os.path.join(src, "sq2", "**", "*_counter_collection.csv")).items():
-        sq.setdefault(k, {}).update(v)
+    for extra in ("sq2", "sq3"):
+        for k, v in counter_means(os.path.join(src, extra, "**", "*_counter_collection.csv")).items():
+            sq.setdefault(k, {}).update(v)
     out = {}
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, {}).get("FETCH_SIZE", 0.0)
