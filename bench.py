@@ -399,6 +399,8 @@ def main():
                          "the all-reduce when there is more than one rank)")
     ap.add_argument("--no-td-tail", action="store_true",
                     help="A/B: the gradient kernels of the TD step one by one on two streams instead of the fused launches (xq_dqn_set_td_tail)")
+    ap.add_argument("--l0-grad", choices=("mfma", "segmented"), default="segmented",
+                    help="A/B: layer-0 weight gradient as segmented sums (library default) or on the bf16 matrix pipe (exact 3-term split)")
     ap.add_argument("--no-variants", action="store_true", help="skip the variant legs (other TD net, full fp32 product): A/B runs")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps, barrier + synchronize on both sides) is run this many times back to "
@@ -473,6 +475,7 @@ def main():
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
     t.dqn.set_qmax_mode(_capi.QMAX_SCREENED if args.qmax == "screened" else _capi.QMAX_FULL)
     t.dqn.set_l0_derive(not args.no_derive)       # layer-0 sums of s' from those of s (library default: off, the reference's order)
+    if args.l0_grad == "mfma": t.dqn.set_l0_grad_mode(1)
     if args.no_td_tail: t.dqn.set_td_tail(False)  # A/B: the gradient kernels one by one on two streams (library default: fused launches)
     if args.exchange_overlap >= 0: t.dqn.set_exchange_overlap(args.exchange_overlap)
     grads, comm, comm_error = None, None, ""

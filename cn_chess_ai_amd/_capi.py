@@ -126,6 +126,7 @@ PROTOTYPES = {
     "xq_dqn_set_qmax_mode": [_vp, _i],
     "xq_dqn_set_l0_derive": [_vp, _i],
     "xq_dqn_set_td_tail": [_vp, _i],
+    "xq_dqn_set_l0_grad_mode": [_vp, _i],
     "xq_dqn_set_exchange_overlap": [_vp, _i],
     "xq_dqn_qmax_stats": [_vp, C.POINTER(C.c_uint64)],
     "xq_dqn_qmax_guard": [_vp, _pu64, _pi],

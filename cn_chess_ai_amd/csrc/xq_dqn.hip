@@ -18,6 +18,7 @@
 #include "xq_gemm.hip.h"
 #include "xq_screen.hip.h"
 #include "xq_gemm_dma.hip.h"
+#include "xq_l0grad.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -124,6 +125,9 @@ struct xq_dqn {
     float* grads_full = nullptr;
     float* slabs = nullptr;  size_t slabs_cap = 0;
     float* slabs_l0 = nullptr;  size_t slabs_l0_cap = 0;     // layer-0 gradient partials
+    // layer-0 gradient on the bf16 matrix pipe (xq_l0grad.hip.h): delta_0 as three bf16 planes, transposed [plane][column][sample]
+    uint16_t* l0_planes = nullptr;  size_t l0_planes_cap = 0;
+    bool l0_mfma = false;                       // xq_dqn_set_l0_grad_mode (opt-in: faster alone, not inside the fused launch — DESIGN.md section 5)
     xq_comm* comm = nullptr;                    // xq_dqn_set_comm: bucketed RCCL all-reduce of the gradient buffer inside td_grads
     bool fused_apply = false;                   // xq_dqn_set_fused_apply: apply_grads may sum the layer-0 partials itself
     int l0_pending = 0;                         // > 0: that many layer-0 slabs wait in slabs_l0, not yet reduced into grads_td
@@ -1207,6 +1211,7 @@ struct TailArgs {
     GemmArgs delta; int delta_gx;                  // grid (gx, gy, 1)
     const int32_t* og_act; const float* og_dsc; const float* og_alast; int og_n, og_H, og_chunk; float* og_partial;   // grid (24, chunks)
     const uint32_t* l0_boards; const float* l0_delta; int l0_n, l0_H, l0_HS, l0_chunk, l0_nsets, l0_nch; float* l0_partial;   // (90, nch, H / HS)
+    const uint16_t* l0_planes; long long l0_plane_stride; int l0_kpad, l0_ncb;      // != nullptr: the matrix-pipe form, grid (4, H / 32, nch)
     ColsumJobs cj; int cj_gx, cj_gy;               // grid (gx, R, njobs)
 };
 template <unsigned KINDS>
@@ -1215,6 +1220,12 @@ __global__ __launch_bounds__(256) void td_tail_kernel(const TailArgs a) {
     int b = (int)blockIdx.x;
     if (KINDS & TAIL_L0) {
         if (b < a.n_l0) {
+            if (a.l0_planes != nullptr) {
+                const int rest = b >> 2;
+                l0_grad_mfma_block<0>(a.l0_boards, a.l0_planes, a.l0_plane_stride, a.l0_kpad, a.l0_n, a.l0_H, a.l0_chunk, a.l0_partial, b & 3,
+                                      rest % a.l0_ncb, rest / a.l0_ncb, reinterpret_cast<uint32_t*>(tail_smem));
+                return;
+            }
             const int per = kSquares * a.l0_nch;
             l0_grad_block(a.l0_boards, a.l0_delta, a.l0_n, a.l0_H, a.l0_HS, a.l0_chunk, a.l0_nsets, a.l0_partial, b % per, a.l0_nch, b / per, tail_smem);
             return;
@@ -2445,7 +2456,42 @@ static int l0_gradient(xq_dqn* d, int n, float* dst) {
         }
         out = d->slabs_l0;
     }
-    {
+    if (d->l0_mfma && (H % 64) == 0 && n >= 256) {
+        // the matrix-pipe form (xq_l0grad.hip.h): delta_0 -> three transposed bf16 planes (one launch, 6 us at 8192 x 256), then
+        // one-hot^T x planes on v_mfma_f32_16x16x32_bf16 — exact products, fp32 accumulation
+        const int kpad = nchunks * chunk;
+        const size_t need = l0m_plane_elems(H, kpad);
+        if (need > d->l0_planes_cap) {
+            if (d->l0_planes) { XQ_HIP(hipDeviceSynchronize()); XQ_HIP(hipFree(d->l0_planes)); }
+            XQ_HIP(hipMalloc(&d->l0_planes, need * sizeof(uint16_t)));
+            XQ_HIP(hipMemsetAsync(d->l0_planes, 0, need * sizeof(uint16_t), d->cur));      // (the slack behind the planes is read, never used)
+            d->l0_planes_cap = need;
+        }
+        const long long plane_stride = (long long)H * kpad;
+        const bool was_open = d->tail_open;
+        d->tail_open = false;                        // the split is a launch of its own, in front of the fused launch that is being assembled
+        {
+            ProfScope ps(d, "l0_delta_split", 8.0 * n * H, (double)n * H * 4 + 6.0 * H * kpad);
+            hipLaunchKernelGGL(delta_split_kernel, dim3(kpad / 64, H / 64), dim3(256), 0, d->cur, d->deltas[0], n, H, d->l0_planes, plane_stride, kpad);
+        }
+        d->tail_open = was_open;
+        XQ_HIP(hipGetLastError());
+        const size_t shmem = l0m_lds_bytes(chunk);
+        const double fl = 2.0 * 96 * 16 * (double)H * kpad * 3, by = 6.0 * H * kpad * 4 + 48.0 * n * (H / 32) + 4.0 * nchunks * len;
+        if (d->tail_open) {
+            TailArgs& T = *d->tail;
+            T.l0_boards = d->gboards; T.l0_n = n; T.l0_H = H; T.l0_chunk = chunk; T.l0_nch = nchunks; T.l0_partial = out;
+            T.l0_planes = d->l0_planes; T.l0_plane_stride = plane_stride; T.l0_kpad = kpad; T.l0_ncb = H / kL0mCols;
+            T.n_l0 = 4 * (H / kL0mCols) * nchunks;
+            d->tail_flops += fl; d->tail_bytes += by;
+            d->tail_lds = std::max(d->tail_lds, shmem);
+        } else {
+            ProfScope ps(d, "l0_grad_segsum", fl, by);
+            hipLaunchKernelGGL(l0_grad_mfma_kernel<0>, dim3(4, H / kL0mCols, nchunks), dim3(256), shmem, d->cur, d->gboards, d->l0_planes, plane_stride,
+                               kpad, n, H, chunk, out);
+            XQ_HIP(hipGetLastError());
+        }
+    } else {
         ProfScope ps(d, "l0_grad_segsum", 2.0 * n * 32 * H, (double)n * (32.0 * H * 4 + 48) + 4.0 * nchunks * len);
         const int HS = (H > 256 && H % 256 == 0) ? 256 : H;     // column slab per block (grid z): wide layers keep the H = 256 shape
         int nsets = 4;                               // one accumulator set per wave while they fit in 60 KB of LDS
@@ -2581,7 +2627,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     hipFree(d->grads_td); hipFree(d->grads_full); hipFree(d->slabs); hipFree(d->bias_work); hipFree(d->xdense); hipFree(d->qfull); hipFree(d->tfull);
     hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
     d->prof.collect();
-    hipFree(d->slabs_l0);
+    hipFree(d->slabs_l0); hipFree(d->l0_planes);
     for (int i = 0; i < 2; ++i) { hipFree(d->params_bf[i]); hipFree(d->tacts_bf[i]); hipFree(d->t2acts_bf[i]); hipFree(d->t2acts[i]); }
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts_bf[l]); hipFree(d->sel_acts_bf[l]); }
     hipFree(d->partial_idx);
@@ -2671,6 +2717,12 @@ int xq_dqn_set_l0_derive(xq_dqn* d, int on) {
     if (d) d->sel_invalidate();
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
     d->l0_derive = on != 0;
+    return XQ_OK;
+}
+
+int xq_dqn_set_l0_grad_mode(xq_dqn* d, int mode) {
+    if (!d || (mode != 0 && mode != 1)) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_set_l0_grad_mode: 0 (segmented sums) or 1 (matrix pipe)");
+    d->l0_mfma = mode == 1;
     return XQ_OK;
 }
 

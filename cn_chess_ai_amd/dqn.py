@@ -222,6 +222,14 @@ def _set_td_tail(self, on):
 DQN.set_td_tail = _set_td_tail
 
 
+def _set_l0_grad_mode(self, mode):
+    """Layer-0 weight gradient: 1 = exact dense product on the bf16 matrix pipe (default where the shape allows), 0 = segmented sums."""
+    call("xq_dqn_set_l0_grad_mode", self._h, int(mode))
+
+
+DQN.set_l0_grad_mode = _set_l0_grad_mode
+
+
 def _set_exchange_overlap(self, mode):
     """Data-parallel step: -1 auto, 0 select chain beside the gradient kernels, 1 beside the all-reduce (hides the exchange)."""
     call("xq_dqn_set_exchange_overlap", self._h, int(mode))

@@ -283,6 +283,13 @@ int xq_dqn_set_l0_derive(xq_dqn* d, int on);
  * hidden layer is 256 wide (uniform replay), the TD target / output delta / top hidden delta are computed inside the blocks of the
  * kernel that re-evaluates the screened maxima instead of by a launch of their own.  Results are bitwise identical either way. */
 int xq_dqn_set_td_tail(xq_dqn* d, int on);
+/* How the layer-0 weight gradient of a TD step (updateWeightsBiasesKernel on layer 0, dqn.cu:310-319, fed by the one-hot of
+ * chessai.cpp:268-289) is computed.  0 (default): per-(square, piece) segmented sums of delta rows on the vector ALU.  1 (first hidden
+ * width a multiple of 64, >= 256 samples; other shapes keep 0): the dense product one-hot^T x delta_0 on the bf16 matrix pipe, exact —
+ * the one-hot operand is 0 / 1 and delta_0 is split into three bf16 values per fp32 (hi + mid + lo, every residual exact), products
+ * exact, fp32 accumulation.  Same value up to the summation order (both within a few fp32 ulp of the fp64 oracle).  Measured: 1 is the
+ * faster kernel alone (31 against 40 us at 8192 x 256) and the slower step inside the fused launches, hence opt-in. */
+int xq_dqn_set_l0_grad_mode(xq_dqn* d, int mode);
 /* XQ_QMAX_*: how the TD step finds max_a' Q(s',a').  XQ_QMAX_SCREENED applies to fp32 nets with XQ_TD_ONLINE_NET / XQ_TD_TARGET_NET
  * whose last hidden width is a multiple of 64 and whose product is large enough for the persistent GEMM (>= 512 tiles of 128 x 128);
  * every other case silently keeps the full fp32 product.  Guard: every 32 screened steps the candidate counters are read back

@@ -810,3 +810,30 @@ def test_hidden_tanh_accuracy(xq):
     assert rel.max() < 1e-5, rel.max()
     assert np.all(np.sign(q) == np.sign(x))
     d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes,n", [(CFG2_NET, 1100), ([1260, 64, 8100], 300)])
+def test_layer0_gradient_on_the_matrix_pipe_matches_the_segmented_sums(xq, trace, sizes, n):
+    """xq_dqn_set_l0_grad_mode(1): gW0 = one-hot^T x delta_0 as a bf16 MFMA product with delta_0 split exactly into three bf16 values
+    (xq_l0grad.hip.h).  Same TD step, both modes: every parameter outside layer 0 bit-identical, layer 0 equal up to the summation
+    order (<= 1e-6 of the largest update), and the matrix-pipe update itself within PTOL of the fp64 oracle."""
+    S, A, R, D, S2 = transitions(trace, valid_indices(trace, n, seed=6))
+    R = R / 1000.0
+    lr, scale = 0.05, 1.0 / n
+    outs = []
+    for mode in (0, 1):
+        d, w, b = make_net(xq, sizes, seed=9)
+        d.set_l0_grad_mode(mode)
+        d.td_update(S, S2, A, R, D, td_net=0, mode=0, learning_rate=lr, grad_scale=scale)
+        outs.append(d.get_params())
+        d.close()
+    (w0, b0), (w1, b1) = outs
+    n0 = sizes[0] * sizes[1]
+    assert np.array_equal(w0[n0:], w1[n0:]) and np.array_equal(b0, b1)
+    upd = np.abs(w0[:n0] - w[:n0]).max()
+    assert upd > 0 and np.abs(w0[:n0] - w1[:n0]).max() <= 1e-6 * max(upd, 1e-3)
+    if n <= 300:
+        wt, bt = xo.init_weights(sizes, 77)
+        want_w, want_b, _, _ = oracle_td_update(sizes, w, b, w, b, S, A, R, D, S2, 0.99, lr, scale, 0)
+        assert np.abs(w1 - want_w).max() < PTOL and np.abs(b1 - want_b).max() < PTOL
