@@ -817,7 +817,7 @@ def test_hidden_tanh_accuracy(xq):
 def test_layer0_gradient_on_the_matrix_pipe_matches_the_segmented_sums(xq, trace, sizes, n):
     """xq_dqn_set_l0_grad_mode(1): gW0 = one-hot^T x delta_0 as a bf16 MFMA product with delta_0 split exactly into three bf16 values
     (xq_l0grad.hip.h).  Same TD step, both modes: every parameter outside layer 0 bit-identical, layer 0 equal up to the summation
-    order (<= 1e-6 of the largest update), and the matrix-pipe update itself within PTOL of the fp64 oracle."""
+    order (<= two fp32 ulps of the stored weight), and the matrix-pipe update itself within PTOL of the fp64 oracle."""
     S, A, R, D, S2 = transitions(trace, valid_indices(trace, n, seed=6))
     R = R / 1000.0
     lr, scale = 0.05, 1.0 / n
@@ -832,8 +832,8 @@ def test_layer0_gradient_on_the_matrix_pipe_matches_the_segmented_sums(xq, trace
     n0 = sizes[0] * sizes[1]
     assert np.array_equal(w0[n0:], w1[n0:]) and np.array_equal(b0, b1)
     upd = np.abs(w0[:n0] - w[:n0]).max()
-    assert upd > 0 and np.abs(w0[:n0] - w1[:n0]).max() <= 1e-6 * max(upd, 1e-3)
+    # the parameters are stored in fp32: |w| <= 0.06 => one ulp is 3.7e-9; the two summation orders may round the stored value apart by it
+    assert upd > 0 and np.abs(w0[:n0] - w1[:n0]).max() <= 8e-9 and not np.array_equal(w0[:n0], w[:n0])
     if n <= 300:
-        wt, bt = xo.init_weights(sizes, 77)
         want_w, want_b, _, _ = oracle_td_update(sizes, w, b, w, b, S, A, R, D, S2, 0.99, lr, scale, 0)
         assert np.abs(w1 - want_w).max() < PTOL and np.abs(b1 - want_b).max() < PTOL
