@@ -68,9 +68,32 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
 
     uint32_t word = 0;
     uint4 m = make_uint4(0, 0, 0, 0);
+    // The Q-values the select will need are requested NOW, beside the board and meta loads, whether or not this board will explore
+    // (one board in ten does, and wastes them): behind move generation they were one exposed memory round trip per wave — 45 % of the
+    // wave cycles of the Q-policy launch were waits (profiles/r04_a_pmc_hbm_traffic.json).  Up to 8 k-slabs of the select head
+    // (last hidden width <= 512), two outputs per lane (lane, 64 + lane < 90).
+    float qpre[2][8];
+    float qbias[2] = {0.f, 0.f};
+    const bool q_from_slabs = MODE == MODE_SELFPLAY && P.q_slabs != nullptr && P.q_nslabs <= 8;
     if (active) {
         if (lane < kBoardWords) word = P.boards[(size_t)g * kBoardWords + lane];
         m = P.meta[g];
+        if (q_from_slabs) {
+            const float* p0 = P.q_slabs + (size_t)g * 96 + lane;
+            const float* p1 = P.q_slabs + (size_t)g * 96 + 64 + (lane < 26 ? lane : 0);
+#pragma unroll
+            for (int z = 0; z < 8; ++z) {
+                const bool in = z < P.q_nslabs;
+                qpre[0][z] = in ? p0[z * P.q_slab_stride] : 0.f;
+                qpre[1][z] = in ? p1[z * P.q_slab_stride] : 0.f;
+            }
+            qbias[0] = P.q_bias[lane];
+            qbias[1] = P.q_bias[64 + (lane < 26 ? lane : 0)];
+        } else if (MODE == MODE_SELFPLAY && P.q90 != nullptr) {
+            const float* qrow = P.q90 + (size_t)g * P.q_stride;
+            qpre[0][0] = qrow[lane];
+            qpre[1][0] = qrow[64 + (lane < 26 ? lane : 0)];
+        }
     }
     m.x = __builtin_amdgcn_readfirstlane(m.x); m.y = __builtin_amdgcn_readfirstlane(m.y);
     m.z = __builtin_amdgcn_readfirstlane(m.z); m.w = __builtin_amdgcn_readfirstlane(m.w);
@@ -112,7 +135,22 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
             if (explored) {
                 idx = (int)(r.v[1] % (uint32_t)n_moves);            // dqn.cpp:33
             } else {
-                if (P.q_slabs != nullptr) {
+                if (q_from_slabs) {
+                    auto q_pre = [&](int e) {                                        // q_head_finish_kernel's association, on the
+                        float sum = 0.f;                                             // values requested at the top of the kernel
+#pragma unroll
+                        for (int z = 0; z < 8; z += 4) {
+                            if (z < P.q_nslabs) {
+                                float t = qpre[e][z] + qpre[e][z + 1];
+                                if (z + 3 < P.q_nslabs) t += qpre[e][z + 2] + qpre[e][z + 3];
+                                sum = z == 0 ? t : sum + t;
+                            }
+                        }
+                        return tanhf(qbias[e] + sum);
+                    };
+                    S.q[lane] = q_pre(0);
+                    if (lane < 26) S.q[64 + lane] = q_pre(1);
+                } else if (P.q_slabs != nullptr) {                                   // (more than 8 k-slabs: loaded here)
                     auto q_of = [&](int j) {
                         const float* p = P.q_slabs + (size_t)g * 96 + j;
                         float sum = 0.f;
@@ -126,9 +164,8 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
                     S.q[lane] = q_of(lane);
                     if (lane < 26) S.q[64 + lane] = q_of(64 + lane);
                 } else {
-                const float* qrow = P.q90 + (size_t)g * P.q_stride; // dqn.cpp:37
-                S.q[lane] = qrow[lane];
-                if (lane < 26) S.q[64 + lane] = qrow[64 + lane];
+                    S.q[lane] = qpre[0][0];                                          // dqn.cpp:37 (the row requested at the top)
+                    if (lane < 26) S.q[64 + lane] = qpre[1][0];
                 }
                 wave_sync();
                 const float NEG = -__builtin_inff();
