@@ -287,7 +287,7 @@ int xq_dqn_set_td_tail(xq_dqn* d, int on);
  * chessai.cpp:268-289) is computed.  0 (default): per-(square, piece) segmented sums of delta rows on the vector ALU.  1 (first hidden
  * width a multiple of 64, >= 256 samples; other shapes keep 0): the dense product one-hot^T x delta_0 on the bf16 matrix pipe, exact —
  * the one-hot operand is 0 / 1 and delta_0 is split into three bf16 values per fp32 (hi + mid + lo, every residual exact), products
- * exact, fp32 accumulation.  Same value up to the summation order (both within a few fp32 ulp of the fp64 oracle).  Measured: 1 is the
+ * exact, fp32 accumulation.  Same value up to the summation order (both within a few fp32 ulp of an fp64 evaluation).  Measured: 1 is the
  * faster kernel alone (31 against 40 us at 8192 x 256) and the slower step inside the fused launches, hence opt-in. */
 int xq_dqn_set_l0_grad_mode(xq_dqn* d, int mode);
 /* XQ_QMAX_*: how the TD step finds max_a' Q(s',a').  XQ_QMAX_SCREENED applies to fp32 nets with XQ_TD_ONLINE_NET / XQ_TD_TARGET_NET
