@@ -789,8 +789,11 @@ def main():
                 chains = 3 if dbl else 2
                 big = ((minibatch + 127) // 128) * ((LAYERS[2] + 127) // 128) * chains >= 512
                 return "gemm_f32_kernel<0, 0, 1, %s, 0>" % ("2, 2" if big else "1, 1")
-            if name == "gemm_hidden_fwd@select" and not CFG["bf16"] and len(LAYERS) == 4:
-                return "gemm_f32_kernel<0, 0, 4, 1, 1, 0>"      # one hidden product per ply, the select head riding on it
+            if name == "gemm_hidden_fwd@select" and not CFG["bf16"]:
+                if len(LAYERS) == 4:
+                    return "gemm_f32_kernel<0, 0, 4, 1, 1, 0>"  # one hidden product per ply, the select head riding on it
+                # deeper nets: the plain products and the head-riding last one share the bracket — traffic = their mean
+                return ["gemm_f32_kernel<0, 0, 1, 1, 1, 0>", "gemm_f32_kernel<0, 0, 4, 1, 1, 0>"]
             if name == "qmax_refine":
                 return "qmax_refine2_kernel<" if Hl in (256, 512) else "qmax_refine_kernel<"
             return ROCPROF_NAMES.get(name)
@@ -806,7 +809,12 @@ def main():
             rk = rocprof_kernel(name)
             e["rocprof_kernel"] = rk
             if rk:
-                tr, src = pmc_traffic(rk, args.config)
+                if isinstance(rk, list):
+                    got = [pmc_traffic(x, args.config) for x in rk]
+                    vals = [t_ for t_, _ in got if t_]
+                    tr, src = (sum(vals) / len(vals) if vals else None), got[0][1]
+                else:
+                    tr, src = pmc_traffic(rk, args.config)
                 e["traffic"] = tr
                 e["traffic_source"] = src
                 if tr and wk and wk["hbm_bytes"]:

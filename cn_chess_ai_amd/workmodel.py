@@ -9,7 +9,6 @@ Names are the bracket names of xq_dqn_kernel_stats; "@select" = the same kernel 
 stream).  Per-LAUNCH figures: a kernel launched several times per step (td_tail_deltas of a 3-hidden-layer net, the select
 chain with several plies per update) gets the mean over its launches of one step.
 """
-import math
 
 NO = 8100            # outputs (90 x 90 actions, chessai.cpp:399-402)
 STATE = 1260         # 90 x 14 one-hot inputs, never materialised
@@ -143,6 +142,38 @@ def step_work(layers, minibatch, n_games, plies=1, bf16=False, bf16_bwd=False, t
             slabs += pick_splits(h[l], h[l - 1], B) * h[l] * h[l - 1]
         touched = STATE * H1 + sum(h[l] * h[l - 1] for l in range(1, k)) + 96 * Hl + 96 + sum(h)
         put("sgd_apply", 2.0 * touched, 4 * (slabs + 2 * touched), "hbm", "ordered sum of every partial-sum slab + SGD step on the touched parameters")
+    else:
+        # bf16 net (and xq_dqn_set_td_tail(0)): the same work as kernels of their own on two streams.  bf16 operands where the backward
+        # products run on the bf16 loop (XQ_PRECISION_BF16_FULL), fp32 sums everywhere.
+        eb = 2 if bf16_bwd else 4
+        if k >= 2:
+            fl = by = 0.0
+            for l in range(k - 2, -1, -1):
+                fl += 2.0 * B * h[l + 1] * h[l]
+                by += B * h[l + 1] * eb + h[l] * h[l + 1] * eb + B * h[l] * (eb + 4 + (2 if bf16_bwd else 0))
+            put("gemm_hidden_delta", fl / (k - 1), by / (k - 1), "mfma", "hidden delta product (delta_{l+1} . weight view) (1 - a^2)",
+                PEAK_BF16_MFMA_TFLOPS if bf16_bwd else PEAK_F32_MFMA_TFLOPS)
+            fl = by = 0.0
+            for l in range(1, k):
+                sp = max(1, min(16, 256 // max(1, (h[l] // 256) * (h[l - 1] // 128)))) if bf16_bwd else pick_splits(h[l], h[l - 1], B)
+                fl += 2.0 * h[l] * h[l - 1] * B
+                by += B * (h[l] + h[l - 1]) * eb + sp * h[l] * h[l - 1] * 4
+            put("gemm_grad_hidden", fl / (k - 1), by / (k - 1), "mfma", "hidden weight-gradient product, split-K slabs",
+                PEAK_BF16_MFMA_TFLOPS if bf16_bwd else PEAK_F32_MFMA_TFLOPS)
+        chunk = 2048 if B >= 16384 else 1024
+        nch = (B + chunk - 1) // chunk
+        put("l0_grad_segsum", 2.0 * B * 32 * H1, B * H1 * 4 + 48 * B + nch * STATE * H1 * 4, "hbm",
+            "layer-0 gradient as per-(square, piece) segmented sums of delta rows (L2 gather)")
+        put("out_grad_segsum", out_fl, out_by, "hbm", "output-layer gradient rows 0..95 as segmented sums by action")
+        R = max(1, min(64, B // 64))
+        put("bias_grad_colsum", float(B * sum(h)), B * sum(h) * 4 + R * sum(h) * 4, "hbm", "bias gradients: column sums of every hidden delta")
+        slabs = nch * STATE * H1 + nch_out * (96 * Hl + 96) + R * sum(h)
+        for l in range(1, k):
+            sp = max(1, min(16, 256 // max(1, (h[l] // 256) * (h[l - 1] // 128)))) if bf16_bwd else pick_splits(h[l], h[l - 1], B)
+            slabs += sp * h[l] * h[l - 1]
+        touched = STATE * H1 + sum(h[l] * h[l - 1] for l in range(1, k)) + 96 * Hl + 96 + sum(h)
+        put("sgd_apply", 2.0 * touched, 4 * (slabs + 2 * touched) + (2 * touched if bf16 else 0), "hbm",
+            "ordered sum of every partial-sum slab + SGD step on the touched parameters (+ their bf16 shadow)")
     nw = STATE * H1 + sum(h[l] * h[l - 1] for l in range(1, k)) + Hl * NO
     nb = sum(h) + NO
     put("target_sync_copy", 0.0, 8.0 * (nw + nb), "hbm", "updateTargetNetwork(): device copy of all parameters")
