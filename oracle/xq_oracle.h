@@ -11,9 +11,18 @@
  *     and — for the scan order — by the real getValidMoves() per-square lists.
  *   - ChessAI::getAIMove / startSelfPlay / onGameCompleted (chessai.cpp:29-83, :191-266, :370-393): restatement with the C
  *     library rand() injected; no upstream vectors exist for them.
- *   - NN (dqn.cu / dqn.cpp): restatement only — dqn.cu needs nvcc/CUDA headers that this image lacks, so the
- *     reference NN cannot be built here without stand-ins: "parity unpinned" by execution; pinned only by the
- *     structural known answers in SURVEY.md (offsets, parameter counts, file size).
+ *   - NN runtime (dqn.cu: constructor, forward, backpropagate with the hidden delta as written, copyWeightsAndBiasesFrom):
+ *     PINNED BY EXECUTION since round 4 — dqn.cu + dqn.h go through the image's own hipify-perl (cuda* -> hip* API
+ *     identifiers only, checked line by line) and hipcc, the reference's five kernels and host code then run on an MI355X
+ *     (oracle/_ref/xqref_nn, oracle/ref/ref_nn_driver.cpp); outputs in tests/golden/ref_nn.npz; this restatement equals them
+ *     to <= 2e-17 on Q-values, every bias and all of layer 0's weights for the three BASELINE topologies and four small ones
+ *     (tests/test_ref_nn_golden.py).  Not pinnable by any execution: the updated weights of layers >= 1, which upstream
+ *     computes from device memory it has already released (dqn.cu:371 / :441) — modelled here as "the released block still
+ *     holds the activation", which is what the reference's author evidently observed and what HIP's allocator reproduces
+ *     for 14 of the fixture's 48 cases.
+ *   - DQN façade (dqn.cpp: selectAction, train, save / load): restatement — dqn.cpp needs Qt >= 6.6 (QDataStream::Qt_6_6,
+ *     Qt 6 include graph) and this image has Qt 5.9.7: unbuildable without stand-ins, not built; pinned by the structural
+ *     known answers in SURVEY.md (file size 9 650 484 B, byte order) and by the injected-rand() tests.
  */
 #ifndef XQ_ORACLE_H
 #define XQ_ORACLE_H
