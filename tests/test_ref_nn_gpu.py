@@ -81,3 +81,57 @@ def test_backpropagate_matches_the_reference_run(xq, topo):
         if step > 1e-4:
             assert np.abs(got0 - ref0).max() < 2e-3 * step + 1e-7
     d.close()
+
+
+def test_live_reference_run_on_a_fresh_seed(xq, tmp_path):
+    """The reference NN runtime itself (oracle/_ref/xqref_nn travels with the snapshot), run NOW on this GPU with a seed the
+    fixture does not hold: its Q-values and its one-step update against the oracle (fp64, 1e-14) and the HIP path."""
+    import os
+    import subprocess
+
+    import gen_golden_nn as gg
+    import xqoracle as xo
+    if not os.path.exists(gg.BIN):
+        pytest.skip("oracle/_ref/xqref_nn not built (needs /root/reference in the authoring container)")
+    probe = subprocess.run([gg.BIN, "probe"], capture_output=True, text=True)
+    if probe.returncode != 0:
+        pytest.skip("allocator probe: small blocks are not sub-allocated here; not running the reference's backpropagate")
+    seed, sizes = 4242, [1260, 256, 256, 8100]
+    out = str(tmp_path / "live.bin")
+    subprocess.run(["timeout", "-k", "10", "120", gg.BIN, "nn", out, str(seed)] + [str(s) for s in sizes], check=True)
+    rec = gg.parse(out)
+    w, b = refnn.params(seed, sizes)
+    d = xq.DQN(sizes, 0.001, 0.99, seed=1)
+    d.set_params(w, b)
+    qpos = rec["q_positions"]
+
+    def inp(tag):
+        x = np.zeros(sizes[0])
+        if tag + "_onehot" in rec:
+            x[rec[tag + "_onehot"]] = 1.0
+        else:
+            x[:] = rec[tag + "_dense"]
+        return x
+    for k in range(6):
+        x = inp(f"fwd{k}")
+        assert np.abs(xo.nn_forward(sizes, w, b, x)[qpos] - rec[f"fwd{k}_q"]).max() <= 1e-14
+        assert np.abs(d.getQValues(x)[qpos] - rec[f"fwd{k}_q"]).max() < 5e-6
+    nhid, n0 = sum(sizes[1:-1]), sizes[0] * sizes[1]
+    for u in range(4):
+        tag = f"bp{u}"
+        x = inp(tag)
+        a, (y, lr) = int(rec[tag + "_action"][0]), rec[tag + "_y_lr"]
+        t = xo.nn_forward(sizes, w, b, x)
+        t[a] = y
+        w2, b2 = w.copy(), b.copy()
+        assert xo.nn_backprop(sizes, w2, b2, x, t, lr, 0) == 0
+        rows, cols = rec[tag + "_w0_rows"], rec[tag + "_w0_cols"]
+        ref0 = rec[tag + "_w0"].reshape(len(rows), len(cols))
+        assert np.abs(b2[:nhid] - rec[tag + "_hidden_biases"]).max() <= 1e-14
+        assert np.abs(w2[:n0].reshape(sizes[1], sizes[0])[np.ix_(rows, cols)] - ref0).max() <= 1e-14
+        d.set_params(w, b)
+        d.backpropagate(x, t, lr, 1.0, 0)
+        gw, gb = d.get_params()
+        assert np.abs(gb[:nhid] - rec[tag + "_hidden_biases"]).max() < PTOL
+        assert np.abs(gw[:n0].reshape(sizes[1], sizes[0])[np.ix_(rows, cols)] - ref0).max() < PTOL
+    d.close()
