@@ -3211,6 +3211,14 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
                         {sel_net, next_boards, touts, touts_bf, nullptr, screened ? d->scr_ab : nullptr, scr_new || bf_frag},
                         {XQ_NET_TARGET, next_boards, t2outs, t2outs_bf, nullptr, nullptr, false}};
     XQ_TRY(chain_boards(d, jobs, dbl ? 3 : 2, slots, n, screened ? &shadow : nullptr));
+    // The select chain of the trainer starts HERE when max_a' Q(s',a') runs on the bf16 matrix pipe (screening pass of an fp32 net, or
+    // the output layer of a bf16 net): its layer-0 gather (L2-bound) then runs beside the screening pass (matrix-pipe-bound) and
+    // is gone when the refine kernel — a chain of dependent memory round trips that the gather doubles in length — starts.  Same-box
+    // A/B, round 4 (3 x 300 steps per leg): behind the screening pass 0.1946-0.1969 ms, here 0.1888-0.1937; behind the layer-0 gather of
+    // this step 0.1886-0.1896 against 0.1914-0.1921; at the very top of the step no difference; --config 4 / 5 -0.3 % / -0.9 %.
+    // The full fp32 product keeps the chip to itself: there the chain starts behind it (below).
+    const bool gate_early = (screened || bf) && !d->late_gate;
+    if (gate_early) XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
     int zparts = kReduceParts;
     if (screened) {
         const int tiles_m = (NO + 127) / 128, total = tiles_m * ((n + 127) / 128);
@@ -3256,10 +3264,9 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             hipLaunchKernelGGL((gemm_colmax_persistent_kernel<2, 2, DT_BF16, CM_TOP2>), dim3(grid), dim3(256), bias_lds_all, d->cur, g, tiles_m, total);
             XQ_HIP(hipGetLastError());
         }
-        // (the select chain of the trainer starts here.  Behind the refine kernel instead — which would then have the chip to itself,
-        // 17 instead of 27-34 us — the select chain ends after the gradients and the step waits for it: 0.197 -> 0.207 ms; in front of
-        // the screening pass: no difference)
-        if (!d->late_gate) XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
+        // (the select chain of the trainer started in front of the screening pass, above.  Behind the refine kernel instead — which would
+        // then have the chip to itself, 17 instead of 27-34 us — the select chain ends after the gradients and the step waits for
+        // it: 0.197 -> 0.207 ms)
         {
             ProfScope ps(d, "qmax_refine", 2.0 * n * Hl * 3, 12.0 * G * n + 4.0 * n * Hl);
             const size_t lds = (size_t)G * kRefineSamples * (sizeof(uint32_t) + sizeof(uint16_t));
@@ -3369,7 +3376,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             XQ_GEMM((launch_gemm<L_KCONTIG, L_KCONTIG, EPI_COLMAX>(d, g, 1, "gemm_qmax_rowmax")));
         }
     }
-    if (!d->late_gate) XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
+    if (!d->late_gate && !gate_early) XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
     {   // the partial maxima of every sample folded into kReduceParts values (+ row indices): coalesced, block-cooperative
         ProfScope ps(d, "colmax_reduce", (double)n * n_part, (dbl ? 8.0 : 4.0) * n * (n_part + kReduceParts));
         hipLaunchKernelGGL(colmax_reduce_kernel, dim3((n + 63) / 64, kReduceParts), dim3(256), 0, d->cur, d->partial,
