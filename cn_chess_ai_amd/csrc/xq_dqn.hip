@@ -1214,13 +1214,17 @@ struct TailArgs {
     const uint16_t* l0_planes; long long l0_plane_stride; int l0_kpad, l0_ncb;      // != nullptr: the matrix-pipe form, grid (4, H / 32, nch)
     ColsumJobs cj; int cj_gx, cj_gy;               // grid (gx, R, njobs)
 };
-template <unsigned KINDS>
+// L0MFMA: the layer-0 blocks are the matrix-pipe form (xq_dqn_set_l0_grad_mode(1)) — an instantiation of its own: that body needs 180
+// VGPRs against 136 for the rest, and behind a run-time branch in the default kernel it capped every block of the launch at two waves
+// per SIMD.  (Measured, same box, 3 x 3 x 300 steps: 180 / 136 / 106 VGPRs — the last forced with amdgpu_waves_per_eu(4) — 0.1887-0.1899 /
+// 0.1896-0.1903 / 0.1885-0.1897 ms per step: the launch is not bound by its occupancy.)
+template <unsigned KINDS, bool L0MFMA = false>
 __global__ __launch_bounds__(256) void td_tail_kernel(const TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tail_smem[];
     int b = (int)blockIdx.x;
     if (KINDS & TAIL_L0) {
         if (b < a.n_l0) {
-            if (a.l0_planes != nullptr) {
+            if (L0MFMA) {
                 const int rest = b >> 2;
                 l0_grad_mfma_block<0>(a.l0_boards, a.l0_planes, a.l0_plane_stride, a.l0_kpad, a.l0_n, a.l0_H, a.l0_chunk, a.l0_partial, b & 3,
                                       rest % a.l0_ncb, rest / a.l0_ncb, reinterpret_cast<uint32_t*>(tail_smem));
@@ -3006,7 +3010,8 @@ static int tail_launch(xq_dqn* d, bool last, const char* name) {
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), d->tail_lds, d->cur, T);
     };
-    if (last) launch(td_tail_kernel<TAIL_L0 | TAIL_GRAD | TAIL_OUT | TAIL_COLSUM>);
+    if (last && T.l0_planes != nullptr) launch(td_tail_kernel<TAIL_L0 | TAIL_GRAD | TAIL_OUT | TAIL_COLSUM, true>);
+    else if (last) launch(td_tail_kernel<TAIL_L0 | TAIL_GRAD | TAIL_OUT | TAIL_COLSUM>);
     else launch(td_tail_kernel<TAIL_GRAD | TAIL_DELTA | TAIL_OUT>);
     XQ_HIP(hipGetLastError());
     return XQ_OK;
