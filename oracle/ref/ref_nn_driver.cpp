@@ -5,7 +5,7 @@
 // /root/reference/src/dqn.cu and /root/reference/include/dqn.h are CUDA sources; this image has no nvcc and no
 // CUDA runtime, but it ships AMD's own source translator (/opt/rocm/bin/hipify-perl).  oracle/Makefile, target
 // `refnn`, pipes the two files — read where they lie — through hipify-perl into oracle/_ref/src/ (git-ignored AND
-// gpurun-ignored: the text never enters history and never travels), checks that every changed line differs only by
+// gpurun-ignored AND deleted when the recipe ends: the text never enters history, never travels, does not stay), checks that every changed line differs only by
 // cuda* -> hip* API identifiers / the runtime header name, and compiles the result with hipcc for gfx950 against
 // the image's QtCore 5.9.7.  The five kernels (dqn.cu:184-195, 275-319), the launch geometry, the allocation
 // pattern and the host control flow of NeuralNetwork::forward / ::backpropagate (dqn.cu:199-260, 323-467) are
