@@ -234,7 +234,6 @@ int cmd_nn(int argc, char** argv) {
         }
         // layers >= 1: depend on the read of released activations — recorded, never golden
         for (int l = 1; l < nL; ++l) {
-            const size_t n = (size_t)sizes[l] * sizes[l + 1];
             std::vector<int64_t> pos(256);
             std::vector<double> val(256);
             for (int i = 0; i < 256; ++i) {
@@ -244,7 +243,6 @@ int cmd_nn(int argc, char** argv) {
                 pos[i] = (int64_t)(row * sizes[l] + col);
                 val[i] = nn.host_weights[nn.weightOffsets[l] + pos[i]];
             }
-            (void)n;
             put_i64(tag + "_ub_w" + std::to_string(l) + "_pos", pos);
             put_f64(tag + "_ub_w" + std::to_string(l), val);
         }
