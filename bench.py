@@ -116,6 +116,18 @@ def cpu_baseline(seconds=15.0):
             out["env_only_reference_steps_per_s"] = float(s) / float(t)
         except Exception as e:   # Qt runtime missing on the box: report, do not fail the bench
             out["env_only_reference_error"] = str(e)[:80]
+    refnn = os.path.join(ROOT, "oracle", "_ref", "xqref_nn")
+    if os.path.exists(refnn):   # the reference's OWN NN runtime (dqn.cu through hipify-perl, oracle/ref/ref_nn_driver.cpp) on this very GPU:
+        try:                    # the NN work of one ply of ChessAI::train — two forwards + one backpropagate, batch 1 — as upstream does it
+            if subprocess.run([refnn, "probe"], capture_output=True, timeout=60).returncode == 0:
+                r = json.loads(subprocess.check_output(["timeout", "-k", "5", "60", refnn, "time", "300"] + [str(x) for x in (1260, 128, 8100)],
+                                                       timeout=90).decode().strip().splitlines()[-1])
+                out["reference_nn_runtime_on_this_gpu"] = {
+                    "value": r["plies_per_s"], "unit": "plies/s (2 x forward + 1 x backpropagate, batch 1, net 1260-128-8100 fp64)",
+                    "sample": f"{r['plies']} plies in {r['seconds']:.2f} s", "what": "/root/reference/src/dqn.cu's kernels and host code, "
+                    "CUDA API identifiers renamed by hipify-perl, run by oracle/_ref/xqref_nn as a child process — no env, no move generation"}
+        except Exception as e:
+            out["reference_nn_runtime_error"] = str(e)[:80]
     return out
 
 

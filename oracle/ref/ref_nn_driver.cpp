@@ -29,6 +29,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cinttypes>
 #include <cstdint>
 #include <cstdio>
@@ -275,14 +276,46 @@ int cmd_nn(int argc, char** argv) {
     return 0;
 }
 
+// time <iters> <L0> <L1> ... : the NN work of one ply of ChessAI::train (chessai.cpp:121-133) — getQValues(state), getQValues(nextState),
+// backpropagate(state, target) — as the reference's own runtime does it on THIS GPU: batch 1, a cudaMalloc / cudaFree / synchronize per
+// layer.  Prints one JSON line.  (The read of released memory inside backpropagate is there as in every run of the reference.)
+int cmd_time(int argc, char** argv) {
+    if (argc < 5) return 64;
+    const int iters = std::atoi(argv[2]);
+    std::vector<int> sizes;
+    for (int i = 3; i < argc; ++i) sizes.push_back(std::atoi(argv[i]));
+    NeuralNetwork nn(sizes);
+    fill_params(nn, 99);
+    const int IN = sizes.front();
+    std::vector<double> x(IN, 0.0), x2(IN, 0.0);
+    for (int i : onehot_indices(99, 1, IN, 30)) x[i] = 1.0;
+    for (int i : onehot_indices(99, 2, IN, 30)) x2[i] = 1.0;
+    for (int w = 0; w < 3; ++w) { auto q = nn.forward(x); auto q2 = nn.forward(x2); q[w] = 0.1; nn.backpropagate(x, q, 0.001); }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0; it < iters; ++it) {
+        std::vector<double> q = nn.forward(x);
+        std::vector<double> q2 = nn.forward(x2);
+        double m = q2[0]; for (double v : q2) m = v > m ? v : m;
+        q[it % 90] = -1.0 + 0.99 * m;
+        nn.backpropagate(x, q, 0.001);
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("{\"plies\": %d, \"seconds\": %.4f, \"plies_per_s\": %.1f}\n", iters, sec, iters / sec);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
+    if (argc >= 2 && std::strcmp(argv[1], "time") == 0) {
+        try { return cmd_time(argc, argv); }
+        catch (const std::exception& e) { std::fprintf(stderr, "xqref_nn: %s\n", e.what()); return 70; }
+    }
     if (argc >= 2 && std::strcmp(argv[1], "probe") == 0) return cmd_probe();
     if (argc >= 2 && std::strcmp(argv[1], "nn") == 0) {
         try { return cmd_nn(argc, argv); }
         catch (const std::exception& e) { std::fprintf(stderr, "xqref_nn: %s\n", e.what()); return 70; }
     }
-    std::fprintf(stderr, "usage: xqref_nn probe | nn <out.bin> <seed> <L0> <L1> ... <Ln>\n");
+    std::fprintf(stderr, "usage: xqref_nn probe | nn <out.bin> <seed> <L0> <L1> ... <Ln> | time <iters> <L0> ... <Ln>\n");
     return 64;
 }
