@@ -92,7 +92,7 @@ def cpu_all_cores(seconds=8.0):
     return {"value": total, "cores": T, "sample": f"{T} independent instances x {seconds:.0f} s"}
 
 
-def cpu_baseline(seconds=15.0):
+def cpu_baseline(seconds=15.0, reference_nn=False):
     """CPU port of the reference loop (oracle/xq_oracle.c: xqo_train_episode = chessai.cpp:90-167 with the
     {1260,128,8100} fp64 net, batch 1, bug-compatible backprop) on one host core, bounded to ~`seconds`."""
     steps, episodes, el = cpu_train_loop(seconds)
@@ -117,7 +117,7 @@ def cpu_baseline(seconds=15.0):
         except Exception as e:   # Qt runtime missing on the box: report, do not fail the bench
             out["env_only_reference_error"] = str(e)[:80]
     refnn = os.path.join(ROOT, "oracle", "_ref", "xqref_nn")
-    if os.path.exists(refnn):   # the reference's OWN NN runtime (dqn.cu through hipify-perl, oracle/ref/ref_nn_driver.cpp) on this very GPU:
+    if reference_nn and os.path.exists(refnn):   # (--reference-nn) the reference's OWN NN runtime (dqn.cu through hipify-perl, oracle/ref/ref_nn_driver.cpp) on this very GPU:
         try:                    # the NN work of one ply of ChessAI::train — two forwards + one backpropagate, batch 1 — as upstream does it
             if subprocess.run([refnn, "probe"], capture_output=True, timeout=60).returncode == 0:
                 r = json.loads(subprocess.check_output(["timeout", "-k", "5", "60", refnn, "time", "300"] + [str(x) for x in (1260, 128, 8100)],
@@ -378,6 +378,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reference-nn", action="store_true",
+                    help="cpu_baseline also times the reference's own NN runtime on this GPU (oracle/_ref/xqref_nn time; off by default: upstream's "
+                         "backpropagate reads device memory it has released, which the default bench does not need to run)")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # one instance of cpu_all_cores()
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with HIP events (diagnostic)")
     ap.add_argument("--games", type=int, default=N_GAMES, help="games per GPU (default = BASELINE's 8192; other values are diagnostic)")
@@ -955,7 +958,7 @@ def main():
             line["facade"] = f
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline() if args.config == 2 else cpu_baseline(6.0)
+                line["cpu_baseline"] = cpu_baseline(15.0 if args.config == 2 else 6.0, args.reference_nn)
             except Exception as e:           # never lose the measured line to the reporting leg
                 line["cpu_baseline"] = {"value": None, "unit": "env steps/s", "cores": 0, "kind": "port", "sample": "failed: " + str(e)[:160]}
         print(json.dumps(line), flush=True)
