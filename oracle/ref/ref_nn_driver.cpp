@@ -100,7 +100,10 @@ int cmd_probe() {
     if (hipMalloc(&c, 2048) != hipSuccess) return 2;
     const uintptr_t blk = (uintptr_t)x & ~(uintptr_t)((2u << 20) - 1);
     auto inblk = [&](const void* p) { return ((uintptr_t)p & ~(uintptr_t)((2u << 20) - 1)) == blk; };
-    const bool same = inblk(a) && inblk(b) && inblk(c);
+    // carved out of one block, back to back (a fragment allocator), not three mappings of their own that happen to be neighbours
+    const bool tight = (uintptr_t)a > (uintptr_t)x && (uintptr_t)a - (uintptr_t)x <= 80 * 1024 && (uintptr_t)b > (uintptr_t)a &&
+                       (uintptr_t)b - (uintptr_t)a <= 16 * 1024 && (uintptr_t)c > (uintptr_t)b && (uintptr_t)c - (uintptr_t)b <= 8 * 1024;
+    const bool same = inblk(a) && inblk(b) && inblk(c) && tight;
     (void)hipFree(b);
     if (hipMalloc(&d, 64800) != hipSuccess) return 2;
     std::printf("{\"x\": \"%p\", \"a\": \"%p\", \"b\": \"%p\", \"c\": \"%p\", \"d_after_free_b\": \"%p\", "
