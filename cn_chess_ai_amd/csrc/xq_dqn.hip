@@ -14,6 +14,9 @@
 // row-major [out][in], concatenated] [b_0 .. b_out].  Keeping layers >= 1 in the reference's flat order lets the
 // bug-compatible hidden delta (dqn.cu:406-423 as written: wrong stride, reads across layer boundaries) be expressed
 // as the same GEMM with a different base/leading dimension.
+// This file = the handle (struct xq_dqn) + host orchestration + the C ABI; the kernels live in xq_l0.hip.h (layer-0 gathers and
+// segmented sums), xq_tail.hip.h (TD delta, gradient sums, fused launches, SGD), xq_refine.hip.h (screening pass 2), xq_l0grad.hip.h
+// (layer-0 gradient on the matrix pipe), xq_gemm*.hip.h and xq_screen.hip.h (matrix-pipe products).
 #include "xq_internal.h"
 #include "xq_gemm.hip.h"
 #include "xq_screen.hip.h"
@@ -193,1543 +196,14 @@ struct ProfScope {
     ~ProfScope() { p.end(h, s, flops, bytes); }
 };
 
-// ---------------------------------------------------------------------------------------------------------------
-// kernels
-// ---------------------------------------------------------------------------------------------------------------
+}  // namespace xq
 
-// where sample b of a minibatch lives: identity, an explicit slot list, or the replay sampler's Philox stream recomputed
-// in place (ctr = {b, 0, call, 1}, key = seed, % size — identical to replay_sample_kernel).  A windowed sample draws from the
-// `size` ring slots that start at `start` (the overlapped trainer excludes the slots a concurrent collect is writing).
-struct SlotSrc {
-    const int32_t* slots;
-    uint32_t implicit, call, seed_lo, seed_hi, size, start, cap;
-};
-__device__ __forceinline__ int slot_of(const SlotSrc& s, int b) {
-    if (s.implicit) {
-        uint32_t v = s.start + philox4x32_10((uint32_t)b, 0u, s.call, 1u, s.seed_lo, s.seed_hi).v[0] % s.size;
-        if (v >= s.cap) v -= s.cap;
-        return (int)v;
-    }
-    return s.slots ? s.slots[b] : b;
-}
-// the forward chains of a TD step (s on the online net, s' on the TD net, and for Double DQN s' on the target net as well)
-// share one launch per layer
-enum { kMaxChains = 3 };
-// bf16 copy of a weight matrix [NO][K] (K % 64 == 0) + the largest row norm (exact screening of max_a' Q(s',a'), see
-// qmax_refine_kernel).  A quarter-wave per row, 2 rows per quarter, all of a quarter's loads in flight together (pure latency:
-// 8 MB in, 4 MB out); block `blk` of 256 threads takes rows [32 blk, 32 blk + 32); rows >= NO of the padded copy stay zero.
-struct ShadowJob {
-    const float* W; const float* bias; int NO, K; uint16_t* Wb;
-    unsigned* w_dyn; unsigned* b_dyn;         // rows 0..95 (kShadowDynBlocks blocks): this step's parity slots
-    unsigned* w_stat; unsigned* b_stat;       // rows >= 96
-    int nblocks;                              // blocks to run: all of them, or kShadowDynBlocks when rows >= 96 are still valid
-};
-enum { kShadowRows = 32, kShadowDynBlocks = 3 };
-__device__ __forceinline__ void screen_shadow_block(const ShadowJob& S, int blk, float* nrm /* LDS [8] */) {
-    const int ql = (int)(threadIdx.x & 15), quarter = (int)(threadIdx.x >> 4);
-    const int row0 = blk * kShadowRows + quarter * 2;
-    float mx = 0.f;
-    float bm = fmaxf(row0 < S.NO ? fabsf(S.bias[row0]) : 0.f, row0 + 1 < S.NO ? fabsf(S.bias[row0 + 1]) : 0.f);
-    if (S.K == 256) {
-        float4 x[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                x[u][t] = *reinterpret_cast<const float4*>(S.W + (long long)min(row0 + u, S.NO - 1) * 256 + t * 64 + ql * 4);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            float ss = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                ss += x[u][t].x * x[u][t].x + x[u][t].y * x[u][t].y + x[u][t].z * x[u][t].z + x[u][t].w * x[u][t].w;
-                if (row0 + u < S.NO) {
-                    const uint16_t q0 = bf16_bits(x[u][t].x), q1 = bf16_bits(x[u][t].y), q2 = bf16_bits(x[u][t].z), q3 = bf16_bits(x[u][t].w);
-                    *reinterpret_cast<uint2*>(S.Wb + (long long)(row0 + u) * 256 + t * 64 + ql * 4) =
-                        make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
-                }
-            }
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
-            mx = fmaxf(mx, row0 + u < S.NO ? ss : 0.f);
-        }
-    } else {
-        for (int u = 0; u < 2; ++u) {
-            float ss = 0.f;
-            if (row0 + u < S.NO)
-                for (int k = ql * 4; k < S.K; k += 64) {
-                    const float4 y = *reinterpret_cast<const float4*>(S.W + (long long)(row0 + u) * S.K + k);
-                    ss += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
-                    const uint16_t q0 = bf16_bits(y.x), q1 = bf16_bits(y.y), q2 = bf16_bits(y.z), q3 = bf16_bits(y.w);
-                    *reinterpret_cast<uint2*>(S.Wb + (long long)(row0 + u) * S.K + k) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
-                }
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
-            mx = fmaxf(mx, ss);
-        }
-    }
-#pragma unroll
-    for (int off = 32; off >= 16; off >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, off, 64)); bm = fmaxf(bm, __shfl_xor(bm, off, 64)); }
-    if ((threadIdx.x & 63) == 0) { nrm[threadIdx.x >> 6] = mx; nrm[4 + (threadIdx.x >> 6)] = bm; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float m = sqrtf(fmaxf(fmaxf(nrm[0], nrm[1]), fmaxf(nrm[2], nrm[3])));
-        const float b = fmaxf(fmaxf(nrm[4], nrm[5]), fmaxf(nrm[6], nrm[7]));
-        unsigned* wslot = blk < kShadowDynBlocks ? S.w_dyn : S.w_stat;
-        unsigned* bslot = blk < kShadowDynBlocks ? S.b_dyn : S.b_stat;
-        const unsigned mb = __builtin_bit_cast(unsigned, m), bb = __builtin_bit_cast(unsigned, b);
-        if (mb > *reinterpret_cast<volatile unsigned*>(wslot)) atomicMax(wslot, mb);
-        if (bb > *reinterpret_cast<volatile unsigned*>(bslot)) atomicMax(bslot, bb);
-    }
-}
-__global__ __launch_bounds__(256) void screen_shadow_kernel(ShadowJob S) {
-    __shared__ float nrm[8];
-    screen_shadow_block(S, (int)blockIdx.x, nrm);
-}
+// kernels (each header opens namespace xq itself)
+#include "xq_l0.hip.h"
+#include "xq_tail.hip.h"
+#include "xq_refine.hip.h"
 
-struct L0Jobs {
-    const uint32_t* boards[kMaxChains];
-    const float* W0T[kMaxChains];
-    const uint16_t* W0T_bf[kMaxChains];      // bf16 Q-net: shadow of W0^T (same [1260][H] order)
-    const float* b0[kMaxChains];
-    float* out[kMaxChains];                  // fp32 activations (may be nullptr in bf16 mode when nothing reads them)
-    uint16_t* out_bf[kMaxChains];            // bf16 Q-net: bf16 bits of the activations
-    uint32_t* gathered[kMaxChains];
-    int njobs;
-    int nrows;                               // grid rows that gather (njobs - derive_next); the shadow row, if any, is row nrows
-    int derive_next;                         // 1: job 0's waves also produce job 1 (s' = s after one move, SAME net) from their own layer-0 sums:
-                                             // z1(s') = z1(s) - rows of the squares that changed + rows of what stands there now
-    int out_bf_frag;                         // fp32 net: the bf16 copy out_bf is written in MFMA B-fragment order (scr_afrag_index)
-    ShadowJob shadow;                        // W != nullptr: the blocks of grid row y == njobs convert the screening shadow (no extra launch)
-};
-
-// Layer 0 from packed boards: a_1 = tanh(b_0 + sum over occupied squares of W0^T[sq*14 + piece-1][:]).
-// One wave per sample; ascending square order = the reference's i-ascending accumulation with the zeros skipped.
-// BF16: rows come from the bf16 shadow (half the L2 traffic of this gather), the sum runs in fp32, the result is rounded to bf16.
-template <bool BF16>
-__global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, int n, int H) {
-    __shared__ int rows[4][96];
-    if ((int)blockIdx.y == J.nrows) {                   // block-uniform: the screening shadow rides in the same grid
-        if ((int)blockIdx.x < J.shadow.nblocks) screen_shadow_block(J.shadow, (int)blockIdx.x, reinterpret_cast<float*>(&rows[0][0]));
-        return;
-    }
-    const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    const int b = (int)blockIdx.x * 4 + wid;
-    if (b >= n) return;
-    const int job = (J.derive_next && blockIdx.y >= 1) ? (int)blockIdx.y + 1 : (int)blockIdx.y;    // job 1 is produced by job 0's waves
-    const float* __restrict__ W0T = J.W0T[job];
-    const uint16_t* __restrict__ W0B = J.W0T_bf[job];
-    const float* __restrict__ b0 = J.b0[job];
-    float* __restrict__ out = J.out[job];
-    uint16_t* __restrict__ out_bf = J.out_bf[job];
-    uint32_t* __restrict__ gathered = J.gathered[job];
-    const int srow = slot_of(src, b);
-    const uint32_t* bw = J.boards[job] + (long long)srow * kBoardWords;
-    if (gathered != nullptr && lane < kBoardWords)      // the minibatch's boards, contiguous, for the layer-0 gradient
-        gathered[(long long)b * kBoardWords + lane] = bw[lane];
-    const int s0 = lane, s1 = 64 + lane;
-    const uint32_t n0 = (bw[s0 >> 3] >> (4 * (s0 & 7))) & 15u;
-    const uint32_t n1 = s1 < kSquares ? (bw[s1 >> 3] >> (4 * (s1 & 7))) & 15u : 0u;
-    const unsigned long long m0 = __ballot(n0 != 0), m1 = __ballot(n1 != 0);
-    const int c0 = __popcll(m0);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (n0) rows[wid][__popcll(m0 & below)] = s0 * 14 + (int)n0 - 1;
-    if (n1) rows[wid][c0 + __popcll(m1 & below)] = s1 * 14 + (int)n1 - 1;
-    const int cnt = c0 + __popcll(m1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // s' from s: the squares whose piece code differs (a move changes two), in ascending order, as (row to take out, row to put in);
-    // boards that are not a move apart (an unused slot, a foreign pair) get the full row list of s' instead
-    __shared__ int dpair[4][8][2];
-    __shared__ int rows2[4][96];
-    int nd = -1, cnt2 = 0;                                // nd = -1: nothing derived here; nd > 8: cnt2 rows in rows2
-    if (J.derive_next && job == 0) {
-        const uint32_t* bw2 = J.boards[1] + (long long)srow * kBoardWords;
-        const uint32_t p0 = (bw2[s0 >> 3] >> (4 * (s0 & 7))) & 15u;
-        const uint32_t p1 = s1 < kSquares ? (bw2[s1 >> 3] >> (4 * (s1 & 7))) & 15u : 0u;
-        const unsigned long long d0 = __ballot(p0 != n0), d1 = __ballot(p1 != n1);
-        nd = __popcll(d0) + __popcll(d1);
-        if (nd <= 8) {
-            if (p0 != n0) { const int k = __popcll(d0 & below); dpair[wid][k][0] = n0 ? s0 * 14 + (int)n0 - 1 : -1; dpair[wid][k][1] = p0 ? s0 * 14 + (int)p0 - 1 : -1; }
-            if (p1 != n1) { const int k = __popcll(d0) + __popcll(d1 & below); dpair[wid][k][0] = n1 ? s1 * 14 + (int)n1 - 1 : -1; dpair[wid][k][1] = p1 ? s1 * 14 + (int)p1 - 1 : -1; }
-        } else {
-            const unsigned long long q0 = __ballot(p0 != 0), q1 = __ballot(p1 != 0);
-            const int e0 = __popcll(q0);
-            if (p0) rows2[wid][__popcll(q0 & below)] = s0 * 14 + (int)p0 - 1;
-            if (p1) rows2[wid][e0 + __popcll(q1 & below)] = s1 * 14 + (int)p1 - 1;
-            cnt2 = e0 + __popcll(q1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    auto load4 = [&](int row, int col) -> float4 {
-        if (BF16) {
-            const uint2 x = *reinterpret_cast<const uint2*>(W0B + (long long)row * H + col);
-            return make_float4(__builtin_bit_cast(float, x.x << 16), __builtin_bit_cast(float, x.x & 0xFFFF0000u),
-                               __builtin_bit_cast(float, x.y << 16), __builtin_bit_cast(float, x.y & 0xFFFF0000u));
-        }
-        return *reinterpret_cast<const float4*>(W0T + (long long)row * H + col);
-    };
-    if (BF16 && (H & 7) == 0 && ((H >= 512 && (H & 511) == 0) || (H >= 64 && 512 % H == 0))) {
-        // 16-byte loads (8 bf16 per lane): a 1-KB row needs all 64 lanes; narrower rows are shared out — lane group g takes the
-        // rows i = g (mod G) — and the groups' partial sums are combined by a fixed shuffle tree
-        const int lpr = H >= 512 ? 64 : H / 8;            // lanes per row
-        const int G = 64 / lpr, grp = lane / lpr, lc = lane - grp * lpr;
-        for (int col = lc * 8; col < H; col += 512) {
-            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            auto add8 = [&](const uint4& x) {
-                a[0] += __builtin_bit_cast(float, x.x << 16); a[1] += __builtin_bit_cast(float, x.x & 0xFFFF0000u);
-                a[2] += __builtin_bit_cast(float, x.y << 16); a[3] += __builtin_bit_cast(float, x.y & 0xFFFF0000u);
-                a[4] += __builtin_bit_cast(float, x.z << 16); a[5] += __builtin_bit_cast(float, x.z & 0xFFFF0000u);
-                a[6] += __builtin_bit_cast(float, x.w << 16); a[7] += __builtin_bit_cast(float, x.w & 0xFFFF0000u);
-            };
-            int i = grp;
-            for (; i + 3 * G < cnt; i += 4 * G) {
-                const uint4 x0 = *reinterpret_cast<const uint4*>(W0B + (long long)rows[wid][i] * H + col);
-                const uint4 x1 = *reinterpret_cast<const uint4*>(W0B + (long long)rows[wid][i + G] * H + col);
-                const uint4 x2 = *reinterpret_cast<const uint4*>(W0B + (long long)rows[wid][i + 2 * G] * H + col);
-                const uint4 x3 = *reinterpret_cast<const uint4*>(W0B + (long long)rows[wid][i + 3 * G] * H + col);
-                add8(x0); add8(x1); add8(x2); add8(x3);
-            }
-            for (; i < cnt; i += G) add8(*reinterpret_cast<const uint4*>(W0B + (long long)rows[wid][i] * H + col));
-            for (int off = lpr; off < 64; off <<= 1) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) a[k] += __shfl_xor(a[k], off, 64);
-            }
-            if (grp == 0) {
-                const float4 ba = *reinterpret_cast<const float4*>(b0 + col), bb = *reinterpret_cast<const float4*>(b0 + col + 4);
-                const float bias[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
-                uint16_t qv[8];
-                float tv[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { qv[k] = bf16_bits(tanh_fast(a[k] + bias[k])); tv[k] = bf16_to_float(qv[k]); }
-                *reinterpret_cast<uint4*>(out_bf + (long long)b * H + col) =
-                    make_uint4((uint32_t)qv[0] | ((uint32_t)qv[1] << 16), (uint32_t)qv[2] | ((uint32_t)qv[3] << 16),
-                               (uint32_t)qv[4] | ((uint32_t)qv[5] << 16), (uint32_t)qv[6] | ((uint32_t)qv[7] << 16));
-                if (out) {
-                    *reinterpret_cast<float4*>(out + (long long)b * H + col) = make_float4(tv[0], tv[1], tv[2], tv[3]);
-                    *reinterpret_cast<float4*>(out + (long long)b * H + col + 4) = make_float4(tv[4], tv[5], tv[6], tv[7]);
-                }
-                if (nd >= 0) {                          // the s' chain of the same sample, same net (xq_dqn_set_l0_derive), from these sums
-                    float a2[8];
-                    if (nd <= 8) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) a2[k] = a[k];
-                        auto acc8 = [&](const uint4& x, float sgn) {
-                            a2[0] += sgn * __builtin_bit_cast(float, x.x << 16); a2[1] += sgn * __builtin_bit_cast(float, x.x & 0xFFFF0000u);
-                            a2[2] += sgn * __builtin_bit_cast(float, x.y << 16); a2[3] += sgn * __builtin_bit_cast(float, x.y & 0xFFFF0000u);
-                            a2[4] += sgn * __builtin_bit_cast(float, x.z << 16); a2[5] += sgn * __builtin_bit_cast(float, x.z & 0xFFFF0000u);
-                            a2[6] += sgn * __builtin_bit_cast(float, x.w << 16); a2[7] += sgn * __builtin_bit_cast(float, x.w & 0xFFFF0000u);
-                        };
-                        for (int k = 0; k < nd; ++k) {     // wave-uniform
-                            const int ro = dpair[wid][k][0], ri = dpair[wid][k][1];
-                            if (ro >= 0) acc8(*reinterpret_cast<const uint4*>(W0B + (long long)ro * H + col), -1.f);
-                            if (ri >= 0) acc8(*reinterpret_cast<const uint4*>(W0B + (long long)ri * H + col), 1.f);
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) a2[k] = 0.f;
-                        for (int k = 0; k < cnt2; ++k) {
-                            const uint4 x = *reinterpret_cast<const uint4*>(W0B + (long long)rows2[wid][k] * H + col);
-                            a2[0] += __builtin_bit_cast(float, x.x << 16); a2[1] += __builtin_bit_cast(float, x.x & 0xFFFF0000u);
-                            a2[2] += __builtin_bit_cast(float, x.y << 16); a2[3] += __builtin_bit_cast(float, x.y & 0xFFFF0000u);
-                            a2[4] += __builtin_bit_cast(float, x.z << 16); a2[5] += __builtin_bit_cast(float, x.z & 0xFFFF0000u);
-                            a2[6] += __builtin_bit_cast(float, x.w << 16); a2[7] += __builtin_bit_cast(float, x.w & 0xFFFF0000u);
-                        }
-                    }
-                    uint16_t q2[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) q2[k] = bf16_bits(tanh_fast(a2[k] + bias[k]));
-                    *reinterpret_cast<uint4*>(J.out_bf[1] + (long long)b * H + col) =
-                        make_uint4((uint32_t)q2[0] | ((uint32_t)q2[1] << 16), (uint32_t)q2[2] | ((uint32_t)q2[3] << 16),
-                                   (uint32_t)q2[4] | ((uint32_t)q2[5] << 16), (uint32_t)q2[6] | ((uint32_t)q2[7] << 16));
-                    if (J.out[1]) {
-                        *reinterpret_cast<float4*>(J.out[1] + (long long)b * H + col) =
-                            make_float4(bf16_to_float(q2[0]), bf16_to_float(q2[1]), bf16_to_float(q2[2]), bf16_to_float(q2[3]));
-                        *reinterpret_cast<float4*>(J.out[1] + (long long)b * H + col + 4) =
-                            make_float4(bf16_to_float(q2[4]), bf16_to_float(q2[5]), bf16_to_float(q2[6]), bf16_to_float(q2[7]));
-                    }
-                }
-            }
-        }
-    } else if ((H & 3) == 0) {
-        for (int col = lane * 4; col < H; col += 256) {
-            float4 acc = *reinterpret_cast<const float4*>(b0 + col);
-            int i = 0;
-            for (; i + 4 <= cnt; i += 4) {
-                const float4 w0 = load4(rows[wid][i], col), w1 = load4(rows[wid][i + 1], col);
-                const float4 w2 = load4(rows[wid][i + 2], col), w3 = load4(rows[wid][i + 3], col);
-                acc.x = ((acc.x + w0.x) + w1.x) + w2.x + w3.x;
-                acc.y = ((acc.y + w0.y) + w1.y) + w2.y + w3.y;
-                acc.z = ((acc.z + w0.z) + w1.z) + w2.z + w3.z;
-                acc.w = ((acc.w + w0.w) + w1.w) + w2.w + w3.w;
-            }
-            for (; i < cnt; ++i) {
-                const float4 w = load4(rows[wid][i], col);
-                acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
-            }
-            float4 t = make_float4(tanhf(acc.x), tanhf(acc.y), tanhf(acc.z), tanhf(acc.w));
-            if (BF16) {
-                const uint16_t q0 = bf16_bits(t.x), q1 = bf16_bits(t.y), q2 = bf16_bits(t.z), q3 = bf16_bits(t.w);
-                *reinterpret_cast<uint2*>(out_bf + (long long)b * H + col) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
-                t = make_float4(bf16_to_float(q0), bf16_to_float(q1), bf16_to_float(q2), bf16_to_float(q3));
-            } else if (out_bf) {            // fp32 net: a bf16 COPY beside the exact activations (screening operand, one hidden layer)
-                const uint16_t q0 = bf16_bits(t.x), q1 = bf16_bits(t.y), q2 = bf16_bits(t.z), q3 = bf16_bits(t.w);
-                *reinterpret_cast<uint2*>(out_bf + (J.out_bf_frag ? scr_afrag_index(b, col, H) : (long long)b * H + col)) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
-            }
-            if (out) *reinterpret_cast<float4*>(out + (long long)b * H + col) = t;
-            if (!BF16 && nd >= 0) {                       // the s' chain of the same sample, same net
-                float4 a2;
-                if (nd <= 8) {
-                    a2 = acc;
-                    for (int k = 0; k < nd; ++k) {        // wave-uniform
-                        const int ro = dpair[wid][k][0], ri = dpair[wid][k][1];
-                        if (ro >= 0) { const float4 w = load4(ro, col); a2.x -= w.x; a2.y -= w.y; a2.z -= w.z; a2.w -= w.w; }
-                        if (ri >= 0) { const float4 w = load4(ri, col); a2.x += w.x; a2.y += w.y; a2.z += w.z; a2.w += w.w; }
-                    }
-                } else {
-                    a2 = *reinterpret_cast<const float4*>(b0 + col);
-                    for (int k = 0; k < cnt2; ++k) { const float4 w = load4(rows2[wid][k], col); a2.x += w.x; a2.y += w.y; a2.z += w.z; a2.w += w.w; }
-                }
-                const float4 t2 = make_float4(tanhf(a2.x), tanhf(a2.y), tanhf(a2.z), tanhf(a2.w));
-                if (J.out_bf[1]) {
-                    const uint16_t q0 = bf16_bits(t2.x), q1 = bf16_bits(t2.y), q2 = bf16_bits(t2.z), q3 = bf16_bits(t2.w);
-                    *reinterpret_cast<uint2*>(J.out_bf[1] + (J.out_bf_frag ? scr_afrag_index(b, col, H) : (long long)b * H + col)) =
-                        make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
-                }
-                if (J.out[1]) *reinterpret_cast<float4*>(J.out[1] + (long long)b * H + col) = t2;
-            }
-        }
-    } else {
-        for (int col = lane; col < H; col += 64) {
-            float acc = b0[col];
-            for (int i = 0; i < cnt; ++i)
-                acc += BF16 ? bf16_to_float(W0B[(long long)rows[wid][i] * H + col]) : W0T[(long long)rows[wid][i] * H + col];
-            float t = tanhf(acc);
-            if (BF16) { const uint16_t q = bf16_bits(t); out_bf[(long long)b * H + col] = q; t = bf16_to_float(q); }
-            if (out) out[(long long)b * H + col] = t;
-        }
-    }
-}
-
-// Layer 0 of the SELECT chain with its sums kept between plies (one wave per game, fp32): a_1 = tanh(z_1), z_1 = b_0 + sum of the rows of
-// the occupied squares.  derive != 0 and at most 8 squares differ from the board this game showed last time (a move changes two; a
-// game that ended shows the start position: dozens): z_1 = kept z_1 - rows of what stood on the changed squares + rows of what
-// stands there now, ascending square order — 4 row reads instead of ~25.  Otherwise the full sum in l0_forward_kernel's order.
-// Either way z_1 and the board are kept for the next ply.  The kept sums are only valid while W0 / b0 do not change (the host
-// drops them on every parameter update), i.e. across the plies of one update (bench --config 4: three of four plies).
-__global__ __launch_bounds__(256) void l0_select_kernel(const uint32_t* __restrict__ boards, uint32_t* __restrict__ prev_boards,
-                                                        const float* __restrict__ W0T, const float* __restrict__ b0, float* __restrict__ z1,
-                                                        float* __restrict__ out, int n, int H, int derive) {
-    __shared__ int rows[4][96];
-    __shared__ int dpair[4][8][2];
-    const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    const int b = (int)blockIdx.x * 4 + wid;
-    if (b >= n) return;
-    const uint32_t* bw = boards + (long long)b * kBoardWords;
-    uint32_t* pw = prev_boards + (long long)b * kBoardWords;
-    const int s0 = lane, s1 = 64 + lane;
-    const uint32_t n0 = (bw[s0 >> 3] >> (4 * (s0 & 7))) & 15u;
-    const uint32_t n1 = s1 < kSquares ? (bw[s1 >> 3] >> (4 * (s1 & 7))) & 15u : 0u;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    int nd = 99, cnt = 0;
-    if (derive) {
-        const uint32_t p0 = (pw[s0 >> 3] >> (4 * (s0 & 7))) & 15u;
-        const uint32_t p1 = s1 < kSquares ? (pw[s1 >> 3] >> (4 * (s1 & 7))) & 15u : 0u;
-        const unsigned long long d0 = __ballot(p0 != n0), d1 = __ballot(p1 != n1);
-        nd = __popcll(d0) + __popcll(d1);
-        if (nd <= 8) {
-            if (p0 != n0) { const int k = __popcll(d0 & below); dpair[wid][k][0] = p0 ? s0 * 14 + (int)p0 - 1 : -1; dpair[wid][k][1] = n0 ? s0 * 14 + (int)n0 - 1 : -1; }
-            if (p1 != n1) { const int k = __popcll(d0) + __popcll(d1 & below); dpair[wid][k][0] = p1 ? s1 * 14 + (int)p1 - 1 : -1; dpair[wid][k][1] = n1 ? s1 * 14 + (int)n1 - 1 : -1; }
-        }
-    }
-    if (nd > 8) {
-        const unsigned long long m0 = __ballot(n0 != 0), m1 = __ballot(n1 != 0);
-        const int c0 = __popcll(m0);
-        if (n0) rows[wid][__popcll(m0 & below)] = s0 * 14 + (int)n0 - 1;
-        if (n1) rows[wid][c0 + __popcll(m1 & below)] = s1 * 14 + (int)n1 - 1;
-        cnt = c0 + __popcll(m1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int col = lane * 4; col < H; col += 256) {
-        float4 acc;
-        if (nd <= 8) {
-            acc = *reinterpret_cast<const float4*>(z1 + (long long)b * H + col);
-            for (int k = 0; k < nd; ++k) {            // wave-uniform
-                const int ro = dpair[wid][k][0], ri = dpair[wid][k][1];
-                if (ro >= 0) { const float4 w = *reinterpret_cast<const float4*>(W0T + (long long)ro * H + col); acc.x -= w.x; acc.y -= w.y; acc.z -= w.z; acc.w -= w.w; }
-                if (ri >= 0) { const float4 w = *reinterpret_cast<const float4*>(W0T + (long long)ri * H + col); acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w; }
-            }
-        } else {
-            acc = *reinterpret_cast<const float4*>(b0 + col);
-            int i = 0;
-            for (; i + 4 <= cnt; i += 4) {
-                const float4 w0 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i] * H + col);
-                const float4 w1 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i + 1] * H + col);
-                const float4 w2 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i + 2] * H + col);
-                const float4 w3 = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i + 3] * H + col);
-                acc.x = ((acc.x + w0.x) + w1.x) + w2.x + w3.x;
-                acc.y = ((acc.y + w0.y) + w1.y) + w2.y + w3.y;
-                acc.z = ((acc.z + w0.z) + w1.z) + w2.z + w3.z;
-                acc.w = ((acc.w + w0.w) + w1.w) + w2.w + w3.w;
-            }
-            for (; i < cnt; ++i) {
-                const float4 w = *reinterpret_cast<const float4*>(W0T + (long long)rows[wid][i] * H + col);
-                acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
-            }
-        }
-        *reinterpret_cast<float4*>(z1 + (long long)b * H + col) = acc;
-        *reinterpret_cast<float4*>(out + (long long)b * H + col) = make_float4(tanhf(acc.x), tanhf(acc.y), tanhf(acc.z), tanhf(acc.w));
-    }
-    if (lane < kBoardWords) pw[lane] = bw[lane];
-}
-
-// block -> square: the squares of the start position first.  A block's run time grows with the number of samples that have a piece on
-// its square (a home square of the back rank: nearly all of them; a square in the middle of the board: a few per cent) and the grid
-// runs in two rounds of blocks (59 KB of LDS: two per CU) — the long blocks must be in the first round, or the kernel ends with a
-// few of them running alone (device timestamps in the training loop: 36.5 us from first block start to last block end with the
-// squares in board order, 28.1 us in this order; per block 1.5 us loads + 1.8 compaction + 6.9 streaming (mean) + 2.5 output)
-__constant__ unsigned char kL0SquareOrder[90] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 19, 25, 27, 29, 31, 33, 35, 54, 56, 58, 60, 62, 64, 70, 81, 82, 83, 84, 85, 86, 87, 88, 89, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 21, 22, 23, 24, 26, 28, 30, 32, 34, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 55, 57, 59, 61, 63, 65, 66, 67, 68, 69, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80};
-
-// Layer-0 weight gradient gW0^T[(sq,piece)][:] = sum over the samples that have `piece` on `sq` of delta_0[sample][:]
-// (the one-hot input of chessai.cpp:268-289 transposed).  A dense one-hot GEMM would spend 2*1260*H FLOP per sample on
-// zeros; here block (sq, chunk) compacts the samples of its chunk that occupy `sq` (ascending sample order, so the sums
-// are bitwise reproducible), then streams their delta rows (1 KB each, L2-resident) into 14 LDS accumulator rows.
-// partial[chunk][sq*14 + piece-1][H]; the ordered chunk reduction is the usual reduce_slabs_kernel.
-// Wide layers: blockIdx.z picks a slab of HS columns (grid z = H / HS) — at H = 512 one block per (square, chunk) could keep only two
-// accumulator sets in LDS (two of its four waves streaming, 265 us at 16384 x 512); two 256-column slabs are two blocks of the
-// H = 256 shape each (four sets, 2 blocks per CU).  Every slab compacts the chunk for itself (cheap) and streams its own columns.
-// (block body: `lin` = linear id of the block inside its column slab, nch = chunks, slab = column slab — gridDim (90, nch, H / HS) in
-// l0_grad_kernel; td_tail_kernel hands the same triple to its layer-0 blocks)
-__device__ __forceinline__ void l0_grad_block(const uint32_t* __restrict__ gboards, const float* __restrict__ delta0_all,
-                                              int n, int Hfull, int HS, int chunk, int nsets, float* __restrict__ partial_all,
-                                              int lin, int nch, int slab, float* __restrict__ smem) {
-    const int H = HS;                                   // width this block works on; rows of delta0 / partial are Hfull apart
-    const float* __restrict__ delta0 = delta0_all + (long long)slab * HS;
-    float* __restrict__ partial = partial_all + (long long)slab * HS;
-    float* acc = smem;                                  // [nsets][14][H]
-    uint16_t* list = reinterpret_cast<uint16_t*>(smem + (long long)nsets * 14 * H);   // [chunk] (b_local | piece << 11)
-    // workgroups go to the 8 XCDs round-robin in linear order: chunk = linear id mod nchunks keeps all 90 square-blocks of a chunk
-    // (they stream the same 1 MB of delta rows, each up to 32 times) behind one XCD's L2 when there are 8 chunks
-    const int s = kL0SquareOrder[lin / nch];
-    const int c0 = (lin % nch) * chunk;
-    const int c1 = min(n, c0 + chunk);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    // the chunk's piece codes first (up to 8 independent loads per thread in flight), accumulator zeroing under their latency
-    constexpr int kMaxIters = 8;                         // chunk <= 2048
-    uint32_t nibs = 0;
-#pragma unroll
-    for (int it = 0; it < kMaxIters; ++it) {
-        const int b = c0 + it * 256 + tid;
-        // (unconditional, clamped: a predicated load compiles to a branch with its own wait, one memory round trip per load)
-        uint32_t nib = (gboards[(long long)min(b, c1 - 1) * kBoardWords + (s >> 3)] >> (4 * (s & 7))) & 15u;
-        if (b >= c1) nib = 0;
-        nibs |= nib << (4 * it);
-    }
-    if (((nsets * 14 * H) & 3) == 0) {
-        float4* a4 = reinterpret_cast<float4*>(acc);
-        for (int i = tid; i < nsets * 14 * H / 4; i += 256) a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-        for (int i = tid; i < nsets * 14 * H; i += 256) acc[i] = 0.f;
-    }
-    // phase 1: ordered compaction of the occupied samples with two barriers in all: the per-wave counts of every round are
-    // published first, the offsets are then prefix sums over (round, wave) that every thread computes for itself
-    __shared__ int wc[kMaxIters][4];
-    const int iters = (c1 - c0 + 255) / 256;
-#pragma unroll
-    for (int it = 0; it < kMaxIters; ++it) {
-        const uint32_t nib = (nibs >> (4 * it)) & 15u;
-        const unsigned long long m = __ballot(nib != 0);
-        if (lane == 0) wc[it][wid] = __popcll(m);
-    }
-    __syncthreads();
-    int off = 0;
-#pragma unroll
-    for (int it = 0; it < kMaxIters; ++it) {
-        if (it < iters) {
-            const uint32_t nib = (nibs >> (4 * it)) & 15u;
-            const unsigned long long m = __ballot(nib != 0);
-            int o = off;
-            for (int w = 0; w < wid; ++w) o += wc[it][w];
-            if (nib) list[o + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((it * 256 + tid) | (nib << 11));
-        }
-        off += wc[it][0] + wc[it][1] + wc[it][2] + wc[it][3];
-    }
-    __syncthreads();
-    const int cnt = off;
-    // phase 2: wave w streams list entries w, w+nsets, ... (whole 1-KB rows as float4 per lane, 16 rows in flight per
-    // wave) into ITS OWN accumulator set; the sets are added in fixed order afterwards => bitwise reproducible
-    if (wid < nsets && (H & 3) == 0) {
-        float* my = acc + (long long)wid * 14 * H;
-        for (int col = lane * 4; col < H; col += 256) {
-            // rows of the same piece arrive in runs (a square mostly holds one or two piece kinds): a run is summed in
-            // registers and touches its LDS accumulator once, instead of one read-modify-write round trip per row
-            int cur = 0;                                   // piece code of the open run (wave-uniform), 0 = none
-            float rx = 0.f, ry = 0.f, rz = 0.f, rw = 0.f;
-            auto flush = [&]() {
-                if (cur != 0) {
-                    float4* a = reinterpret_cast<float4*>(my + (cur - 1) * H + col);
-                    float4 t = *a;
-                    t.x += rx; t.y += ry; t.z += rz; t.w += rw;
-                    *a = t;
-                }
-            };
-            int i = wid;
-            for (; i + 15 * nsets < cnt; i += 16 * nsets) {
-                int e[16];
-                float4 v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    e[u] = list[i + u * nsets];
-                    const float4 x = *reinterpret_cast<const float4*>(delta0 + (long long)(c0 + (e[u] & 2047)) * Hfull + col);
-                    v[u].x = x.x; v[u].y = x.y; v[u].z = x.z; v[u].w = x.w;
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int p = __builtin_amdgcn_readfirstlane(e[u] >> 11);
-                    if (p != cur) { flush(); cur = p; rx = v[u].x; ry = v[u].y; rz = v[u].z; rw = v[u].w; }
-                    else { rx += v[u].x; ry += v[u].y; rz += v[u].z; rw += v[u].w; }
-                }
-            }
-            for (; i < cnt; i += nsets) {
-                const int e1 = list[i];
-                const float4 x = *reinterpret_cast<const float4*>(delta0 + (long long)(c0 + (e1 & 2047)) * Hfull + col);
-                const int p = __builtin_amdgcn_readfirstlane(e1 >> 11);
-                if (p != cur) { flush(); cur = p; rx = x.x; ry = x.y; rz = x.z; rw = x.w; }
-                else { rx += x.x; ry += x.y; rz += x.z; rw += x.w; }
-            }
-            flush();
-        }
-    } else if ((H & 3) != 0 && wid == 0) {
-        for (int col = lane; col < H; col += 64)
-            for (int i = 0; i < cnt; ++i) {
-                const int e1 = list[i];
-                acc[((e1 >> 11) - 1) * H + col] += delta0[(long long)(c0 + (e1 & 2047)) * Hfull + col];
-            }
-    }
-    __syncthreads();
-    float* out = partial + ((long long)(lin % nch) * kStateSize + (long long)s * 14) * Hfull;
-    const int used = (H & 3) == 0 ? nsets : 1;
-    for (int i = tid; i < 14 * H; i += 256) {
-        float t = acc[i];
-        for (int w = 1; w < used; ++w) t += acc[(long long)w * 14 * H + i];
-        out[(long long)(i / H) * Hfull + (i % H)] = t;
-    }
-}
-__global__ __launch_bounds__(256) void l0_grad_kernel(const uint32_t* __restrict__ gboards, const float* __restrict__ delta0_all,
-                                                      int n, int Hfull, int HS, int chunk, int nsets, float* __restrict__ partial_all) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    l0_grad_block(gboards, delta0_all, n, Hfull, HS, chunk, nsets, partial_all, (int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.y,
-                  (int)blockIdx.z, smem);
-}
-
-// zmax[b] = max over the column-max GEMM's partial rows t of partial[t][b] (and, for Double DQN, the row index that came with
-// the first maximum).  The partials are [n_partial][n]: a block takes 64 consecutive samples so that every wave-instruction reads
-// 256 contiguous bytes of one partial row (td_delta_kernel's one-wave-per-sample walk touched a cache line per value); wave w
-// folds rows w, w+4, ... with 8 independent loads in flight, the four waves combine through LDS.
-// blockIdx.y = one of kReduceParts contiguous ranges of partial rows (4x the blocks in flight: the kernel is pure latency);
-// zmax / zidx are [kReduceParts][n], td_delta_kernel folds the last kReduceParts values of its sample itself.
-enum { kReduceParts = 4 };
-__global__ __launch_bounds__(256) void colmax_reduce_kernel(const float* __restrict__ partial_all, const int* __restrict__ partial_idx_all,
-                                                            int n_partial_all, int n, long long ld, float* __restrict__ zmax_all,
-                                                            int* __restrict__ zidx_all) {
-    const int per = (n_partial_all + kReduceParts - 1) / kReduceParts;
-    const int t0 = (int)blockIdx.y * per;
-    const int n_partial = max(0, min(per, n_partial_all - t0));
-    const float* partial = partial_all + (long long)t0 * ld;          // rows of the partial arrays are `ld` apart (>= n)
-    const int* partial_idx = partial_idx_all ? partial_idx_all + (long long)t0 * ld : nullptr;
-    float* zmax = zmax_all + (long long)blockIdx.y * n;
-    int* zidx = zidx_all + (long long)blockIdx.y * n;
-    __shared__ float sv[4][64];
-    __shared__ int si[4][64];
-    const int lane = (int)(threadIdx.x & 63), wid = (int)(threadIdx.x >> 6);
-    const int b = (int)blockIdx.x * 64 + lane;
-    const bool ok = b < n;
-    float m = -__builtin_inff();
-    int mi = 0x7fffffff;
-    const bool arg = partial_idx != nullptr;
-    int t = wid;
-    for (; t + 28 < n_partial; t += 32) {
-        float v[8];
-        int vi[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            v[u] = ok ? partial[(long long)(t + 4 * u) * ld + b] : -__builtin_inff();
-            vi[u] = (ok && arg) ? partial_idx[(long long)(t + 4 * u) * ld + b] : 0x7fffffff;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (arg) { if (v[u] > m || (v[u] == m && vi[u] < mi)) { m = v[u]; mi = vi[u]; } }
-            else m = fmaxf(m, v[u]);
-        }
-    }
-    for (; t < n_partial; t += 4) {
-        const float v = ok ? partial[(long long)t * ld + b] : -__builtin_inff();
-        const int vi = (ok && arg) ? partial_idx[(long long)t * ld + b] : 0x7fffffff;
-        if (arg) { if (v > m || (v == m && vi < mi)) { m = v; mi = vi; } }
-        else m = fmaxf(m, v);
-    }
-    sv[wid][lane] = m; si[wid][lane] = mi;
-    __syncthreads();
-    if (wid == 0 && ok) {
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const float v = sv[w][lane];
-            const int vi = si[w][lane];
-            if (arg) { if (v > m || (v == m && vi < mi)) { m = v; mi = vi; } }
-            else m = fmaxf(m, v);
-        }
-        zmax[b] = m;
-        if (arg) zidx[b] = mi;
-    }
-}
-
-// What the generalised TD step (BASELINE configs[4], build-defined) adds to td_delta_kernel; all optional.
-struct TdExtra {
-    const int* partial_idx;        // Double DQN: row index of the maximum of every sample (first maximum), reduced
-    const float* wout_t; const uint16_t* wout_t_bf; const float* bout_t;   // target net's output layer (fp32 master / bf16 shadow)
-    const float* alast_t; const uint16_t* alast_t_bf;                      // a_last(s') of the target net (fp32 / bf16 bits)
-    const uint16_t* wout_bf;       // bf16 Q-net: shadow of the online output layer for Q(s,a)
-    const float* is_w; const float* is_wmax;     // prioritized replay: raw importance weights [n] and their batch maximum
-    float* prio; unsigned* pmax_live;            // prioritized replay: priority table (by ring slot) and the running maximum (float bits)
-    float per_eps, per_alpha;
-    int double_dqn, nout;
-    uint16_t* dtop_bf;             // XQ_PRECISION_BF16_FULL: the top hidden delta rounded to bf16 beside the fp32 one
-};
-
-// TD target, output delta and the TOP hidden delta for one sample per wave (chessai.cpp:122-128 +
-// outputLayerDeltaKernel dqn.cu:288-295 + hiddenLayerDeltaKernel dqn.cu:297-308 for the last hidden layer).
-// The output delta of a TD step has ONE non-zero entry per sample (column action.to), so the last hidden layer's delta
-// is a scaled row of the weight view — no GEMM:  dtop[b][i] = delta_b * View[a_b][i] * (1 - a_last[b][i]^2), where
-// View[a][i] = view[a*view_ld + i] is the as-written (reference mode: a < view_kmax = width of the last hidden layer,
-// stride = width of the layer below) or the textbook (row a of W_out) operand.  Also emits, per sample, the scalar
-// delta and the action (gathered through `slots`) for the segmented output-layer gradient.
-// Double DQN: the partials carry (max z_online(s'), its row a*); y = r + gamma * tanh(W_out_target[a*] . a_last_target(s') + b).
-// Prioritized replay: delta is scaled by w_b / max w, and (|Q(s,a) - y| + eps)^alpha goes back into the priority table.
-__global__ __launch_bounds__(256) void td_delta_kernel(int n, SlotSrc src,
-                                                       const int32_t* __restrict__ action_to, const float* __restrict__ reward,
-                                                       const uint8_t* __restrict__ done, const float* __restrict__ a_last, int H,
-                                                       const float* __restrict__ w_out, const float* __restrict__ b_out,
-                                                       const float* __restrict__ partial, int n_partial, float gamma,
-                                                       const float* __restrict__ view, long long view_ld, int view_kmax,
-                                                       float* __restrict__ dtop, float* __restrict__ dsc, int32_t* __restrict__ act,
-                                                       float* __restrict__ qsa, float* __restrict__ yv, float* __restrict__ lossv,
-                                                       TdExtra X) {
-    const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    const int b = (int)blockIdx.x * 4 + wid;
-    if (b >= n) return;
-    const int s = slot_of(src, b);
-    const int a = action_to[s];
-    const bool live = a >= 0 && a < 96;
-    float delta = 0.f, q = 0.f, y = 0.f;
-    const float* ar = a_last + (long long)b * H;
-    if (H == 256 && !X.wout_bf && !X.double_dqn && n_partial <= 4) {
-        // fp32 net, 256-wide last hidden layer, no arg-max: every load that depends only on (b, s, a) is
-        // issued up front as one 16-byte load per lane — the general path below is a chain of five dependent memory round trips
-        const int ac = live ? a : 0;
-        const float4 av = *reinterpret_cast<const float4*>(ar + lane * 4);
-        const float4 wv = *reinterpret_cast<const float4*>(w_out + (long long)ac * 256 + lane * 4);
-        const bool has_view = live && a < view_kmax;
-        const float4 vv = has_view ? *reinterpret_cast<const float4*>(view + (long long)a * view_ld + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float zm = partial[b];                         // the (up to kReduceParts) maxima left per sample
-#pragma unroll
-        for (int t = 1; t < 4; ++t) zm = fmaxf(zm, partial[(long long)min(t, n_partial - 1) * n + b]);
-        const float bo = b_out[ac], r = reward[s];
-        const bool dn = done[s] != 0;
-        const float isw = X.is_w ? X.is_w[b] / X.is_wmax[0] : 1.f;
-        float z = (av.x * wv.x + av.y * wv.y) + (av.z * wv.z + av.w * wv.w);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
-        if (live) {
-            q = tanhf(z + bo);
-            y = dn ? r : r + gamma * tanhf(zm);
-            delta = (q - y) * (1.f - q * q) * isw;
-        }
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has_view) {
-            o.x = delta * vv.x * (1.f - av.x * av.x); o.y = delta * vv.y * (1.f - av.y * av.y);
-            o.z = delta * vv.z * (1.f - av.z * av.z); o.w = delta * vv.w * (1.f - av.w * av.w);
-        }
-        *reinterpret_cast<float4*>(dtop + (long long)b * 256 + lane * 4) = o;
-    } else if (H == 512 && !X.wout_bf && !X.double_dqn && n_partial <= 4) {
-        // fp32 net, 512-wide last hidden layer (BASELINE configs[3]): the 256-wide path with two 16-byte pieces per lane and row
-        // (columns 4 lane + 256 v); per-lane partial = piece 0 + piece 1, then the same shuffle tree
-        const int ac = live ? a : 0;
-        const bool has_view = live && a < view_kmax;
-        float4 av[2], wv[2], vv[2];
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            av[v] = *reinterpret_cast<const float4*>(ar + v * 256 + lane * 4);
-            wv[v] = *reinterpret_cast<const float4*>(w_out + (long long)ac * 512 + v * 256 + lane * 4);
-            vv[v] = has_view ? *reinterpret_cast<const float4*>(view + (long long)a * view_ld + v * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float zm = partial[b];
-#pragma unroll
-        for (int t = 1; t < 4; ++t) zm = fmaxf(zm, partial[(long long)min(t, n_partial - 1) * n + b]);
-        const float bo = b_out[ac], r = reward[s];
-        const bool dn = done[s] != 0;
-        const float isw = X.is_w ? X.is_w[b] / X.is_wmax[0] : 1.f;
-        float z = ((av[0].x * wv[0].x + av[0].y * wv[0].y) + (av[0].z * wv[0].z + av[0].w * wv[0].w)) +
-                  ((av[1].x * wv[1].x + av[1].y * wv[1].y) + (av[1].z * wv[1].z + av[1].w * wv[1].w));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
-        if (live) {
-            q = tanhf(z + bo);
-            y = dn ? r : r + gamma * tanhf(zm);
-            delta = (q - y) * (1.f - q * q) * isw;
-        }
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (has_view) {
-                o.x = delta * vv[v].x * (1.f - av[v].x * av[v].x); o.y = delta * vv[v].y * (1.f - av[v].y * av[v].y);
-                o.z = delta * vv[v].z * (1.f - av[v].z * av[v].z); o.w = delta * vv[v].w * (1.f - av[v].w * av[v].w);
-            }
-            *reinterpret_cast<float4*>(dtop + (long long)b * 512 + v * 256 + lane * 4) = o;
-        }
-    } else if (H == 512 && X.wout_bf && n_partial <= 4 && (!X.double_dqn || X.wout_t_bf)) {
-        // bf16 net, 512-wide last hidden layer (BASELINE configs[4]): the same idea — every load that depends only on (b, s, a) issued up
-        // front, 8 columns per lane as 16-byte loads; Double DQN adds ONE dependent round trip (the target net's row of the arg-max)
-        const int ac = live ? a : 0;
-        const float* arp = ar + lane * 8;
-        const float4 av0 = *reinterpret_cast<const float4*>(arp), av1 = *reinterpret_cast<const float4*>(arp + 4);
-        const uint4 wq = *reinterpret_cast<const uint4*>(X.wout_bf + (long long)ac * 512 + lane * 8);
-        const bool has_view = live && a < view_kmax;
-        const float* vp = view + (long long)(has_view ? a : 0) * view_ld + lane * 8;
-        float4 vv0 = *reinterpret_cast<const float4*>(vp), vv1 = *reinterpret_cast<const float4*>(vp + 4);
-        float pm[4]; int pi[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            pm[t] = partial[(long long)min(t, n_partial - 1) * n + b];
-            pi[t] = X.double_dqn ? X.partial_idx[(long long)min(t, n_partial - 1) * n + b] : 0;
-        }
-        uint4 atq = make_uint4(0u, 0u, 0u, 0u);
-        if (X.double_dqn) atq = *reinterpret_cast<const uint4*>(X.alast_t_bf + (long long)b * 512 + lane * 8);
-        const float bo = b_out[ac], r = reward[s];
-        const bool dn = done[s] != 0;
-        const float isw = X.is_w ? X.is_w[b] / X.is_wmax[0] : 1.f;
-        auto lo = [](uint32_t x) { return __builtin_bit_cast(float, x << 16); };
-        auto hi = [](uint32_t x) { return __builtin_bit_cast(float, x & 0xFFFF0000u); };
-        float z = ((av0.x * lo(wq.x) + av0.y * hi(wq.x)) + (av0.z * lo(wq.y) + av0.w * hi(wq.y))) +
-                  ((av1.x * lo(wq.z) + av1.y * hi(wq.z)) + (av1.z * lo(wq.w) + av1.w * hi(wq.w)));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
-        float zm = pm[0]; int zi = pi[0];
-#pragma unroll
-        for (int t = 1; t < 4; ++t) {
-            if (X.double_dqn) { if (pm[t] > zm || (pm[t] == zm && pi[t] < zi)) { zm = pm[t]; zi = pi[t]; } }
-            else zm = fmaxf(zm, pm[t]);
-        }
-        if (X.double_dqn) {          // value of the online net's greedy action on the TARGET net
-            const int astar = (zi >= 0 && zi < X.nout) ? zi : 0;
-            const uint4 tq = *reinterpret_cast<const uint4*>(X.wout_t_bf + (long long)astar * 512 + lane * 8);
-            float zt = ((lo(atq.x) * lo(tq.x) + hi(atq.x) * hi(tq.x)) + (lo(atq.y) * lo(tq.y) + hi(atq.y) * hi(tq.y))) +
-                       ((lo(atq.z) * lo(tq.z) + hi(atq.z) * hi(tq.z)) + (lo(atq.w) * lo(tq.w) + hi(atq.w) * hi(tq.w)));
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) zt += __shfl_xor(zt, off, 64);
-            zm = zt + X.bout_t[astar];
-        }
-        if (live) {
-            q = tanhf(z + bo);
-            y = dn ? r : r + gamma * tanhf(zm);
-            delta = (q - y) * (1.f - q * q) * isw;
-        }
-        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (has_view) {
-            o[0] = delta * vv0.x * (1.f - av0.x * av0.x); o[1] = delta * vv0.y * (1.f - av0.y * av0.y);
-            o[2] = delta * vv0.z * (1.f - av0.z * av0.z); o[3] = delta * vv0.w * (1.f - av0.w * av0.w);
-            o[4] = delta * vv1.x * (1.f - av1.x * av1.x); o[5] = delta * vv1.y * (1.f - av1.y * av1.y);
-            o[6] = delta * vv1.z * (1.f - av1.z * av1.z); o[7] = delta * vv1.w * (1.f - av1.w * av1.w);
-        }
-        float* dp = dtop + (long long)b * 512 + lane * 8;
-        *reinterpret_cast<float4*>(dp) = make_float4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<float4*>(dp + 4) = make_float4(o[4], o[5], o[6], o[7]);
-        if (X.dtop_bf)
-            *reinterpret_cast<uint4*>(X.dtop_bf + (long long)b * 512 + lane * 8) =
-                make_uint4((uint32_t)bf16_bits(o[0]) | ((uint32_t)bf16_bits(o[1]) << 16), (uint32_t)bf16_bits(o[2]) | ((uint32_t)bf16_bits(o[3]) << 16),
-                           (uint32_t)bf16_bits(o[4]) | ((uint32_t)bf16_bits(o[5]) << 16), (uint32_t)bf16_bits(o[6]) | ((uint32_t)bf16_bits(o[7]) << 16));
-    } else {
-    if (live) {
-        float z = 0.f;
-        if (X.wout_bf) { const uint16_t* wr = X.wout_bf + (long long)a * H; for (int i = lane; i < H; i += 64) z += bf16_to_float(wr[i]) * ar[i]; }
-        else { const float* wr = w_out + (long long)a * H; for (int i = lane; i < H; i += 64) z += wr[i] * ar[i]; }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
-        z += b_out[a];
-        float zm = partial[b];                         // max_k z_k(s'): the kReduceParts values colmax_reduce_kernel left per sample
-        int zi = X.double_dqn ? X.partial_idx[b] : 0;
-        for (int t = 1; t < n_partial; ++t) {
-            const float v = partial[(long long)t * n + b];
-            if (X.double_dqn) {
-                const int vi = X.partial_idx[(long long)t * n + b];
-                if (v > zm || (v == zm && vi < zi)) { zm = v; zi = vi; }
-            } else zm = fmaxf(zm, v);
-        }
-        if (X.double_dqn) {          // value of the online net's greedy action on the TARGET net
-            const int astar = (zi >= 0 && zi < X.nout) ? zi : 0;
-            float zt = 0.f;
-            for (int i = lane; i < H; i += 64) {
-                const float wv = X.wout_t_bf ? bf16_to_float(X.wout_t_bf[(long long)astar * H + i]) : X.wout_t[(long long)astar * H + i];
-                const float av = X.alast_t_bf ? bf16_to_float(X.alast_t_bf[(long long)b * H + i]) : X.alast_t[(long long)b * H + i];
-                zt += wv * av;
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) zt += __shfl_xor(zt, off, 64);
-            zm = zt + X.bout_t[astar];
-        }
-        q = tanhf(z);
-        const float r = reward[s];
-        y = done[s] ? r : r + gamma * tanhf(zm);       // max_k tanh(z_k) = tanh(max_k z_k)
-        delta = (q - y) * (1.f - q * q);               // (a - target) * (1 - tanh(z)^2)
-        if (X.is_w) delta *= X.is_w[b] / X.is_wmax[0];
-    }
-    float* drow = dtop + (long long)b * H;
-    if (live && a < view_kmax) {
-        const float* vr = view + (long long)a * view_ld;
-        for (int i = lane; i < H; i += 64) {
-            const float h = ar[i];
-            const float v = delta * vr[i] * (1.f - h * h);
-            drow[i] = v;
-            if (X.dtop_bf) X.dtop_bf[(long long)b * H + i] = bf16_bits(v);
-        }
-    } else {
-        for (int i = lane; i < H; i += 64) { drow[i] = 0.f; if (X.dtop_bf) X.dtop_bf[(long long)b * H + i] = 0; }
-    }
-    }
-    if (lane == 0) {
-        dsc[b] = delta;
-        act[b] = live ? a : -1;
-        qsa[b] = q; yv[b] = y;
-        lossv[b] = live ? 0.5f * (q - y) * (q - y) : 0.f;
-        if (X.prio && live) {
-            const float p = powf(fabsf(q - y) + X.per_eps, X.per_alpha);
-            X.prio[s] = p;
-            // the running maximum rarely moves once training is under way: test first, so that 16 K waves do not queue on one address
-            // (positive floats order like their bit patterns; a maximum is order-independent, hence still deterministic)
-            if (__float_as_uint(p) > __hip_atomic_load(X.pmax_live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMax(X.pmax_live, __float_as_uint(p));
-        }
-    }
-}
-
-// Output-layer gradient of a TD minibatch: gW_out[j][:] = sum over the samples with action.to == j of delta_b * a_last[b][:]
-// and gb_out[j] = sum of delta_b (j < 96).  Segmented sums instead of a [96 x B] x [B x H] product: every sample's
-// activation row is read exactly once.  Block (group of 4 actions, chunk of samples): ordered compaction of the chunk's
-// samples whose action falls in the group, then the rows are streamed into per-wave LDS accumulators (combined in fixed
-// order => bitwise reproducible).  partial[chunk][96*H + 96] (weights, then biases).
-__device__ __forceinline__ void out_grad_block(const int32_t* __restrict__ act, const float* __restrict__ dsc,
-                                               const float* __restrict__ a_last, int n, int H, int chunk,
-                                               float* __restrict__ partial, int g /* actions 4g .. 4g+3 */, int chunk_id, float* __restrict__ smem) {
-    float* acc = smem;                                  // [4 waves][4 actions][H]
-    uint16_t* list = reinterpret_cast<uint16_t*>(smem + 16 * H);   // [chunk] (b_local | class << 11)
-    __shared__ int total;
-    __shared__ float bsum[4][4];
-    const int c0 = chunk_id * chunk, c1 = min(n, c0 + chunk);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    // the chunk's actions first (all loads of a thread in flight together), accumulator zeroing under their latency; then the
-    // ordered compaction with two barriers in all: per-wave counts of every round published first, offsets = prefix sums over
-    // (round, wave) that every thread computes for itself
-    constexpr int kMaxIters = 8;                         // chunk <= 2048
-    __shared__ int wc[kMaxIters][4];
-    int clsv[kMaxIters];
-#pragma unroll
-    for (int it = 0; it < kMaxIters; ++it) {
-        const int b = c0 + it * 256 + tid;
-        const int a = act[min(b, c1 - 1)];                // unconditional, clamped (see l0_grad_kernel)
-        clsv[it] = (b < c1 && a >= 4 * g && a < 4 * g + 4) ? a - 4 * g : -1;
-    }
-    for (int i = tid; i < 16 * H; i += 256) acc[i] = 0.f;
-#pragma unroll
-    for (int it = 0; it < kMaxIters; ++it) {
-        const unsigned long long m = __ballot(clsv[it] >= 0);
-        if (lane == 0) wc[it][wid] = __popcll(m);
-    }
-    __syncthreads();
-    {
-        const int iters = (c1 - c0 + 255) / 256;
-        int off = 0;
-#pragma unroll
-        for (int it = 0; it < kMaxIters; ++it) {
-            if (it < iters) {
-                const unsigned long long m = __ballot(clsv[it] >= 0);
-                int o = off;
-                for (int w = 0; w < wid; ++w) o += wc[it][w];
-                if (clsv[it] >= 0) list[o + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((it * 256 + tid) | (clsv[it] << 11));
-            }
-            off += wc[it][0] + wc[it][1] + wc[it][2] + wc[it][3];
-        }
-        if (tid == 0) total = off;
-    }
-    __syncthreads();
-    const int cnt = total;
-    float* my = acc + (long long)wid * 4 * H;
-    float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
-    // wave w takes entries w, w+4, ... (fixed assignment), 8 rows in flight
-    int i = wid;
-    for (; i + 28 < cnt; i += 32) {
-        int bb[8], cl[8];
-        float dl[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = list[i + 4 * u];
-            bb[u] = c0 + (e & 2047); cl[u] = e >> 11;
-            dl[u] = dsc[bb[u]];
-        }
-        for (int col = lane * 4; col < H; col += 256) {
-            float4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float4 x = *reinterpret_cast<const float4*>(a_last + (long long)bb[u] * H + col);
-                v[u].x = x.x; v[u].y = x.y; v[u].z = x.z; v[u].w = x.w;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                float4* a = reinterpret_cast<float4*>(my + cl[u] * H + col);
-                float4 t = *a;
-                t.x += dl[u] * v[u].x; t.y += dl[u] * v[u].y; t.z += dl[u] * v[u].z; t.w += dl[u] * v[u].w;
-                *a = t;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (cl[u] == 0) bs0 += dl[u]; else if (cl[u] == 1) bs1 += dl[u]; else if (cl[u] == 2) bs2 += dl[u]; else bs3 += dl[u];
-        }
-    }
-    for (; i < cnt; i += 4) {
-        const int e = list[i];
-        const int b = c0 + (e & 2047), cls = e >> 11;
-        const float d1 = dsc[b];
-        if (cls == 0) bs0 += d1; else if (cls == 1) bs1 += d1; else if (cls == 2) bs2 += d1; else bs3 += d1;
-        for (int col = lane * 4; col < H; col += 256) {
-            const float4 x = *reinterpret_cast<const float4*>(a_last + (long long)b * H + col);
-            float4* a = reinterpret_cast<float4*>(my + cls * H + col);
-            float4 t = *a;
-            t.x += d1 * x.x; t.y += d1 * x.y; t.z += d1 * x.z; t.w += d1 * x.w;
-            *a = t;
-        }
-    }
-    if (lane == 0) { bsum[wid][0] = bs0; bsum[wid][1] = bs1; bsum[wid][2] = bs2; bsum[wid][3] = bs3; }
-    __syncthreads();
-    float* out = partial + (long long)chunk_id * (96LL * H + 96);
-    for (int i = tid; i < 4 * H; i += 256)
-        out[(long long)4 * g * H + i] = ((acc[i] + acc[4 * H + i]) + acc[8 * H + i]) + acc[12 * H + i];
-    if (tid < 4) out[96LL * H + 4 * g + tid] = ((bsum[0][tid] + bsum[1][tid]) + bsum[2][tid]) + bsum[3][tid];
-}
-__global__ __launch_bounds__(256) void out_grad_kernel(const int32_t* __restrict__ act, const float* __restrict__ dsc,
-                                                       const float* __restrict__ a_last, int n, int H, int chunk,
-                                                       float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    out_grad_block(act, dsc, a_last, n, H, chunk, partial, (int)blockIdx.x, (int)blockIdx.y, smem);
-}
-
-// dense output delta (general DQN::backpropagate target): d = (q - t) * (1 - q^2)
-__global__ void out_delta_dense_kernel(const float* __restrict__ q, const float* __restrict__ t, long long total, float* __restrict__ d) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const float a = q[i];
-        d[i] = (a - t[i]) * (1.f - a * a);
-    }
-}
-
-// Bias gradients = column sums of the delta matrices.  All layers of one TD step go through ONE launch (job table)
-// of partial sums over row chunks, then ONE ordered reduction launch (deterministic, no atomics).
-struct ColsumJobs {
-    const float* X[XQ_MAX_LAYERS + 1];
-    long long ld[XQ_MAX_LAYERS + 1];
-    int C[XQ_MAX_LAYERS + 1];
-    float* dst[XQ_MAX_LAYERS + 1];
-    long long poff[XQ_MAX_LAYERS + 1];   // first column of the job in the workspace
-    int njobs, n, rows_per, R;
-    float* work;                         // [R][wld]: row y = the sums over row chunk y, the jobs side by side — for the TD step in the
-    long long wld;                       // order of the hidden biases, so that the SGD kernel can take the R rows as slabs (fused_apply)
-};
-__device__ __forceinline__ void colsum_partial_block(const ColsumJobs& J, int bx, int by, int job) {
-    __shared__ float red[4][64];
-    const int C = J.C[job];
-    const int tx = (int)(threadIdx.x & 63), ty = (int)(threadIdx.x >> 6);
-    const int c = bx * 64 + tx;
-    if (bx * 64 >= C) return;
-    const float* X = J.X[job];
-    const long long ld = J.ld[job];
-    const int r0 = by * J.rows_per, r1 = min(J.n, r0 + J.rows_per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (c < C) {
-        int r = r0 + ty;
-        for (; r + 12 < r1; r += 16) {
-            s0 += X[(long long)r * ld + c];
-            s1 += X[(long long)(r + 4) * ld + c];
-            s2 += X[(long long)(r + 8) * ld + c];
-            s3 += X[(long long)(r + 12) * ld + c];
-        }
-        for (; r < r1; r += 4) s0 += X[(long long)r * ld + c];
-    }
-    red[ty][tx] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (ty == 0 && c < C)
-        J.work[J.poff[job] + (long long)by * J.wld + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-}
-__global__ __launch_bounds__(256) void colsum_partial_kernel(ColsumJobs J) {
-    colsum_partial_block(J, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
-}
-__global__ __launch_bounds__(256) void colsum_final_kernel(ColsumJobs J) {   // 64 columns x 4 partial lanes per block
-    __shared__ float red[4][64];
-    const int job = (int)blockIdx.y;
-    const int C = J.C[job];
-    const int tx = (int)(threadIdx.x & 63), ty = (int)(threadIdx.x >> 6);
-    const int c = (int)blockIdx.x * 64 + tx;
-    if ((int)blockIdx.x * 64 >= C) return;
-    // the order of reduce_slabs_kernel / sgd_segments_kernel (four chains z = j, j + 4, ..; ((s0 + s1) + (s2 + s3))): the SGD kernel may
-    // sum the rows itself (fused_apply) with the same bits
-    float s0 = 0.f;
-    if (c < C) {
-        const float* p = J.work + J.poff[job] + c;
-        const int R4 = J.R & ~3;
-        for (int z = ty; z < R4; z += 4) s0 += p[(long long)z * J.wld];
-        if (ty == 0) for (int z = R4; z < J.R; ++z) s0 += p[(long long)z * J.wld];     // the leftover rows continue chain 0, as there
-    }
-    red[ty][tx] = s0;
-    __syncthreads();
-    if (ty == 0 && c < C) J.dst[job][c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-}
-
-// The tail of a TD step as TWO launches on one stream instead of seven on two: every event record on the critical stream costs
-// ~6 us of idle time and the join at the end 3-12 us, more than the kernels between them are worth.  One launch
-// carries the blocks of several kernels ("horizontal fusion"): the grid is the concatenation of their grids, a block finds its body
-// from its linear id (block-uniform branch), dynamic LDS = the largest of the bodies present.  Launch 1 (behind td_delta_kernel,
-// once per hidden layer below the top one): the delta GEMM of the next layer down + what only needs the deltas already there — the
-// weight-gradient GEMM of the layer above it and, first time round, the output-layer segmented sum.  Launch 2: the layer-0
-// segmented sum + the bias column sums.  Long blocks come first in the grid.  Every body is the block function of the stand-alone
-// kernel, so the results are bitwise those of the two-stream path (tests/test_dqn_gpu.py).
-enum { TAIL_DELTA = 1, TAIL_GRAD = 2, TAIL_OUT = 4, TAIL_COLSUM = 8, TAIL_L0 = 16 };
-struct TailArgs {
-    // grid order: [l0][grad][delta][out][colsum]; n_* = blocks of each part (0 = absent)
-    int n_l0, n_grad, n_delta, n_out, n_colsum;
-    GemmArgs grad;  int grad_gx, grad_gy;          // 64x64 tiles: grid (gx, gy, splits)
-    GemmArgs delta; int delta_gx;                  // grid (gx, gy, 1)
-    const int32_t* og_act; const float* og_dsc; const float* og_alast; int og_n, og_H, og_chunk; float* og_partial;   // grid (24, chunks)
-    const uint32_t* l0_boards; const float* l0_delta; int l0_n, l0_H, l0_HS, l0_chunk, l0_nsets, l0_nch; float* l0_partial;   // (90, nch, H / HS)
-    const uint16_t* l0_planes; long long l0_plane_stride; int l0_kpad, l0_ncb;      // != nullptr: the matrix-pipe form, grid (4, H / 32, nch)
-    ColsumJobs cj; int cj_gx, cj_gy;               // grid (gx, R, njobs)
-};
-// L0MFMA: the layer-0 blocks are the matrix-pipe form (xq_dqn_set_l0_grad_mode(1)) — an instantiation of its own: that body needs 180
-// VGPRs against 136 for the rest, and behind a run-time branch in the default kernel it capped every block of the launch at two waves
-// per SIMD.  (Measured, same box, 3 x 3 x 300 steps: 180 / 136 / 106 VGPRs — the last forced with amdgpu_waves_per_eu(4) — 0.1887-0.1899 /
-// 0.1896-0.1903 / 0.1885-0.1897 ms per step: the launch is not bound by its occupancy.)
-template <unsigned KINDS, bool L0MFMA = false>
-__global__ __launch_bounds__(256) void td_tail_kernel(const TailArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float tail_smem[];
-    int b = (int)blockIdx.x;
-    if (KINDS & TAIL_L0) {
-        if (b < a.n_l0) {
-            if (L0MFMA) {
-                const int rest = b >> 2;
-                l0_grad_mfma_block<0>(a.l0_boards, a.l0_planes, a.l0_plane_stride, a.l0_kpad, a.l0_n, a.l0_H, a.l0_chunk, a.l0_partial, b & 3,
-                                      rest % a.l0_ncb, rest / a.l0_ncb, reinterpret_cast<uint32_t*>(tail_smem));
-                return;
-            }
-            const int per = kSquares * a.l0_nch;
-            l0_grad_block(a.l0_boards, a.l0_delta, a.l0_n, a.l0_H, a.l0_HS, a.l0_chunk, a.l0_nsets, a.l0_partial, b % per, a.l0_nch, b / per, tail_smem);
-            return;
-        }
-        b -= a.n_l0;
-    }
-    if (KINDS & TAIL_GRAD) {
-        if (b < a.n_grad) {
-            const int per = a.grad_gx * a.grad_gy, r = b % per;
-            gemm_f32_block<L_MCONTIG, L_MCONTIG, EPI_STORE, 1, 1>(a.grad, r % a.grad_gx, r / a.grad_gx, b / per, tail_smem, tail_smem + g_tile_floats(64));
-            return;
-        }
-        b -= a.n_grad;
-    }
-    if (KINDS & TAIL_DELTA) {
-        if (b < a.n_delta) {
-            gemm_f32_block<L_KCONTIG, L_MCONTIG, EPI_DELTA, 1, 1>(a.delta, b % a.delta_gx, b / a.delta_gx, 0, tail_smem, tail_smem + g_tile_floats(64));
-            return;
-        }
-        b -= a.n_delta;
-    }
-    if (KINDS & TAIL_OUT) {
-        if (b < a.n_out) {
-            out_grad_block(a.og_act, a.og_dsc, a.og_alast, a.og_n, a.og_H, a.og_chunk, a.og_partial, b % 24, b / 24, tail_smem);
-            return;
-        }
-        b -= a.n_out;
-    }
-    if (KINDS & TAIL_COLSUM) {
-        if (b < a.n_colsum) {
-            const int per = a.cj_gx * a.cj_gy, r = b % per;
-            colsum_partial_block(a.cj, r % a.cj_gx, r / a.cj_gx, b / per);
-        }
-    }
-}
-
-// out[i] = sum_z slabs[z*stride + i], z ascending (deterministic)
-__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslabs, long long stride, long long len, float* __restrict__ out) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int z = 0;
-        for (; z + 3 < nslabs; z += 4) {
-            s0 += slabs[(long long)z * stride + i];
-            s1 += slabs[(long long)(z + 1) * stride + i];
-            s2 += slabs[(long long)(z + 2) * stride + i];
-            s3 += slabs[(long long)(z + 3) * stride + i];
-        }
-        for (; z < nslabs; ++z) s0 += slabs[(long long)z * stride + i];
-        out[i] = (s0 + s1) + (s2 + s3);
-    }
-}
-
-struct SegTable {
-    float* dst[16];
-    const float* src[16];
-    long long len[16];
-    int nslabs[16];            // > 0: src holds that many partial-sum slabs `stride` apart; they are summed here, in the order
-    long long stride[16];      //      of reduce_slabs_kernel (bit-identical to reducing first), instead of by a kernel of their own
-    uint16_t* dst_bf[16];      // bf16 Q-net: shadow of dst, refreshed with the rounded new value (nullptr: none)
-    int nseg;
-    int reduce_only;           // dst = the slab sum itself (no step): the gradient buffer a reader or an all-reduce needs, in one launch
-};
-// ---- exact screening of z_max[b] = max_j (W_out[j] . a[b] + b_out[j])  (xq_dqn_set_qmax_mode(XQ_QMAX_SCREENED)) ------
-// The fp32 column-max GEMM computes 8100 outputs per sample to keep one.  Screening computes all of them once on the bf16 matrix
-// pipe (16x the fp32 MFMA rate), with a rigorous bound on what bf16 operands can hide, and re-evaluates in fp32 only the few
-// outputs that could still be the maximum.  With u = 2^-8 (round-to-nearest bf16, 8-bit significand):
-//   z~_j = fl32(sum_k bf16(W_jk) bf16(a_k)) + b_j
-//   |z~_j - z_j| <= (2u + u^2) sum_k |W_jk a_k|  [operand rounding]  +  2K 2^-23 sum_k |W_jk a_k|  [fp32 accumulation of the exact
-//                   products inside and between the MFMAs, K <= 1024]
-//               <= B := kScreenEps ||a||_2 max_j ||W_j||_2           [Cauchy-Schwarz; kScreenEps = 2^-7 * 1.0625 >= 2^-7 + 2^-16 + 2^-12]
-//   j* = argmax z_j  =>  z~_j* >= z_j* - B >= z_J - B >= z~_J - 2B with J = argmax z~: every output whose screened value is within
-//   2B of the screened maximum is a candidate and j* is among them.  The threshold used is m~ - 2B (1 + 2^-5) - 2^-16 (|m~| + 2B):
-//   the 2^-5 absorbs the rounding of the fp32 re-evaluation itself (<= K 2^-24 sum|W a| <= 2^-14/kScreenEps B per value), so the
-//   result is the maximum over ALL outputs of the fp32-evaluated value, not only a value close to it; the last term covers the
-//   5-bit position tag (<= 2^-18 relative at both ends).
-// Pass 1 (gemm_colmax_persistent_kernel<.., DT_BF16, CM_TOP2>) leaves, per sample and per 32-row lane group, the largest screened
-// value (tagged with its row) and the second largest.  Pass 2 (qmax_refine_kernel): threshold per sample, then one fp32 dot per
-// candidate group whose second value is below the threshold (the usual case), 32 dots for a group with two values above it.
-constexpr float kScreenEps = 0.0078125f * 1.0625f;
-// the bias travels inside the accumulation chain (C operand of a tile's first MFMA, xq_screen.hip.h) or is added behind it (the
-// older kernel): either way it adds at most (K + 1) 2^-24 |b_j| of rounding to the screened value and the same to the fp32
-// re-evaluation; 2^-9 max_j |b_j| covers both for K <= 1024, including the 2^-5 share of B the threshold reserves for the latter
-constexpr float kScreenBiasEps = 0.001953125f;
-enum { kScreenCheckEvery = 32, kScreenHoldSteps = 512 };
-constexpr double kScreenMaxPairs = 24.0, kScreenMaxWhole = 1.0;     // candidate groups / whole groups per sample above which the
-                                                                    // fp32 re-evaluation costs more than the product it replaces
-
-__device__ __forceinline__ int float_order_key(float f) {             // signed-int order == float order (no NaNs here)
-    const int b = __builtin_bit_cast(int, f);
-    return b ^ ((b >> 31) & 0x7fffffff);
-}
-__device__ __forceinline__ float float_from_key(int k) { return __builtin_bit_cast(float, k ^ ((k >> 31) & 0x7fffffff)); }
-__device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// Pass 2.  Block = 32 consecutive samples x 8 group phases (thread = (sample, phase); P1 / P2 are [G][n], group-major, so a
-// half-wave reads 128 contiguous bytes per group).  G <= 512.  Every thread keeps its G/8 screened values in registers between the
-// maximum and the candidate scan.  Dynamic LDS: G * 32 single-row candidates (32 bits) + G * 32 whole-group candidates (16 bits) —
-// one entry per (sample, group) pair at most, so neither list can overflow.  The fp32 dots run a quarter-wave per row: singles two
-// per quarter and round (32 per round), a whole group as ONE round of the block (its 32 rows over the 16 quarters).
-// wmax_next: zeroed for the next step's shadow pass.  stats: [2] += candidate pairs, [3] += pairs recomputed as whole groups.
-enum { kRefineSamples = 32, kRefineMaxPerThread = 64 };
-
-// one fp32 dot per quarter-wave (16 lanes x float4 x K/64 passes), all loads of both operands issued before the first fma
-template <int KFIX>
-__device__ __forceinline__ float quarter_dot(const float* __restrict__ ap, const float* __restrict__ wp, int K, int ql) {
-    float acc = 0.f;
-    if (KFIX > 0) {
-        constexpr int NT = KFIX > 0 ? KFIX / 64 : 1;
-        float4 x[NT], w[NT];
-#pragma unroll
-        for (int t = 0; t < KFIX / 64; ++t) {
-            x[t] = *reinterpret_cast<const float4*>(ap + t * 64 + ql * 4);
-            w[t] = *reinterpret_cast<const float4*>(wp + t * 64 + ql * 4);
-        }
-#pragma unroll
-        for (int t = 0; t < KFIX / 64; ++t) {
-            acc = fmaf(x[t].x, w[t].x, acc); acc = fmaf(x[t].y, w[t].y, acc);
-            acc = fmaf(x[t].z, w[t].z, acc); acc = fmaf(x[t].w, w[t].w, acc);
-        }
-    } else {
-        for (int k = ql * 4; k < K; k += 64) {
-            const float4 x = *reinterpret_cast<const float4*>(ap + k);
-            const float4 w = *reinterpret_cast<const float4*>(wp + k);
-            acc = fmaf(x.x, w.x, acc); acc = fmaf(x.y, w.y, acc); acc = fmaf(x.z, w.z, acc); acc = fmaf(x.w, w.w, acc);
-        }
-    }
-    return acc;
-}
-__device__ __forceinline__ float quarter_sum(float v) {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ int screen_row(int g, int code) {       // inverse of the CM_TOP2 position code
-    const int q = code & 15;
-    return (g >> 2) * 128 + ((g >> 1) & 1) * 64 + 4 * (g & 1) + (code >> 4) * 32 + (q & 3) + 8 * (q >> 2);
-}
-
-template <int KFIX, int NPT>                 // NPT = screened values per thread = ceil(G / 8), unrolled (32 for 8100 outputs)
-__global__ __launch_bounds__(256) void qmax_refine_kernel(const float* __restrict__ P1, const float* __restrict__ P2, int G, int n, long long ldp,
-                                                          const float* __restrict__ a_last, int K, const float* __restrict__ W,
-                                                          const float* __restrict__ bias, int NO, unsigned* __restrict__ wm, int parity,
-                                                          float* __restrict__ zmax, unsigned long long* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cand[];            // [G * 32]: sample | row << 5
-    uint16_t* wlist = reinterpret_cast<uint16_t*>(cand + (size_t)G * kRefineSamples);    // [G * 32]: sample | group << 5
-    __shared__ float sv[8][32];
-    __shared__ float na[32], thr[32];
-    __shared__ int best[32];
-    __shared__ int cnt, nexp;
-    const int tid = (int)threadIdx.x;
-    const int sl = tid & 31, phase = tid >> 5;
-    const int ql = tid & 15, quarter = tid >> 4;
-    const int b0 = (int)blockIdx.x * kRefineSamples;
-    const int b = b0 + sl;
-    const bool ok = b < n;
-    if (tid == 0) { cnt = 0; nexp = 0; if (blockIdx.x == 0) { wm[parity ^ 1] = 0u; wm[2 + (parity ^ 1)] = 0u; } }   // next step's slots
-    unsigned long long st_pairs = 0, st_whole = 0;   // candidate counters: [block][2] running totals, one writer per slot (stream order)
-    if (tid == 0) { st_pairs = stats[2 * blockIdx.x]; st_whole = stats[2 * blockIdx.x + 1]; }
-    if (tid < 32) best[tid] = (int)0x80000000;
-    // this thread's screened values: groups phase, phase + 8, ...
-    // (unconditional, clamped loads: a predicate per load compiles to a branch per load)
-    float v[NPT], v2[NPT];                          // the second values too, up front: one memory round trip less
-    const int bc = min(b, n - 1);
-#pragma unroll
-    for (int u = 0; u < NPT; ++u) {
-        const int g = min(phase + 8 * u, G - 1);
-        v[u] = P1[(long long)g * ldp + bc];
-        v2[u] = P2[(long long)g * ldp + bc];
-    }
-#pragma unroll
-    for (int u = 0; u < NPT; ++u)
-        if (!ok || phase + 8 * u >= G) { v[u] = kColmaxPadBias; v2[u] = kColmaxPadBias; }
-    // ||a_b||^2: a quarter-wave per sample, two samples per quarter
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i = quarter + 16 * r;
-        const float* ap = a_last + (long long)min(b0 + i, n - 1) * K;
-        const float ss = quarter_sum(quarter_dot<KFIX>(ap, ap, K, ql));
-        if (ql == 0) na[i] = ss;
-    }
-    float m = kColmaxPadBias;
-#pragma unroll
-    for (int u = 0; u < NPT; ++u) m = fmaxf(m, v[u]);
-    sv[phase][sl] = m;
-    __syncthreads();
-    if (tid < 32) {
-        m = sv[0][sl];
-#pragma unroll
-        for (int p = 1; p < 8; ++p) m = fmaxf(m, sv[p][sl]);
-        const float wmx = fmaxf(__builtin_bit_cast(float, wm[parity]), __builtin_bit_cast(float, wm[4]));
-        const float bmx = fmaxf(__builtin_bit_cast(float, wm[2 + parity]), __builtin_bit_cast(float, wm[5]));
-        const float B = kScreenEps * sqrtf(na[sl]) * wmx + kScreenBiasEps * bmx;
-        float t0 = m - 2.f * B * 1.03125f - 1.52587890625e-05f * (fabsf(m) + 2.f * B);
-        if (!(t0 == t0)) t0 = -__builtin_inff();      // a non-finite norm (diverged net): every group is a candidate, like the full product
-        thr[sl] = b0 + sl < n ? t0 : __builtin_inff();   // no candidates past n
-    }
-    __syncthreads();
-    {
-        const float t = thr[sl];
-#pragma unroll
-        for (int u = 0; u < NPT; ++u) {
-            const int g = phase + 8 * u;
-            if (v[u] >= t) {                         // padding values are far below every threshold
-                if (v2[u] >= t) wlist[atomicAdd(&nexp, 1)] = (uint16_t)(sl | (g << 5));
-                else cand[atomicAdd(&cnt, 1)] = (uint32_t)sl | ((uint32_t)screen_row(g, (int)(__builtin_bit_cast(uint32_t, v[u]) & 31u)) << 5);
-            }
-        }
-    }
-    __syncthreads();
-    // fp32 dots of the candidates (the maximum does not depend on the order they are visited in)
-    const int singles = cnt, wholes = nexp;
-    for (int e0 = 0; e0 < singles; e0 += 64) {                   // 16 quarters x 4 rows per round, all loads of a round in flight
-        float z[4];
-        int s2[4], row[4];
-        bool live[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int e = e0 + quarter + 16 * r;
-            live[r] = e < singles;
-            const uint32_t ent = cand[live[r] ? e : 0];
-            s2[r] = (int)(ent & 31u);
-            row[r] = min((int)(ent >> 5), NO - 1);
-            z[r] = quarter_dot<KFIX>(a_last + (long long)(b0 + s2[r]) * K, W + (long long)row[r] * K, K, ql);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            z[r] = quarter_sum(z[r]) + bias[row[r]];
-            if (live[r] && ql == 0 && z[r] == z[r]) atomicMax(&best[s2[r]], float_order_key(z[r]));   // (a NaN output never wins: fmaxf semantics)
-        }
-    }
-    for (int e = 0; e < wholes; ++e) {                           // a whole group: its 32 rows over the 16 quarters, one round
-        const int ent = wlist[e];
-        const int s2 = ent & 31, g = ent >> 5;
-        float zb = kColmaxPadBias;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int row = screen_row(g, quarter + 16 * r);
-            const int rc = min(row, NO - 1);
-            const float z = quarter_sum(quarter_dot<KFIX>(a_last + (long long)(b0 + s2) * K, W + (long long)rc * K, K, ql)) + bias[rc];
-            if (row < NO) zb = fmaxf(zb, z);
-        }
-        if (ql == 0) atomicMax(&best[s2], float_order_key(zb));
-    }
-    __syncthreads();
-    if (tid < 32 && ok) zmax[b] = float_from_key(best[sl]);
-    if (tid == 0) {                                  // this block's own running totals (512 same-address atomics per launch cost the
-        stats[2 * blockIdx.x] = st_pairs + (unsigned long long)(singles + wholes);      // step 5 us)
-        stats[2 * blockIdx.x + 1] = st_whole + (unsigned long long)wholes;
-    }
-}
-
-// Pass 2 behind screen_top2_kernel (xq_screen.hip.h), which also leaves R[range][sample] = the largest P1 of the sample over the groups
-// of one row range and na[sample] = ||bf16(a)||^2: the threshold needs 16 values per sample instead of 254, and only the groups of the
-// ranges that reach it are looked at (usually one: the kernel reads ~1/10 of the partial arrays, and no activation rows for the norm).
-// ||a|| <= ||bf16(a)|| (1 + 2^-7): inside the slack of kScreenEps (2^-7 * 0.0625 - 2^-12 - 2^-16 = 2.3e-4 against 6.1e-5 + the fp32
-// rounding of the sum of squares).  Same block shape, candidate lists and fp32 re-evaluation as qmax_refine_kernel.
-// TD: the work of td_delta_kernel (its fp32, 256-wide fast path: same loads, same arithmetic, same bits) for the block's 32 samples —
-// wave w owns samples 8w .. 8w+7.  Everything that does not depend on the maximum (action, reward, Q(s,a) = the dot of two 1-KB rows) is
-// requested at the very top and lands under the refine phases; once the block's maxima exist the targets, the scalar deltas and the top
-// hidden deltas follow.  One launch and ~10 us of exposed latency chain fewer on the step's critical stream.
-struct TdFused {
-    SlotSrc src;
-    const int32_t* action_to; const float* reward; const uint8_t* done;
-    const float* a_s;              // last hidden activations of s on the online net [n][256]
-    const float* w_out; const float* b_out;
-    const float* view; long long view_ld; int view_kmax;
-    float gamma;
-    float* dtop; float* dsc; int32_t* act; float* qsa; float* yv; float* lossv;
-};
-template <int KFIX, bool TD = false>
-__global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restrict__ R, int ranges, int gpr /* groups per range */,
-                                                           const float* __restrict__ P1, const float* __restrict__ P2, int G, int n, long long ldp,
-                                                           const float* __restrict__ na_all, const float* __restrict__ a_last, int K,
-                                                           const float* __restrict__ W, const float* __restrict__ bias, int NO,
-                                                           unsigned* __restrict__ wm, int parity, float* __restrict__ zmax,
-                                                           unsigned long long* __restrict__ stats, const TdFused T) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cand[];            // [G * 32]: sample | row << 5
-    uint16_t* wlist = reinterpret_cast<uint16_t*>(cand + (size_t)G * kRefineSamples);    // [G * 32]: sample | group << 5
-    __shared__ float sv[8][32];
-    __shared__ float thr[32];
-    __shared__ int best[32];
-    __shared__ int cnt, nexp;
-    const int tid = (int)threadIdx.x;
-    const int sl = tid & 31, phase = tid >> 5;
-    const int ql = tid & 15, quarter = tid >> 4;
-    const int b0 = (int)blockIdx.x * kRefineSamples;
-    const int b = b0 + sl;
-    const bool ok = b < n;
-    const int bc = min(b, n - 1);
-    if (tid == 0) { cnt = 0; nexp = 0; if (blockIdx.x == 0) { wm[parity ^ 1] = 0u; wm[2 + (parity ^ 1)] = 0u; } }   // next step's slots
-    unsigned long long st_pairs = 0, st_whole = 0;   // candidate counters: [block][2] running totals, one writer per slot (stream order)
-    if (tid == 0) { st_pairs = stats[2 * blockIdx.x]; st_whole = stats[2 * blockIdx.x + 1]; }
-    if (tid < 32) best[tid] = (int)0x80000000;
-    // TD: lanes 0..7 of each wave hold action / reward / done / output bias of the wave's eight samples; zq[i] = Q(s,a) before the tanh
-    const int td_lane = tid & 63, td_w = tid >> 6;
-    int td_a = -1; float td_r = 0.f, td_bo = 0.f; bool td_dn = false;
-    float zq[8];
-    if (TD) {
-        static_assert(!TD || KFIX == 256, "fused TD delta: 256-wide last hidden layer");
-        if (td_lane < 8) {
-            const int bb = min(b0 + td_w * 8 + td_lane, n - 1);
-            const int sslot = slot_of(T.src, bb);
-            td_a = T.action_to[sslot];
-            td_r = T.reward[sslot];
-            td_dn = T.done[sslot] != 0;
-            td_bo = T.b_out[(td_a >= 0 && td_a < 96) ? td_a : 0];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int bb = min(b0 + td_w * 8 + i, n - 1);
-            const int a = __shfl(td_a, i, 64);
-            const int ac = (a >= 0 && a < 96) ? a : 0;
-            const float4 av = *reinterpret_cast<const float4*>(T.a_s + (long long)bb * 256 + td_lane * 4);
-            const float4 wv = *reinterpret_cast<const float4*>(T.w_out + (long long)ac * 256 + td_lane * 4);
-            zq[i] = (av.x * wv.x + av.y * wv.y) + (av.z * wv.z + av.w * wv.w);
-        }
-    }
-    float m = kColmaxPadBias;
-    for (int r = phase; r < ranges; r += 8) m = fmaxf(m, R[(long long)r * ldp + bc]);
-    sv[phase][sl] = m;
-    __syncthreads();
-    if (tid < 32) {
-        m = sv[0][sl];
-#pragma unroll
-        for (int p = 1; p < 8; ++p) m = fmaxf(m, sv[p][sl]);
-        const float wmx = fmaxf(__builtin_bit_cast(float, wm[parity]), __builtin_bit_cast(float, wm[4]));
-        const float bmx = fmaxf(__builtin_bit_cast(float, wm[2 + parity]), __builtin_bit_cast(float, wm[5]));
-        const float B = kScreenEps * sqrtf(na_all[bc]) * wmx + kScreenBiasEps * bmx;
-        float t0 = m - 2.f * B * 1.03125f - 1.52587890625e-05f * (fabsf(m) + 2.f * B);
-        if (!(t0 == t0)) t0 = -__builtin_inff();      // a non-finite norm (diverged net): every group is a candidate, like the full product
-        thr[sl] = ok ? t0 : __builtin_inff();            // no candidates past n
-    }
-    __syncthreads();
-    {
-        const float t = thr[sl];
-        for (int r = phase; r < ranges; r += 8) {
-            if (R[(long long)r * ldp + bc] < t) continue;        // no group of this range reaches the threshold
-            const int g0 = r * gpr, g1 = min(G, g0 + gpr);
-            for (int g = g0; g < g1; g += 4) {                   // four independent loads in flight
-                float v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = P1[(long long)min(g + u, g1 - 1) * ldp + bc];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (g + u < g1 && v[u] >= t) {
-                        const float v2 = P2[(long long)(g + u) * ldp + bc];
-                        if (v2 >= t) wlist[atomicAdd(&nexp, 1)] = (uint16_t)(sl | ((g + u) << 5));
-                        else cand[atomicAdd(&cnt, 1)] = (uint32_t)sl | ((uint32_t)screen_row(g + u, (int)(__builtin_bit_cast(uint32_t, v[u]) & 31u)) << 5);
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // fp32 dots of the candidates (the maximum does not depend on the order they are visited in)
-    const int singles = cnt, wholes = nexp;
-    for (int e0 = 0; e0 < singles; e0 += 64) {                   // 16 quarters x 4 rows per round, all loads of a round in flight
-        float z[4];
-        int s2[4], row[4];
-        bool live[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int e = e0 + quarter + 16 * r;
-            live[r] = e < singles;
-            const uint32_t ent = cand[live[r] ? e : 0];
-            s2[r] = (int)(ent & 31u);
-            row[r] = min((int)(ent >> 5), NO - 1);
-            z[r] = quarter_dot<KFIX>(a_last + (long long)(b0 + s2[r]) * K, W + (long long)row[r] * K, K, ql);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            z[r] = quarter_sum(z[r]) + bias[row[r]];
-            if (live[r] && ql == 0 && z[r] == z[r]) atomicMax(&best[s2[r]], float_order_key(z[r]));   // (a NaN output never wins: fmaxf semantics)
-        }
-    }
-    for (int e = 0; e < wholes; ++e) {                           // a whole group: its 32 rows over the 16 quarters, one round
-        const int ent = wlist[e];
-        const int s2 = ent & 31, g = ent >> 5;
-        float zb = kColmaxPadBias;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int row = screen_row(g, quarter + 16 * r);
-            const int rc = min(row, NO - 1);
-            const float z = quarter_sum(quarter_dot<KFIX>(a_last + (long long)(b0 + s2) * K, W + (long long)rc * K, K, ql)) + bias[rc];
-            if (row < NO) zb = fmaxf(zb, z);
-        }
-        if (ql == 0) atomicMax(&best[s2], float_order_key(zb));
-    }
-    __syncthreads();
-    if (tid < 32 && ok) zmax[b] = float_from_key(best[sl]);
-    if (tid == 0) {                                  // this block's own running totals (512 same-address atomics per launch cost the
-        stats[2 * blockIdx.x] = st_pairs + (unsigned long long)(singles + wholes);      // step 5 us)
-        stats[2 * blockIdx.x + 1] = st_whole + (unsigned long long)wholes;
-    }
-    if (TD) {
-        // the rows for the top hidden delta (L2-hot: read a moment ago / shared by every sample with the same action), all in flight
-        float4 av[8], vv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int bb = min(b0 + td_w * 8 + i, n - 1);
-            const int a = __shfl(td_a, i, 64);
-            const bool has_view = a >= 0 && a < 96 && a < T.view_kmax;
-            av[i] = *reinterpret_cast<const float4*>(T.a_s + (long long)bb * 256 + td_lane * 4);
-            vv[i] = has_view ? *reinterpret_cast<const float4*>(T.view + (long long)a * T.view_ld + td_lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int bb = b0 + td_w * 8 + i;
-            const int a = __shfl(td_a, i, 64);
-            const float r = __shfl(td_r, i, 64), bo = __shfl(td_bo, i, 64);
-            const bool dn = __shfl((int)td_dn, i, 64) != 0;
-            const bool live = a >= 0 && a < 96;
-            float z = zq[i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
-            const float zm = float_from_key(best[td_w * 8 + i]);
-            float q = 0.f, y = 0.f, delta = 0.f;
-            if (live) {
-                q = tanhf(z + bo);
-                y = dn ? r : r + T.gamma * tanhf(zm);
-                delta = (q - y) * (1.f - q * q) * 1.f;
-            }
-            if (bb < n) {                                         // wave-uniform
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live && a < T.view_kmax) {
-                    o.x = delta * vv[i].x * (1.f - av[i].x * av[i].x); o.y = delta * vv[i].y * (1.f - av[i].y * av[i].y);
-                    o.z = delta * vv[i].z * (1.f - av[i].z * av[i].z); o.w = delta * vv[i].w * (1.f - av[i].w * av[i].w);
-                }
-                *reinterpret_cast<float4*>(T.dtop + (long long)bb * 256 + td_lane * 4) = o;
-                if (td_lane == 0) {
-                    T.dsc[bb] = delta;
-                    T.act[bb] = live ? a : -1;
-                    T.qsa[bb] = q; T.yv[bb] = y;
-                    T.lossv[bb] = live ? 0.5f * (q - y) * (q - y) : 0.f;
-                }
-            }
-        }
-    }
-}
-
-// Q head with the k range split over blocks (q_head) or folded into the last hidden product (EPI_HEAD): q[m][j] = tanh(b_j + the sum of
-// the k-slabs of the product), slabs added four at a time as (s0 + s1) + (s2 + s3), the groups of four in ascending order (nslabs even).
-// One thread per output.
-__global__ __launch_bounds__(256) void q_head_finish_kernel(const float* __restrict__ slabs, long long slab_stride, int nslabs, int n, int n_out, int lds_,
-                                                            const float* __restrict__ bias, float* __restrict__ q, int ldq) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)n * n_out) return;
-    const int m = (int)(i / n_out), j = (int)(i % n_out);
-    const float* p = slabs + (long long)m * lds_ + j;
-    float s = 0.f;
-    for (int z = 0; z < nslabs; z += 4) {
-        float t = p[z * slab_stride] + p[(z + 1) * slab_stride];
-        if (z + 3 < nslabs) t += p[(z + 2) * slab_stride] + p[(z + 3) * slab_stride];
-        s = z == 0 ? t : s + t;
-    }
-    q[(long long)m * ldq + j] = tanhf(bias[j] + s);
-}
-
-// bf16 shadow of a weight range (set_params / load_model / set_precision)
-__global__ void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        dst[i] = bf16_bits(src[i]);
-}
-// SGD: dst -= alpha * src per segment (updateWeightsBiasesKernel dqn.cu:310-319, batched form)
-__global__ void sgd_segments_kernel(SegTable t, float alpha) {
-    const int sgm = (int)blockIdx.y;
-    if (sgm >= t.nseg) return;
-    float* d = t.dst[sgm];
-    const float* s = t.src[sgm];
-    const int nslabs = t.nslabs[sgm];
-    const long long len = t.len[sgm], st = t.stride[sgm];
-    uint16_t* db = t.dst_bf[sgm];
-    if (nslabs <= 0) {
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
-            const float v = d[i] - alpha * s[i];
-            d[i] = v;
-            if (db) db[i] = bf16_bits(v);
-        }
-        return;
-    }
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int z = 0;
-        for (; z + 3 < nslabs; z += 4) {
-            s0 += s[(long long)z * st + i];
-            s1 += s[(long long)(z + 1) * st + i];
-            s2 += s[(long long)(z + 2) * st + i];
-            s3 += s[(long long)(z + 3) * st + i];
-        }
-        for (; z < nslabs; ++z) s0 += s[(long long)z * st + i];
-        if (t.reduce_only) { d[i] = (s0 + s1) + (s2 + s3); continue; }
-        const float v = d[i] - alpha * ((s0 + s1) + (s2 + s3));
-        d[i] = v;
-        if (db) db[i] = bf16_bits(v);
-    }
-}
+namespace xq {
 
 // ---------------------------------------------------------------------------------------------------------------
 // host helpers
@@ -2624,7 +1098,7 @@ static int dqn_init(xq_dqn* d, const int* layer_sizes, int n_sizes, double learn
 int xq_dqn_destroy(xq_dqn* d) {
     if (!d) return XQ_OK;
     hipStreamSynchronize(d->stream);
-    if (d->own_stream) retire_stream(d->stream);
+    retire_stream(d->stream);                                // (synchronised above: nothing queued on it is left to wait for — also when the stream is the caller's, which may destroy it next)
     for (int i = 0; i < 2; ++i) { hipFree(d->params[i]); hipFree(d->tacts[i]); }
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts[l]); hipFree(d->deltas[l]); hipFree(d->sel_acts[l]); }
     hipFree(d->gboards); hipFree(d->dsc); hipFree(d->act_mb); hipFree(d->q90); hipFree(d->sel_q90); for (auto& K : d->sel_keep) { hipFree(K.z1); hipFree(K.prev_boards); } hipFree(d->partial); hipFree(d->zmax); hipFree(d->zidx); hipFree(d->qsa); hipFree(d->yv); hipFree(d->lossv);
@@ -2637,7 +1111,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     hipFree(d->partial_idx);
     hipFree(d->qh_slabs[0]); hipFree(d->qh_slabs[1]);
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) hipFree(d->deltas_bf[l]);
-    if (d->side) { hipStreamSynchronize(d->side); hipStreamDestroy(d->side); }
+    if (d->side) { hipStreamSynchronize(d->side); retire_stream(d->side); hipStreamDestroy(d->side); }
     delete d->tail;
     if (d->ev_fork) hipEventDestroy(d->ev_fork);
     if (d->ev_join) hipEventDestroy(d->ev_join);
@@ -2796,6 +1270,8 @@ static int chain_dense(xq_dqn* d, int net, const float* x, int n, float* const* 
     g.B = d->w0t(net); g.ldb = d->L[1];
     g.C = outs[0]; g.ldc = d->L[1];
     g.bias = d->bl(net, 0);
+    g.libm_tanh = 1;                     // layer 0 takes libm's tanhf on BOTH routes (the packed-board gather kernels call it too): a dense
+                                         // one-hot and the board it encodes then differ by summation order only
     XQ_GEMM((launch_gemm<L_KCONTIG, L_MCONTIG, EPI_BIAS_TANH>(d, g, 1, "gemm_l0_dense_fwd")));
     for (int l = 1; l + 1 < d->nl; ++l) {
         GemmArgs h; memset(&h, 0, sizeof h);

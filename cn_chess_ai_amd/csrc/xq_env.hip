@@ -517,7 +517,7 @@ int xq_env_create(int n_games, uint64_t seed, uint32_t first_game_id, void* hip_
 int xq_env_destroy(xq_env* e) {
     if (!e) return XQ_OK;
     hipStreamSynchronize(e->stream);
-    if (e->own_stream) retire_stream(e->stream);
+    retire_stream(e->stream);        // synchronised above; unconditional: a caller-owned stream may be destroyed right after this call
     hipFree(e->boards); hipFree(e->meta); hipFree(e->stats); hipFree(e->results); hipFree(e->codes);
     hipFree(e->counts); hipFree(e->actions); hipFree(e->q90); hipFree(e->validmat); hipFree(e->ep_ring);
     hipFree(e->ep_head);

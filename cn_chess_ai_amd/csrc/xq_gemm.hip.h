@@ -36,7 +36,8 @@ __device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_ca
 __device__ __forceinline__ float bf16_to_float(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 // tanh for values that are rounded to bf16 right away (hidden activations of the bf16 Q-net): 1 - 2 / (1 + e^2x) on the hardware
 // exp and reciprocal — absolute error ~1e-7, far below half a bf16 ulp except for |x| < 1e-4 where it cannot matter; tanhf costs
-// ~40 instructions per value, which the bf16 MFMA no longer hides (the fp32 epilogues keep tanhf)
+// ~40 instructions per value, which the bf16 MFMA no longer hides (fp32 nets: tanh_hidden below for the hidden products, tanhf
+// for layer 0 and the output layer)
 __device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 // tanh of the fp32 hidden layers (forward epilogues of the hidden products; NeuralNetwork::forward, dqn.cu:184-195, calls libm's tanh
 // in fp64).  libm's tanhf is ~40 VALU instructions per value and was 10-15 % of an 8192 x 512 x 512 product (tools/f32_fwd_probe.hip);

@@ -17,7 +17,9 @@ inline unsigned& order_mask() { static unsigned m = ORD_ALL; return m; }
 // last write and behind every read since.  The event is recorded LAZILY — on the producer's stream at the moment a consumer on another
 // stream shows up (streams run in order, so a record made later still lies behind the producer's work) — because a record costs the
 // recording stream ~6 us and most producers are never waited for.  Streams the library destroys are struck
-// from every resource first (retire_stream); a caller-owned stream must outlive the handles that exchanged data through it.
+// from every resource first (retire_stream), and every xq_*_destroy strikes the handle's stream — its own or the caller's — after
+// synchronising it; a caller that destroys a lent stream while a handle still uses it gets its entries dropped at the next access
+// (order_behind: a record on a dead stream fails, a dead stream has nothing left to wait for).
 struct SharedResource {
     unsigned cls;
     bool has_writer = false;
@@ -32,8 +34,8 @@ struct SharedResource {
     int order_behind(hipStream_t waiter, hipStream_t producer);
     int read(hipStream_t s);
     int write(hipStream_t s);
-    void forget(hipStream_t s);        // s was synchronised and goes away
-    void host_synchronised() { has_writer = false; n_readers = 0; }     // the whole device was synchronised: nothing left to wait for
+    void forget(hipStream_t s);        // s was synchronised and goes away (caller holds the registry's mutex: retire_stream, order_behind)
+    void host_synchronised();          // the whole device was synchronised: nothing left to wait for
 };
 void retire_stream(hipStream_t s);     // after hipStreamSynchronize(s), before hipStreamDestroy(s)
 

@@ -9,7 +9,7 @@
 //   * the one-hot operand is 0 / 1 — exact in bf16;
 //   * delta0 = hi + mid + lo with three bf16 values per fp32 (8 + 8 + 8 significant bits; each residual is formed exactly in fp32), so
 //     every product is exact and the MFMA accumulates in fp32: the result differs from a sequential fp32 sum only by summation order.
-// Round 2 tried this shape and measured 87.7 us (tools/experiments/xq_onehot.hip.h): it expanded the one-hot tile with VALU compares,
+// Round 2 tried this shape and measured 87.7 us (profiles/r02_e_onehot_mfma_experiment_*): it expanded the one-hot tile with VALU compares,
 // split delta0 inside the product kernel once per 64-row block, and had 184 blocks.  Here:
 //   * delta_split_kernel writes the three bf16 planes TRANSPOSED ([plane][column][sample]) once: an MFMA operand fragment (8 consecutive
 //     k = samples of one column) is then one 16-byte load per lane, 64 contiguous bytes per column and wave-instruction;

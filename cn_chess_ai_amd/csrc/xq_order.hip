@@ -28,21 +28,32 @@ SharedResource::~SharedResource() {
     if (ev) (void)hipEventDestroy(ev);
 }
 
+// (callers hold registry_mutex())
 int SharedResource::order_behind(hipStream_t waiter, hipStream_t producer) {
     if (waiter == producer || !(order_mask() & cls)) return XQ_OK;
     if (!ev) XQ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    XQ_HIP(hipEventRecord(ev, producer));            // lazily: behind everything the producer's stream holds by now
+    // lazily: behind everything the producer's stream holds by now.  A record that fails means the producer's stream is gone (a caller
+    // destroyed a stream it had lent to a handle without xq_stream_destroy / the handle's destroy, which strike it from here): a
+    // destroyed stream has finished its work, so its entry is dropped and there is nothing left to wait for — the error is not kept.
+    if (hipEventRecord(ev, producer) != hipSuccess) {
+        (void)hipGetLastError();
+        forget(producer);
+        return XQ_OK;
+    }
     XQ_HIP(hipStreamWaitEvent(waiter, ev, 0));
     return XQ_OK;
 }
 
+// read() / write() / host_synchronised() take the registry's mutex: retire_stream() — any handle or stream being destroyed on another
+// thread — edits the same fields of EVERY resource.  Uncontended in the trainer (one thread): ~20 ns per access.
 int SharedResource::read(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(registry_mutex());
     for (int i = 0; i < n_readers; ++i)
         if (readers[i] == s) return XQ_OK;           // already ordered behind the last write
     if (has_writer) XQ_TRY(order_behind(s, writer));
     if (n_readers == 4) {                            // a fifth reading stream takes the place of the fourth and waits for it, so that a
         XQ_TRY(order_behind(s, readers[3]));         // later writer that waits for s is behind both
-        readers[3] = s;
+        if (n_readers == 4) readers[3] = s; else readers[n_readers++] = s;     // (order_behind may have dropped a dead reader)
     } else {
         readers[n_readers++] = s;
     }
@@ -50,13 +61,22 @@ int SharedResource::read(hipStream_t s) {
 }
 
 int SharedResource::write(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(registry_mutex());
     bool waited = false;
-    for (int i = 0; i < n_readers; ++i)
-        if (readers[i] != s) { XQ_TRY(order_behind(s, readers[i])); waited = true; }
+    hipStream_t rd[4];
+    const int nr = n_readers;
+    for (int i = 0; i < nr; ++i) rd[i] = readers[i];                  // (a copy: order_behind may strike a dead stream from readers[])
+    for (int i = 0; i < nr; ++i)
+        if (rd[i] != s) { XQ_TRY(order_behind(s, rd[i])); waited = true; }
     // (every reader is itself behind the last writer: waiting for one of them covers it)
     if (has_writer && writer != s && !waited) XQ_TRY(order_behind(s, writer));
     has_writer = true; writer = s; n_readers = 0;
     return XQ_OK;
+}
+
+void SharedResource::host_synchronised() {
+    std::lock_guard<std::mutex> lock(registry_mutex());
+    has_writer = false; n_readers = 0;
 }
 
 void SharedResource::forget(hipStream_t s) {

@@ -295,7 +295,7 @@ static int replay_init(xq_replay* r, int capacity, uint64_t seed, void* hip_stre
 int xq_replay_destroy(xq_replay* r) {
     if (!r) return XQ_OK;
     hipStreamSynchronize(r->stream);
-    if (r->own_stream) retire_stream(r->stream);
+    retire_stream(r->stream);        // synchronised above; unconditional: a caller-owned stream may be destroyed right after this call
     hipFree(r->dev.boards); hipFree(r->dev.next_boards); hipFree(r->dev.action_to); hipFree(r->dev.reward);
     hipFree(r->dev.done); hipFree(r->slots_dev);
     hipFree(r->dev.prio); hipFree(r->per.leaves); hipFree(r->per.upper); hipFree(r->per.scalars); hipFree(r->per.wave_counts); hipFree(r->per.is_w);

@@ -112,11 +112,11 @@ int xq_trainer_destroy(xq_trainer* t) {
     if (!t) return XQ_OK;
     if (t->cstream) hipStreamSynchronize(t->cstream);
     hipStreamSynchronize(t->stream);
-    if (t->cstream) hipStreamDestroy(t->cstream);
+    if (t->cstream) { retire_stream(t->cstream); hipStreamDestroy(t->cstream); }
     if (t->ev_params) hipEventDestroy(t->ev_params);
     if (t->ev_collect) hipEventDestroy(t->ev_collect);
     if (t->ev_grads) hipEventDestroy(t->ev_grads);
-    if (t->own_stream) retire_stream(t->stream);
+    retire_stream(t->stream);        // synchronised above; unconditional: a caller-owned stream may be destroyed right after this call
     xq_env_destroy(t->env);
     xq_dqn_destroy(t->dqn);
     xq_replay_destroy(t->replay);

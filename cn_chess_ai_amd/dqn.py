@@ -223,7 +223,7 @@ DQN.set_td_tail = _set_td_tail
 
 
 def _set_l0_grad_mode(self, mode):
-    """Layer-0 weight gradient: 1 = exact dense product on the bf16 matrix pipe (default where the shape allows), 0 = segmented sums."""
+    """Layer-0 weight gradient: 0 = segmented sums (library default), 1 = exact dense product on the bf16 matrix pipe (where the shape allows)."""
     call("xq_dqn_set_l0_grad_mode", self._h, int(mode))
 
 

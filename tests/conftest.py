@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "refnn_live: runs upstream's NN runtime (oracle/_ref/xqref_nn) on the GPU; opt-in, XQ_RUN_REFERENCE_NN=1")
 
 
 @pytest.fixture(scope="session")
