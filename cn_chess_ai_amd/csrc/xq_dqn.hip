@@ -130,6 +130,9 @@ struct xq_dqn {
     float* slabs_l0 = nullptr;  size_t slabs_l0_cap = 0;     // layer-0 gradient partials
     // layer-0 gradient on the bf16 matrix pipe (xq_l0grad.hip.h): delta_0 as three bf16 planes, transposed [plane][column][sample]
     uint16_t* l0_planes = nullptr;  size_t l0_planes_cap = 0;
+    uint16_t* l0_sel = nullptr;     size_t l0_sel_cap = 0;       // selector half-words of the minibatch's boards (xq_l0grad.hip.h)
+    bool l0_split_done = false;                 // this step's layer-0 delta product wrote the planes in its epilogue
+    bool l0_sel_done = false;                   // this step's selector words rode in an earlier fused launch
     bool l0_mfma = false;                       // xq_dqn_set_l0_grad_mode (opt-in: faster alone, not inside the fused launch — DESIGN.md section 5)
     xq_comm* comm = nullptr;                    // xq_dqn_set_comm: bucketed RCCL all-reduce of the gradient buffer inside td_grads
     bool fused_apply = false;                   // xq_dqn_set_fused_apply: apply_grads may sum the layer-0 partials itself
@@ -764,6 +767,28 @@ static int check_reference_topology(const xq_dqn* d) {
 // hidden deltas l = nl-2 .. 0 from the output-side delta `dnext` ([n][ld_next], only the first k_nz columns can be
 // non-zero).  reference mode: delta_l = (dnext[:, :L[l+1]] x View) * (1-a^2), View[i][idx] = Wflat[wo[l+1] + i*L[l] + idx];
 // textbook: View[k][idx] = W_{l+1}[k][idx], k < L[l+2].
+// matrix-pipe form of the layer-0 gradient (xq_dqn_set_l0_grad_mode(1), xq_l0grad.hip.h): taken at these shapes
+static bool l0_mfma_shape(const xq_dqn* d, int n) { return d->l0_mfma && (d->L[1] % 64) == 0 && n >= 256; }
+static int l0_chunk_of(int n) { return n >= 16384 ? 2048 : 1024; }
+static int ensure_l0_mfma(xq_dqn* d, int n) {
+    const int H = d->L[1], chunk = l0_chunk_of(n), kpad = (n + chunk - 1) / chunk * chunk;
+    const size_t need = l0m_plane_elems(H, kpad);
+    if (need > d->l0_planes_cap) {
+        if (d->l0_planes) { XQ_HIP(hipDeviceSynchronize()); XQ_HIP(hipFree(d->l0_planes)); }
+        XQ_HIP(hipMalloc(&d->l0_planes, need * sizeof(uint16_t)));
+        XQ_HIP(hipMemsetAsync(d->l0_planes, 0, need * sizeof(uint16_t), d->cur));      // (the slack behind the planes is read, never used)
+        d->l0_planes_cap = need;
+    }
+    const size_t need_sel = l0sel_elems(kpad);
+    if (need_sel > d->l0_sel_cap) {
+        if (d->l0_sel) { XQ_HIP(hipDeviceSynchronize()); XQ_HIP(hipFree(d->l0_sel)); }
+        XQ_HIP(hipMalloc(&d->l0_sel, need_sel * sizeof(uint16_t)));
+        XQ_HIP(hipMemsetAsync(d->l0_sel, 0, need_sel * sizeof(uint16_t), d->cur));
+        d->l0_sel_cap = need_sel;
+    }
+    return XQ_OK;
+}
+
 static int hidden_deltas(xq_dqn* d, int n, const float* dnext, int ld_next, int k_nz, int mode, int l_start = -1, int l_stop = 0) {
     const float* up = dnext;
     int ld_up = ld_next, nz = k_nz;
@@ -792,6 +817,16 @@ static int hidden_deltas(xq_dqn* d, int n, const float* dnext, int ld_next, int 
         g.ldb = (mode == XQ_BACKPROP_REFERENCE) ? d->L[l] : d->L[l + 1];
         g.C = d->deltas[l]; g.ldc = d->L[l + 1];
         g.H = d->acts[l]; g.ldh = d->L[l + 1];
+        if (l == 0 && l0_mfma_shape(d, n) && (n % l0_chunk_of(n)) == 0) {
+            // delta_0's planes for the matrix-pipe layer-0 gradient straight from this product's epilogue (64 x 64 tiles; whole tiles
+            // and whole chunks only: the planes' zero padding is then empty) — no split launch, no re-read of delta_0
+            const long long t128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+            if (d->small_tiles || t128 < 512) {
+                XQ_TRY(ensure_l0_mfma(d, n));
+                g.split_planes = d->l0_planes; g.split_ld = n; g.split_plane_stride = (long long)d->L[1] * n;
+                d->l0_split_done = true;
+            }
+        }
         XQ_GEMM((launch_gemm<L_KCONTIG, L_MCONTIG, EPI_DELTA>(d, g, 1, "gemm_hidden_delta")));
         up = d->deltas[l]; ld_up = d->L[l + 1]; nz = d->L[l + 1];
     }
@@ -921,7 +956,7 @@ static int l0_gradient(xq_dqn* d, int n, float* dst) {
     const int H = d->L[1];
     // samples per block (list entries hold 11 bits of sample index).  8192 samples: 1024 (2048 measured 56 against 52 us, round 2);
     // 16384 samples: 2048 — half the partial slabs for the SGD kernel to sum (41 -> 20 MB), bench --config 5 0.717 -> 0.704 ms
-    const int chunk = n >= 16384 ? 2048 : 1024;
+    const int chunk = l0_chunk_of(n);
     const int nchunks = (n + chunk - 1) / chunk;
     const long long len = (long long)kStateSize * H;
     float* out = dst;
@@ -934,39 +969,44 @@ static int l0_gradient(xq_dqn* d, int n, float* dst) {
         }
         out = d->slabs_l0;
     }
-    if (d->l0_mfma && (H % 64) == 0 && n >= 256) {
-        // the matrix-pipe form (xq_l0grad.hip.h): delta_0 -> three transposed bf16 planes (one launch, 6 us at 8192 x 256), then
+    if (l0_mfma_shape(d, n)) {
+        // the matrix-pipe form (xq_l0grad.hip.h): boards -> selector half-words, delta_0 -> three transposed bf16 planes, then
         // one-hot^T x planes on v_mfma_f32_16x16x32_bf16 — exact products, fp32 accumulation
         const int kpad = nchunks * chunk;
-        const size_t need = l0m_plane_elems(H, kpad);
-        if (need > d->l0_planes_cap) {
-            if (d->l0_planes) { XQ_HIP(hipDeviceSynchronize()); XQ_HIP(hipFree(d->l0_planes)); }
-            XQ_HIP(hipMalloc(&d->l0_planes, need * sizeof(uint16_t)));
-            XQ_HIP(hipMemsetAsync(d->l0_planes, 0, need * sizeof(uint16_t), d->cur));      // (the slack behind the planes is read, never used)
-            d->l0_planes_cap = need;
-        }
+        XQ_TRY(ensure_l0_mfma(d, n));
+        const size_t need_sel = l0sel_elems(kpad);
         const long long plane_stride = (long long)H * kpad;
         const bool was_open = d->tail_open;
-        d->tail_open = false;                        // the split is a launch of its own, in front of the fused launch that is being assembled
-        {
+        d->tail_open = false;                        // launches of their own, in front of the fused launch that is being assembled
+        if (!d->l0_sel_done) {                       // (fused TD step of a net with >= 2 hidden layers: rode in the launch before this one)
+            ProfScope ps(d, "l0_sel_words", 0.0, (double)n * 48 + 2.0 * need_sel);
+            hipLaunchKernelGGL(l0_sel_kernel, dim3(kpad / 64), dim3(256), 0, d->cur, d->gboards, n, kpad, d->l0_sel);
+        }
+        if (!d->l0_split_done) {                     // (whole tiles: the delta product's epilogue wrote the planes)
             ProfScope ps(d, "l0_delta_split", 8.0 * n * H, (double)n * H * 4 + 6.0 * H * kpad);
             hipLaunchKernelGGL(delta_split_kernel, dim3(kpad / 64, H / 64), dim3(256), 0, d->cur, d->deltas[0], n, H, d->l0_planes, plane_stride, kpad);
         }
+        d->l0_sel_done = d->l0_split_done = false;
         d->tail_open = was_open;
         XQ_HIP(hipGetLastError());
-        const size_t shmem = l0m_lds_bytes(chunk);
-        const double fl = 2.0 * 96 * 16 * (double)H * kpad * 3, by = 6.0 * H * kpad * 4 + 48.0 * n * (H / 32) + 4.0 * nchunks * len;
+        const size_t shmem = l0m_lds_bytes();
+        const double fl = 2.0 * 96 * 16 * (double)H * kpad * 3, by = 6.0 * H * kpad + 2.0 * need_sel + 4.0 * nchunks * len;
         if (d->tail_open) {
             TailArgs& T = *d->tail;
-            T.l0_boards = d->gboards; T.l0_n = n; T.l0_H = H; T.l0_chunk = chunk; T.l0_nch = nchunks; T.l0_partial = out;
-            T.l0_planes = d->l0_planes; T.l0_plane_stride = plane_stride; T.l0_kpad = kpad; T.l0_ncb = H / kL0mCols;
+            T.l0_n = n; T.l0_H = H; T.l0_chunk = chunk; T.l0_nch = nchunks; T.l0_partial = out;
+            T.l0_sel = d->l0_sel; T.l0_planes = d->l0_planes; T.l0_plane_stride = plane_stride; T.l0_kpad = kpad; T.l0_ncb = H / kL0mCols;
             T.n_l0 = 4 * (H / kL0mCols) * nchunks;
             d->tail_flops += fl; d->tail_bytes += by;
             d->tail_lds = std::max(d->tail_lds, shmem);
         } else {
             ProfScope ps(d, "l0_grad_segsum", fl, by);
-            hipLaunchKernelGGL(l0_grad_mfma_kernel<0>, dim3(4, H / kL0mCols, nchunks), dim3(256), shmem, d->cur, d->gboards, d->l0_planes, plane_stride,
-                               kpad, n, H, chunk, out);
+            static bool granted = false;
+            if (!granted) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(l0_grad_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                granted = true;
+            }
+            hipLaunchKernelGGL(l0_grad_mfma_kernel<0>, dim3(4, H / kL0mCols, nchunks), dim3(256), shmem, d->cur, d->l0_sel, d->l0_planes, plane_stride,
+                               kpad, H, chunk, out);
             XQ_HIP(hipGetLastError());
         }
     } else {
@@ -1105,7 +1145,7 @@ int xq_dqn_destroy(xq_dqn* d) {
     hipFree(d->grads_td); hipFree(d->grads_full); hipFree(d->slabs); hipFree(d->bias_work); hipFree(d->xdense); hipFree(d->qfull); hipFree(d->tfull);
     hipFree(d->hb); hipFree(d->ha); hipFree(d->hr); hipFree(d->hd);
     d->prof.collect();
-    hipFree(d->slabs_l0); hipFree(d->l0_planes);
+    hipFree(d->slabs_l0); hipFree(d->l0_planes); hipFree(d->l0_sel);
     for (int i = 0; i < 2; ++i) { hipFree(d->params_bf[i]); hipFree(d->tacts_bf[i]); hipFree(d->t2acts_bf[i]); hipFree(d->t2acts[i]); }
     for (int l = 0; l < XQ_MAX_LAYERS; ++l) { hipFree(d->acts_bf[l]); hipFree(d->sel_acts_bf[l]); }
     hipFree(d->partial_idx);
@@ -1475,7 +1515,7 @@ static void tail_begin(xq_dqn* d) {
 static int tail_launch(xq_dqn* d, bool last, const char* name) {
     d->tail_open = false;
     const TailArgs& T = *d->tail;
-    const long long total = (long long)T.n_l0 + T.n_grad + T.n_delta + T.n_out + T.n_colsum;
+    const long long total = (long long)T.n_l0 + T.n_grad + T.n_delta + T.n_out + T.n_colsum + T.n_sel;
     if (total <= 0) return XQ_OK;
     ProfScope ps(d, name, d->tail_flops, d->tail_bytes);
     auto launch = [&](auto kern) {
@@ -1488,6 +1528,7 @@ static int tail_launch(xq_dqn* d, bool last, const char* name) {
     };
     if (last && T.l0_planes != nullptr) launch(td_tail_kernel<TAIL_L0 | TAIL_GRAD | TAIL_OUT | TAIL_COLSUM, true>);
     else if (last) launch(td_tail_kernel<TAIL_L0 | TAIL_GRAD | TAIL_OUT | TAIL_COLSUM>);
+    else if (T.n_sel) launch(td_tail_kernel<TAIL_GRAD | TAIL_DELTA | TAIL_OUT | TAIL_SEL>);
     else launch(td_tail_kernel<TAIL_GRAD | TAIL_DELTA | TAIL_OUT>);
     XQ_HIP(hipGetLastError());
     return XQ_OK;
@@ -1593,6 +1634,17 @@ static int tail_gradients_impl(xq_dqn* d, int n, float* const* outs, float* G, i
         if (defer_grad) { if (waiting >= 0) XQ_TRY(add_grad(waiting)); waiting = l + 1; }
         else XQ_TRY(add_grad(l + 1));
         if (l == nl - 3) add_out_grad();
+        if (l == 0 && l0_mfma_shape(d, n)) {
+            // the selector half-words of the minibatch's boards (operand of the matrix-pipe layer-0 gradient in the NEXT launch): they
+            // depend on the boards alone, so their blocks ride at the end of this grid, off the dependency chain
+            XQ_TRY(ensure_l0_mfma(d, n));
+            TailArgs& T = *d->tail;
+            const int chunk0 = l0_chunk_of(n), kpad = (n + chunk0 - 1) / chunk0 * chunk0;
+            T.sel_boards = d->gboards; T.sel_n = n; T.sel_kpad = kpad; T.sel_out = d->l0_sel; T.n_sel = kpad / 64;
+            d->tail_bytes += (double)n * 48 + 2.0 * l0sel_elems(kpad);
+            d->tail_lds = std::max(d->tail_lds, (size_t)64 * 13 * sizeof(uint32_t));
+            d->l0_sel_done = true;
+        }
         XQ_TRY(tail_launch(d, false, "td_tail_deltas"));
     }
     // last launch: the layer-0 sums and the bias column sums of every hidden delta (+ the output-layer sums of a net without a second
@@ -1617,6 +1669,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     if (d->nout() < 96) return fail(XQ_ERR_INVALID_ARGUMENT, "TD path needs >= 96 outputs (action.to indexes outputs 0..89)");
     if (mode == XQ_BACKPROP_REFERENCE) XQ_TRY(check_reference_topology(d));
     const bool dbl = td_net == XQ_TD_DOUBLE, bf = d->bf16();
+    d->l0_split_done = d->l0_sel_done = false;       // (set by this step's launches, consumed by l0_gradient)
     // Data-parallel step with more than one rank: the trainer's select chain (it waits for ev_qmax) starts behind the GRADIENTS
     // instead of behind the max pass, so that it runs beside the all-reduce — the exchange is then hidden behind work the step has to
     // do anyway, and the gradient kernels have the chip to themselves.  On one GPU there is nothing to hide behind and the early start

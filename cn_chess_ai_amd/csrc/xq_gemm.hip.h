@@ -108,6 +108,10 @@ struct GemmArgs {
     // EPI_HEAD: first 128 rows of the output layer's weights (row stride head_ldw = N), the slabs [N / 64][M][head_ld]
     const float* head_W; long long head_ldw; float* head_slabs; long long head_slab_stride; int head_ld;
     int libm_tanh;                // EPI_BIAS_TANH: libm's tanhf instead of tanh_hidden — the OUTPUT layer (the audited Q-values) keeps it
+    // EPI_DELTA, whole tiles only (M % 64 == 0, N % 64 == 0): besides C, the delta as three bf16 planes hi / mid / lo of 0.5 * delta (every
+    // residual exact), TRANSPOSED [plane][column n][sample m], rows `split_ld` samples apart — the operand of the matrix-pipe layer-0
+    // gradient (xq_l0grad.hip.h), written here instead of by a launch of its own that re-reads C
+    uint16_t* split_planes; long long split_plane_stride; int split_ld;
 };
 
 // ---- global -> register staging (4 x float4 per thread per operand) --------------------------------------------
@@ -518,6 +522,43 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g_in, int bx, int
                     if (EPI == EPI_BIAS_TANH && g.Cb) {
                         const int row = mb + (q & 3) + 8 * (q >> 2);
                         g.Cb[g.cb_frag ? scr_afrag_index(row, n, g.N) : (long long)row * g.ldcb + n] = bf16_bits(v);
+                    }
+                    if (EPI == EPI_DELTA) hv[q] = v;
+                }
+                if (EPI == EPI_DELTA && g.split_planes) {
+                    // this lane holds column n of 16 of the wave's 32 samples: m32 + {0..3, 8..11, 16..19, 24..27} + 4 h; its partner
+                    // lane ^ 32 holds the other 16.  Word w = samples (2 w, 2 w + 1) of the lane's 16; v_permlane32_swap on the word
+                    // pairs (0, 2), (1, 3), (4, 6), (5, 7) leaves the h = 0 lanes with sample octets 0 and 2 of the 32 and the h = 1
+                    // lanes with octets 1 and 3, each as four words in memory order: two 16-byte stores per plane and lane.
+                    const int m32 = m0 + wm * 32 * TM + i * 32;
+                    uint32_t w[3][8];
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        uint32_t pk[3] = {0u, 0u, 0u};
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float x = 0.5f * hv[q + e];        // x 0.5: the one-hot operand is 2.0 (xq_l0grad.hip.h)
+                            const uint16_t hi = bf16_bits(x);
+                            const float r1 = x - bf16_to_float(hi);   // exact: the residual of a round-to-nearest to 8 bits
+                            const uint16_t mid = bf16_bits(r1);
+                            const float r2 = r1 - bf16_to_float(mid); // exact, <= 8 significant bits left
+                            const uint16_t lo = bf16_bits(r2);
+                            pk[0] |= (uint32_t)hi << (16 * e); pk[1] |= (uint32_t)mid << (16 * e); pk[2] |= (uint32_t)lo << (16 * e);
+                        }
+                        w[0][q >> 1] = pk[0]; w[1][q >> 1] = pk[1]; w[2][q >> 1] = pk[2];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        uint4 o[2];
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(w[t][4 * half], w[t][4 * half + 2], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(w[t][4 * half + 1], w[t][4 * half + 3], false, false);
+                            o[half] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        }
+                        uint16_t* dst = g.split_planes + t * g.split_plane_stride + (long long)n * g.split_ld + m32 + 8 * h;
+                        *reinterpret_cast<uint4*>(dst) = o[0];           // octet h of the 32 samples
+                        *reinterpret_cast<uint4*>(dst + 16) = o[1];      // octet 2 + h
                     }
                 }
             }

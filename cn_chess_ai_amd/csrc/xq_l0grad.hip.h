@@ -1,57 +1,88 @@
-// xq_l0grad.hip.h — layer-0 weight gradient on the bf16 matrix pipe, exact in fp32:  gW0^T[(sq, piece)][col] = sum over the samples
-// that have `piece` on `sq` of delta0[sample][col]  (reference: updateWeightsBiasesKernel on layer 0, dqn.cu:310-319, fed by the
-// one-hot of chessai.cpp:268-289 — there one thread per neuron and a serial loop over the 1260 inputs, batch 1).
+// xq_l0grad.hip.h — layer-0 weight gradient on the bf16 matrix pipe, exact in fp32 (second form, round 5):
+//   gW0^T[(sq, piece)][col] = sum over the samples that have `piece` on `sq` of delta0[sample][col]
+// (reference: updateWeightsBiasesKernel on layer 0, dqn.cu:310-319, fed by the one-hot of chessai.cpp:268-289, batch 1).
 //
-// Why a matrix product after all.  The segmented-sum kernel (l0_grad_block, xq_dqn.hip) reads every 1-KB delta row once per occupied
-// square of its sample — ~30 times, 250 MB through L2 per 8192-sample step — and was the longest kernel of the step (38-45 us).  As a
-// dense product one-hot^T x delta0 every delta value is read once per GROUP of squares (15 groups of 6: 180 MB, 16-byte loads straight
-// into MFMA operand registers), and the 18 GFLOP it costs in bf16 are 7 us of the 2.5 PFLOP/s pipe.  Two things make that exact:
+// Why a matrix product.  The segmented-sum kernel (l0_grad_block, xq_l0.hip.h) reads every 1-KB delta row once per occupied square of
+// its sample — ~24 times, 200-250 MB through L2 per 8192-sample step — and was the longest kernel of the step (37-45 us).  As the dense
+// product one-hot^T x delta0 the 18 GFLOP it costs are ~7 us of the 2.5 PFLOP/s bf16 pipe.  Two things make that exact:
 //   * the one-hot operand is 0 / 1 — exact in bf16;
 //   * delta0 = hi + mid + lo with three bf16 values per fp32 (8 + 8 + 8 significant bits; each residual is formed exactly in fp32), so
 //     every product is exact and the MFMA accumulates in fp32: the result differs from a sequential fp32 sum only by summation order.
-// Round 2 tried this shape and measured 87.7 us (profiles/r02_e_onehot_mfma_experiment_*): it expanded the one-hot tile with VALU compares,
-// split delta0 inside the product kernel once per 64-row block, and had 184 blocks.  Here:
-//   * delta_split_kernel writes the three bf16 planes TRANSPOSED ([plane][column][sample]) once: an MFMA operand fragment (8 consecutive
-//     k = samples of one column) is then one 16-byte load per lane, 64 contiguous bytes per column and wave-instruction;
-//   * the one-hot fragment of (square, 8 samples) is derived in registers from ONE word: the block transposes its samples' piece codes
-//     into words of 8 nibbles per (square, sample octet); XOR with the lane's piece code replicated, two OR-folds and a mask leave one
-//     bit per matching sample, and two instructions per register move it to bit 14 of its half-word (= bf16 2.0; delta0 is halved by
-//     the split) — ~14 VALU per fragment instead of ~25 compares / selects (round 2) or 4 dependent LDS table reads (first version);
-//   * v_mfma_f32_16x16x32_bf16 with M = 16 columns of delta0, N = 16 planes of ONE square (14 used), K = 32 samples: the accumulator
-//     lane (plane n, columns 4g..4g+3) stores 16 contiguous bytes of row (sq*14 + n);
-//   * a wave owns RC x RS = 2 column tiles x 6 squares (48 accumulator registers); the four waves of a block take four groups of 6
-//     squares and the SAME 32 columns, whose delta operand tile (6 KB per k-step) goes global -> registers -> LDS once per block:
-//     50 MB through L2 per step instead of 180-250 (the first version, every wave loading its own operands, ran at L2 speed:
-//     33 us).  Grid 4 square groups x H/32 column blocks x n/1024 sample chunks = 256 blocks at 8192 x 256 — the chunk count (and
-//     with it the 10.3 MB of partial sums the SGD kernel adds in fixed order) stays what it was.
+// v_mfma_f32_16x16x32_bf16 with M = 16 columns of delta0, N = 16 planes of ONE square (14 used), K = 32 samples; a wave owns 2 column
+// tiles x 6 squares (12 accumulators); the four waves of a block take four groups of 6 squares and the SAME 32 columns, whose operand
+// tile goes global -> LDS once per block (50 MB through L2 per step).  Grid 4 square groups x H/32 column blocks x n/1024 chunks.
+// The first form (round 4; 28.7 us alone at 8192 x 256, profiles/r04_g_*) derived the one-hot operand from nibble code words in
+// registers; its loop was ISSUE-bound, not matrix-pipe-bound: per 32-sample k-step and wave 36 MFMAs (576 cycles) sat beside ~180
+// vector instructions — 78 to derive six one-hot fragments (13 each), ~80 accumulator-register moves the compiler made of rotating
+// operand registers — 1360 cycles measured, and every block opened with a 6-us transposition of its boards.  Here
+//   * the one-hot operand is ONE v_perm_b32 per register.  A pre-pass (l0_sel_block) writes, per (square, sample), two 16-bit
+//     "selector" half-words: (piece, 0) << 8 for pieces 1..7 (encoding 0) and (piece - 7) << 8 for pieces 8..14 (encoding 1), 0 otherwise.
+//     v_perm_b32 picks every result byte out of an 8-byte per-lane table by a selector byte: lane n (plane n of a square: encoding
+//     n >= 7, index n + 1 or n - 6) holds the table "0x40 at my index, 0 elsewhere", so a word of two selector half-words becomes two bf16
+//     values 0x4000 (= 2.0; delta0 is halved by the split, exactly) or 0 in one instruction: 4 per fragment instead of 13;
+//   * the selector words travel like the delta tile: global -> LDS by LDS-DMA, [square][k-octet][encoding][8 samples] so that a
+//     fragment is one conflict-free ds_read_b128 — the block has no transposition prologue (6 of the old kernel's 28 us);
+//   * 64 samples per barrier (two MFMA k-steps), a ring of three stages, every fragment read issued one k-step ahead of its MFMAs.
+// Per k-step and wave: 36 MFMAs, 24 v_perm, 12 ds_read_b128.
 #pragma once
 
 #include "xq_gemm.hip.h"
 
-#ifndef XQ_L0M_SCHED
-#define XQ_L0M_SCHED 0
-#endif
-
 namespace xq {
 
-constexpr int kL0mRS = 6;              // squares per wave tile
-constexpr int kL0mRC = 2;              // 16-column tiles per wave
-constexpr int kL0mSqB = 4 * kL0mRS;    // squares per block (4 waves): 24 = three board words; 4 groups cover squares 0..95 (90..95: padding)
-constexpr int kL0mCols = 16 * kL0mRC;  // columns per block: 32 — the block's four waves share the SAME delta operand tile through LDS
-constexpr int kL0mStageB = 3 * kL0mCols * 64;             // 6144 bytes per k-step stage: six 1-KB LDS-DMA pieces = (plane, 16 columns) x 32 k
-constexpr int kL0mStages = 3;          // operand ring: two k-steps stay in flight across the barrier
+constexpr int kL0mRS = 6;                 // squares per wave
+constexpr int kL0mRC = 2;                 // 16-column tiles per wave
+constexpr int kL0mSqB = 4 * kL0mRS;        // squares per block: 24; 4 groups cover squares 0..95 (90..95: empty)
+constexpr int kL0mCols = 16 * kL0mRC;      // columns per block: 32
+constexpr int kL0mStageK = 64;            // samples per stage
+constexpr int kL0mAPieces = 2 * 3 * kL0mRC;            // (k-step, plane, 16-column tile) x 1 KB = 16 columns x 32 k
+constexpr int kL0mSPieces = 2 * 3;                    // (k-step, 8 squares) x 1 KB = 8 squares x 4 octets x 2 encodings x 16 B
+constexpr int kL0mStageB = (kL0mAPieces + kL0mSPieces) * 1024;
+constexpr int kL0mStages = 3;
+constexpr int kL0mSelSquares = 96;
 
-// (the code words of one k-step beyond the chunk exist and are zero: the pipelined loop reads one k-step ahead without a branch)
-__host__ __device__ constexpr size_t l0m_lds_bytes(int chunk) {
-    return (size_t)kL0mStages * kL0mStageB + (size_t)kL0mSqB * (chunk / 8 + 4) * 4;
-}
-// bf16 elements the three planes need: [3][H][kpad] + slack for the operand prefetch that runs (harmlessly) past the last k-step
+// bf16 elements the three planes need: [3][H][kpad] + slack for the stages that are prefetched (harmlessly) past the last chunk
 __host__ __device__ constexpr size_t l0m_plane_elems(int H, int kpad) { return (size_t)3 * H * kpad + 8 * 32 + 64; }
+__host__ __device__ constexpr size_t l0m_lds_bytes() { return (size_t)kL0mStages * kL0mStageB; }
+// u16 elements of the selector array [96][kpad / 8][2][8] + slack for the stage that is prefetched (harmlessly) past the last chunk
+__host__ __device__ constexpr size_t l0sel_elems(int kpad) { return (size_t)kL0mSelSquares * kpad * 2 + 1024; }
 
-// delta0 [n][H] fp32 -> planes[t][col][k] bf16 (t = hi, mid, lo), k padded with zeros to kpad (a multiple of 64).
-// 64 x 64 tiles through LDS: coalesced 16-byte reads along the columns, 32-byte writes along k.
+// selector half-words of 64 consecutive samples (block `blk`): boards [n][12] packed nibbles -> sel[sq][octet][enc][8]
+__device__ __forceinline__ void l0_sel_block(const uint32_t* __restrict__ gboards, int n, int kpad, uint16_t* __restrict__ sel, int blk,
+                                             uint32_t* __restrict__ bw /* LDS [64][13] */) {
+    const int tid = (int)threadIdx.x, b0 = blk * 64;
+    for (int i = tid; i < 64 * kBoardWords; i += 256) {
+        const int s = i / kBoardWords, w = i - s * kBoardWords;
+        bw[s * 13 + w] = b0 + s < n ? gboards[(long long)(b0 + s) * kBoardWords + w] : 0u;
+    }
+    __syncthreads();
+    const int octs = kpad >> 3;
+    for (int p = tid; p < kL0mSelSquares * 16; p += 256) {            // piece = (square, octet of the block, encoding): 16 bytes
+        const int sq = p >> 4, oct = (p >> 1) & 7, enc = p & 1;
+        const int wd = sq >> 3, sh = 4 * (sq & 7);
+        uint32_t o[4];
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t c = (bw[(oct * 8 + 2 * i2 + e) * 13 + wd] >> sh) & 15u;
+                const uint32_t idx = enc ? (c >= 8u ? c - 7u : 0u) : (c <= 7u ? c : 0u);
+                v |= idx << (8 + 16 * e);
+            }
+            o[i2] = v;
+        }
+        *reinterpret_cast<uint4*>(sel + (((long long)sq * octs + (b0 >> 3) + oct) * 2 + enc) * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+__global__ __launch_bounds__(256) void l0_sel_kernel(const uint32_t* __restrict__ gboards, int n, int kpad, uint16_t* __restrict__ sel) {
+    __shared__ uint32_t bw[64 * 13];
+    l0_sel_block(gboards, n, kpad, sel, (int)blockIdx.x, bw);
+}
+
+// delta0 [n][H] fp32 -> planes[t][col][k] bf16 (t = hi, mid, lo of 0.5 * delta0), k in natural order, zero-padded to kpad (multiple of 64)
 __device__ __forceinline__ void delta_split_block(const float* __restrict__ d0, int n, int H, uint16_t* __restrict__ planes,
-                                                  long long plane_stride, int kpad, int tile_k, int tile_c, float* __restrict__ tile /* [64][65] */) {
+                                                   long long plane_stride, int kpad, int tile_k, int tile_c, float* __restrict__ tile /* [64][65] */) {
     const int tid = (int)threadIdx.x;
     const int k0 = tile_k * 64, c0 = tile_c * 64;
     {
@@ -70,20 +101,16 @@ __device__ __forceinline__ void delta_split_block(const float* __restrict__ d0, 
     uint32_t w[3][8];
 #pragma unroll
     for (int j = 0; j < 16; j += 2) {
-        uint32_t pk[3];
-        // order inside an octet of samples: word i of the 16-byte fragment = samples (i, i + 4) — the order in which
-        // l0_grad_mfma_block derives the one-hot operand from a word of 8 nibbles with two instructions per register
-        const int oct = j & 8, i2 = (j & 7) >> 1;
+        uint32_t pk[3] = {0u, 0u, 0u};
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float v = tile[(kq + oct + i2 + 4 * e) * 65 + col];
-            const uint16_t hi = bf16_bits(0.5f * v);             // x 0.5: the one-hot operand is 2.0 (one bit per half-word), see below
+            const float v = tile[(kq + j + e) * 65 + col];
+            const uint16_t hi = bf16_bits(0.5f * v);             // x 0.5: the one-hot operand is 2.0 (bit 14 of a half-word)
             const float r1 = 0.5f * v - bf16_to_float(hi);       // exact: the residual of a round-to-nearest to 8 bits
             const uint16_t mid = bf16_bits(r1);
             const float r2 = r1 - bf16_to_float(mid);            // exact, <= 8 significant bits left
             const uint16_t lo = bf16_bits(r2);
-            if (e == 0) { pk[0] = hi; pk[1] = mid; pk[2] = lo; }
-            else { pk[0] |= (uint32_t)hi << 16; pk[1] |= (uint32_t)mid << 16; pk[2] |= (uint32_t)lo << 16; }
+            pk[0] |= (uint32_t)hi << (16 * e); pk[1] |= (uint32_t)mid << (16 * e); pk[2] |= (uint32_t)lo << (16 * e);
         }
         w[0][j >> 1] = pk[0]; w[1][j >> 1] = pk[1]; w[2][j >> 1] = pk[2];
     }
@@ -94,150 +121,176 @@ __device__ __forceinline__ void delta_split_block(const float* __restrict__ d0, 
         o[1] = make_uint4(w[t][4], w[t][5], w[t][6], w[t][7]);
     }
 }
-
 __global__ __launch_bounds__(256) void delta_split_kernel(const float* __restrict__ d0, int n, int H, uint16_t* __restrict__ planes,
-                                                          long long plane_stride, int kpad) {
+                                                           long long plane_stride, int kpad) {
     __shared__ float tile[64 * 65];
     delta_split_block(d0, n, H, planes, plane_stride, kpad, (int)blockIdx.x, (int)blockIdx.y, tile);
 }
 
-// One block: square group `sqg` (24 squares = board words 3 sqg .. 3 sqg + 2), column block `cb` (32 columns), sample chunk `ch`.
-// smem: l0m_lds_bytes(chunk).  partial: [chunks][1260][H].  Wave w owns squares 24 sqg + 6 w .. + 5 and all 32 columns.
+// One block: square group `sqg` (24 squares), column block `cb` (32 columns), sample chunk `ch` (`chunk` samples, a multiple of 64).
+// smem: l0m_lds_bytes(), 1-KB aligned.  partial: [chunks][1260][H].  Wave w owns squares 24 sqg + 6 w .. + 5 and all 32 columns.
 template <int DBG = 0>
-__device__ __forceinline__ void l0_grad_mfma_block(const uint32_t* __restrict__ gboards, const uint16_t* __restrict__ planes,
-                                                   long long plane_stride, int kpad, int n, int H, int chunk, float* __restrict__ partial,
-                                                   int sqg, int cb, int ch, uint32_t* __restrict__ smem) {
-    const int octs = chunk / 8, ocs = octs + 4;                  // ocs: row stride of `codes` (one spare k-step of zeros)
-    unsigned char* stage = reinterpret_cast<unsigned char*>(smem);                     // [3 stages][6 pieces][1 KB] (1-KB aligned)
-    uint32_t* codes = smem + kL0mStages * kL0mStageB / 4;        // [24][ocs]: 8 nibbles = the piece codes of 8 consecutive samples
+__device__ __forceinline__ void l0_grad_mfma_block(const uint16_t* __restrict__ sel, const uint16_t* __restrict__ planes,
+                                                    long long plane_stride, int kpad, int H, int chunk, float* __restrict__ partial,
+                                                    int sqg, int cb, int ch, unsigned char* __restrict__ smem) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, g = lane >> 4;
-    const int c0 = ch * chunk;
-    if (tid < kL0mSqB * 4) codes[(tid >> 2) * ocs + octs + (tid & 3)] = 0u;
-    // piece codes, transposed: item = (sample octet, board word) -> the 8 x 8 nibble block of 8 samples x 8 squares, one code word per square
-    for (int idx = tid; idx < 3 * octs; idx += 256) {
-        const int wd = idx / octs, oq = idx - wd * octs;
-        uint32_t bw[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {                            // (unconditional, clamped: eight independent loads in flight)
-            const int bsmp = c0 + oq * 8 + u;
-            bw[u] = gboards[(long long)min(bsmp, n - 1) * kBoardWords + 3 * sqg + wd];
-            if (bsmp >= n) bw[u] = 0;
-        }
-#pragma unroll
-        for (int sq8 = 0; sq8 < 8; ++sq8) {
-            uint32_t wv = 0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) wv |= ((bw[u] >> (4 * sq8)) & 15u) << (4 * u);
-            codes[(wd * 8 + sq8) * ocs + oq] = wv;
-        }
-    }
-    // ---- delta operand: global -> LDS by LDS-DMA (global_load_lds_dwordx4: no register round trip), three k-steps deep ----------------
-    // A piece = 1 KB = (plane t, 16 columns) x 32 k: lane L of the DMA carries the 16 bytes (8 k) of column L >> 2, k-octet
-    // (L & 3) ^ f(column), f(col) = (col >> 1) & 3 — the XOR sits on the SOURCE address, the LDS image is written linearly; a fragment
-    // read of 8 lanes (one k-octet, 8 columns) then touches 8 different 16-byte bank groups: conflict-free ds_read_b128.
-    // Every wave issues two pieces per k-step (6 pieces: waves 2 and 3 repeat their first one — same bytes to the same place), so
-    // that one vmcnt constant serves all of them.
-    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)stage);
-    const int pc0 = wid, pc1 = wid + 4 < 6 ? wid + 4 : wid;
-    unsigned voff[2];
+    const int c0 = ch * chunk, octs = kpad >> 3;
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+    // ---- LDS-DMA: 18 pieces of 1 KB per stage; wave w issues pieces w, w + 4, w + 8 (delta tiles), w + 12 and 16 + (w & 1) (selectors:
+    // waves 2 and 3 repeat the last piece of waves 0 and 1 — same bytes to the same place — so that one vmcnt constant serves all) -----
+    // delta piece (kk, t, c16): lane L carries the 16 bytes (8 k) of column L >> 2, k-octet (L & 3) ^ f(column), f(col) = (col >> 1) & 3
+    // — the XOR sits on the SOURCE address, the LDS image is linear; a fragment read then touches 8 different 16-byte bank groups.
+    // selector piece (kk, q): lane L carries square 8 q + (L >> 3), k-octet (L >> 1) & 3, encoding L & 1: the LDS image of a square is
+    // 128 contiguous bytes [octet][encoding][8 samples].
+    unsigned voff[5];
+    int piece[5];
     {
         const int col = lane >> 2, kq = (lane & 3) ^ ((col >> 1) & 3);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int pc = q ? pc1 : pc0, t = pc >> 1, c16 = pc & 1;
-            voff[q] = (unsigned)((t * plane_stride + (long long)(cb * kL0mCols + c16 * 16 + col) * kpad + c0 + kq * 8) * 2);
+        for (int i = 0; i < 3; ++i) {
+            const int p = wid + 4 * i, kk = p / 6, r = p - 6 * kk, t = r >> 1, c16 = r & 1;
+            piece[i] = p;
+            voff[i] = (unsigned)((t * plane_stride + (long long)(cb * kL0mCols + c16 * 16 + col) * kpad + c0 + kk * 32 + kq * 8) * 2);
+        }
+#pragma unroll
+        for (int i = 3; i < 5; ++i) {
+            const int sp = i == 3 ? wid : 4 + (wid & 1), kk = sp / 3, q = sp - 3 * kk;
+            piece[i] = kL0mAPieces + sp;
+            const int sq = sqg * kL0mSqB + q * 8 + (lane >> 3), gg = (lane >> 1) & 3, enc = lane & 1;
+            voff[i] = (unsigned)((((long long)sq * octs + (c0 >> 3) + kk * 4 + gg) * 2 + enc) * 16);
         }
     }
-    const unsigned char* pbase = reinterpret_cast<const unsigned char*>(planes);
-    auto issue = [&](int ks, unsigned st_off) {
+    const unsigned char* pA = reinterpret_cast<const unsigned char*>(planes);
+    const unsigned char* pS = reinterpret_cast<const unsigned char*>(sel);
+    // one 1-KB piece of stage `st` into the ring buffer at byte offset buf_off (i = which of the wave's five)
+    auto issue1 = [&](int st, unsigned buf_off, int i) {
         unsigned keep;
-        const unsigned char* base = pbase + (long long)ks * 64;
-        const unsigned l0 = lds0 + st_off + (unsigned)pc0 * 1024u, l1 = lds0 + st_off + (unsigned)pc1 * 1024u;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-            "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff[0]), "v"(voff[1]), "s"(base), "s"(l0), "s"(l1)
-            : "memory");
+        const unsigned char* base = i < 3 ? pA + (long long)st * (kL0mStageK * 2) : pS + (long long)st * (kL0mStageK / 8 * 32);
+        const unsigned l = lds0 + buf_off + (unsigned)piece[i] * 1024u;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[i]), "s"(base), "s"(l) : "memory");
+    };
+    auto issue = [&](int st, unsigned buf_off) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) issue1(st, buf_off, i);
     };
     issue(0, 0u);
-    issue(1, (unsigned)kL0mStageB);
     f32x4 acc[kL0mRC][kL0mRS];
 #pragma unroll
     for (int c = 0; c < kL0mRC; ++c)
 #pragma unroll
         for (int j = 0; j < kL0mRS; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");             // this wave's pieces of k-step 0 have landed
-    __syncthreads();                                             // ... and everybody's; the code words are complete
-    const uint32_t* crow = codes + (wid * kL0mRS) * ocs + g;
-    // one-hot fragment of (square j, 8 samples) for this lane's plane (piece code m + 1) from the word of 8 nibbles, in registers: XOR
-    // with the code replicated makes the matching nibbles zero; OR-folding each nibble onto its bit 0 and inverting leaves bit 4u set
-    // iff sample u matches; register i of the fragment holds samples (i, i + 4), so it is ((match << (14 - 4 i)) & 0x40004000): bit 14
-    // of a half-word = the bf16 value 2.0 (delta0 was halved by the split, exactly).  ~14 VALU, no LDS — the first version looked the
-    // half-words up in a 16-KB LDS table (4 dependent ds_reads per fragment: 5 us of a 27-us kernel).
-    const uint32_t code8 = (uint32_t)(m + 1) * 0x11111111u;
-    auto onehot = [&](uint32_t wv) {
-        uint32_t x = wv ^ code8;
-        x |= x >> 1;
-        x |= x >> 2;
-        const uint32_t match = ~x & 0x11111111u;
-        const f32x4 bw = {__builtin_bit_cast(float, (match << 14) & 0x40004000u), __builtin_bit_cast(float, (match << 10) & 0x40004000u),
-                          __builtin_bit_cast(float, (match << 6) & 0x40004000u), __builtin_bit_cast(float, (match << 2) & 0x40004000u)};
-        return __builtin_bit_cast(bf16x8, bw);
-    };
-    const int ksteps = DBG == 1 ? 0 : chunk / 32;
-    bf16x8 b[kL0mRS], bn[kL0mRS];
-    uint32_t wn[kL0mRS];
+    // per-lane table of v_perm_b32: byte `idx` of the 8-byte table {S0 : S1} = 0x40 (the high byte of bf16 2.0); selector 0 (empty
+    // square, a piece of the other encoding, every LOW byte of a half-word) picks byte 0 = 0.  Lane n is plane n of its squares (the
+    // MFMA's N index): planes 0..6 = pieces 1..7 (encoding 0, index n + 1), planes 7..13 = pieces 8..14 (encoding 1, index n - 6);
+    // lanes 14 and 15 have index 8: an all-zero table.
+    const int enc = m >= 7 ? 1 : 0;
+    const int idx = m >= 14 ? 8 : (enc ? m - 6 : m + 1);
+    const uint32_t tlo = idx < 4 ? 0x40u << (8 * idx) : 0u, thi = (idx >= 4 && idx < 8) ? 0x40u << (8 * (idx - 4)) : 0u;
+    // fragment offsets inside a stage
+    const unsigned aoff = (unsigned)(m * 64 + ((g ^ ((m >> 1) & 3)) << 4));
+    unsigned soff[kL0mRS];
 #pragma unroll
-    for (int j = 0; j < kL0mRS; ++j) b[j] = onehot(crow[j * ocs]);
-    // fragment of (column tile c, plane t) inside a stage: piece 2 t + c, row m (64 B), k-octet g at slot g ^ f(m)
-    const unsigned foff = (unsigned)(m * 64 + ((g ^ ((m >> 1) & 3)) << 4));
-    // One barrier per k-step; no branch in the loop body: the DMA of the last two k-steps runs past the chunk into memory that exists
-    // (the next column's samples / the slack behind the planes) and lands in stages nobody reads any more; drained behind the loop.
-    unsigned st_rd = 0u, st_wr = 2u * kL0mStageB;
-    for (int ks = 0; ks < ksteps; ++ks) {
-        if (DBG != 4) issue(ks + 2, st_wr);                      // -> the stage read during k-step ks - 1 (everybody is past that barrier)
-#pragma unroll
-        for (int j = 0; j < kL0mRS; ++j) wn[j] = crow[j * ocs + (ks + 1) * 4];
-        bf16x8 a[kL0mRC][3];
-        const unsigned char* sp = stage + st_rd + foff;
-#pragma unroll
-        for (int c = 0; c < kL0mRC; ++c)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) a[c][t] = *reinterpret_cast<const bf16x8*>(sp + (2 * t + c) * 1024);
-        // issue order: a dependent MFMA (same accumulator) comes 12 MFMAs later, not 2 — the pipe never waits for its own result
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int j = 0; j < kL0mRS; ++j) {
-#pragma unroll
-                for (int c = 0; c < kL0mRC; ++c) {
-                    if (DBG != 2) acc[c][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[c][t], b[j], acc[c][j], 0, 0, 0);
-                    else { acc[c][j][0] += (float)a[c][t][0] * (float)b[j][0]; }
-                }
-                if (t == 0) bn[j] = DBG == 3 ? __builtin_bit_cast(bf16x8, f32x4{__builtin_bit_cast(float, wn[j]), 0.f, 0.f, 0.f}) : onehot(wn[j]);
-            }
-#if XQ_L0M_SCHED
-        // one MFMA, then up to three of the one-hot's VALU instructions, 36 times: the VALU work rides in the MFMAs' issue gaps
-        // instead of stretching the first 12 of them
-#pragma unroll
-        for (int i = 0; i < 3 * kL0mRS * kL0mRC; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-        }
-#endif
-#pragma unroll
-        for (int j = 0; j < kL0mRS; ++j) b[j] = bn[j];
-        st_rd = st_rd + kL0mStageB == kL0mStages * kL0mStageB ? 0u : st_rd + kL0mStageB;
-        st_wr = st_wr + kL0mStageB == kL0mStages * kL0mStageB ? 0u : st_wr + kL0mStageB;
-        if (DBG != 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");         // k-step ks + 1 has landed (this wave's pieces)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every fragment read of this stage has returned
-        __builtin_amdgcn_s_barrier();
+    for (int j = 0; j < kL0mRS; ++j) {
+        const int sqw = wid * kL0mRS + j;
+        soff[j] = (unsigned)((kL0mAPieces + (sqw >> 3)) * 1024 + (sqw & 7) * 128 + g * 32 + enc * 16);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no DMA may still be writing LDS when the block ends
+    // ---- the loop: ONE barrier per 64-sample stage, placed in the middle of the stage ------------------------------------------------
+    // Stage st's fragments are read one k-step ahead of their MFMAs: k-step 1's at the top of the stage (under k-step 0's MFMAs),
+    // k-step 0's of stage st + 1 right behind the barrier in the middle of stage st (under k-step 1's MFMAs) — no MFMA ever waits for
+    // an LDS read issued just before it.  Ring of three stages: the DMA of stage st + 2 is issued at the top of stage st into the
+    // buffer stage st - 1 was read from; every wave's last read of that buffer (k-step 1 of stage st - 1, requested at the top of that
+    // stage) returned before the barrier in the middle of stage st - 1.
+    struct Frags { bf16x8 a[kL0mRC][3]; uint4 sw[kL0mRS]; };
+    // the 12 fragment reads of a k-step in the order their consumers come: selector word of square 0 (the previous k-step's last group
+    // turns it into a one-hot), then plane by plane
+    auto read_frag = [&](Frags& f, unsigned boff, int kk, int i) {
+        const unsigned char* sp = smem + boff;
+        constexpr int kind[12] = {0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 0, 0};      // 0: selector word, 1: delta fragment
+        constexpr int arg[12] = {0, 0, 1, 1, 2, 3, 2, 4, 5, 3, 4, 5};       // square j, or t * 2 + c
+        if (kind[i] == 0) f.sw[arg[i]] = *reinterpret_cast<const uint4*>(sp + kk * 3 * 1024 + soff[arg[i]]);
+        else f.a[arg[i] & 1][arg[i] >> 1] = *reinterpret_cast<const bf16x8*>(sp + (kk * 6 + arg[i]) * 1024 + aoff);
+    };
+    auto read_frags = [&](Frags& f, unsigned boff, int kk) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) read_frag(f, boff, kk, i);
+    };
+    auto onehot2 = [&](uint32_t x, uint32_t y, uint32_t& ox, uint32_t& oy) {
+        if (DBG == 3 || DBG == 6) { ox = x; oy = y; }
+        else { ox = __builtin_amdgcn_perm(thi, tlo, x); oy = __builtin_amdgcn_perm(thi, tlo, y); }
+    };
+    // one k-step: 6 groups (squares) x 3 MFMA pairs (planes) on the wave's 12 accumulators.  Between the pairs, pinned there by
+    // sched_barrier: the one-hot operand of the NEXT group (v_perm_b32 x 2 per pair; the next square of this k-step, or square 0 of
+    // `nxt`), and side(pair) — ONE of the next k-step's fragment reads or ONE LDS-DMA piece.  An MFMA holds the vector issue for 8 of its
+    // 16 cycles, so a pair has room for ~16 cycles of other instructions; left alone hipcc puts a k-step's 24 v_perm, its 12 reads and
+    // the DMA in front of its 36 MFMAs, and with one wave per SIMD the matrix pipe idles through all of it.
+    // The MFMAs are asm statements with the accumulators tied in place ("+v"): left to the register allocator they came out of the
+    // loop body in rotated registers, 68 v_accvgpr moves per iteration.  hipcc pads no hazards inside asm: every one-hot fragment is
+    // written >= 2 MFMAs before the MFMA that reads it, except the very first of the block (s_nop 1 below).
+    auto kstep = [&](const Frags& f, const Frags& nxt, uint4& o, auto&& side) {
+#pragma unroll
+        for (int j = 0; j < kL0mRS; ++j) {
+            const bf16x8 b = __builtin_bit_cast(bf16x8, o);
+            const uint4 nx = j + 1 < kL0mRS ? f.sw[j + 1] : nxt.sw[0];
+            uint4 on;
+            if (DBG == 2) {                                      // no MFMAs: their operands stay alive, nothing else changes
+                asm volatile("" : "+v"(acc[0][j]), "+v"(acc[1][j]) : "v"(f.a[0][0]), "v"(f.a[1][0]), "v"(f.a[0][1]), "v"(f.a[1][1]), "v"(f.a[0][2]), "v"(f.a[1][2]), "v"(b));
+                onehot2(nx.x, nx.y, on.x, on.y); onehot2(nx.z, nx.w, on.z, on.w);
+                side(3 * j); side(3 * j + 1); side(3 * j + 2);
+            } else {
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %4, %1"
+                             : "+v"(acc[0][j]), "+v"(acc[1][j]) : "v"(f.a[0][0]), "v"(f.a[1][0]), "v"(b));
+                onehot2(nx.x, nx.y, on.x, on.y);
+                side(3 * j);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %4, %1"
+                             : "+v"(acc[0][j]), "+v"(acc[1][j]) : "v"(f.a[0][1]), "v"(f.a[1][1]), "v"(b));
+                onehot2(nx.z, nx.w, on.z, on.w);
+                side(3 * j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %4, %1"
+                             : "+v"(acc[0][j]), "+v"(acc[1][j]) : "v"(f.a[0][2]), "v"(f.a[1][2]), "v"(b));
+                side(3 * j + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            o = on;
+        }
+    };
+    const int nst = DBG == 1 ? 0 : chunk / kL0mStageK;
+    issue(1, (unsigned)kL0mStageB);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");             // stage 0 has landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                                // ... and everybody's
+    asm volatile("" ::: "memory");
+    Frags f0, f1;
+    read_frags(f0, 0u, 0);
+    if (DBG == 6) read_frags(f1, 0u, 1);
+    uint4 o;
+    onehot2(f0.sw[0].x, f0.sw[0].y, o.x, o.y);
+    onehot2(f0.sw[0].z, f0.sw[0].w, o.z, o.w);
+    asm volatile("s_nop 1" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
+    unsigned b_cur = 0u, b_nxt = (unsigned)kL0mStageB, b_far = 2u * kL0mStageB;
+    for (int st = 0; st < nst; ++st) {
+        // (the last two stages request 64 / 128 samples past the chunk — the next chunk, the next column or the slack behind the arrays —
+        // into buffers nobody reads any more)
+        kstep(f0, f1, o, [&](int p) {
+            if (DBG == 6) return;
+            if (p < 12) read_frag(f1, b_cur, 1, p);
+            else if (p < 17 && DBG != 4) issue1(st + 2, b_far, p - 12);
+        });
+        if (DBG != 4 && DBG != 6) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");        // stage st + 1 has landed (this wave's pieces)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // my reads of stage st have returned
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        kstep(f1, f0, o, [&](int p) {
+            if (DBG == 6) return;
+            if (p < 12) read_frag(f0, b_nxt, 0, p);
+        });
+        const unsigned t = b_cur; b_cur = b_nxt; b_nxt = b_far; b_far = t;
+    }
+    // no DMA may still be writing LDS when the block ends; and the last MFMAs' results need 8+ wait states before anything but an
+    // accumulating MFMA reads them (hipcc does not know the statements above were MFMAs)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
     // D: lane (n = lane & 15, g): plane n of every square, columns 16 c + 4 g .. + 3 of the block's 32
     if (m < 14) {
         float* out = partial + ((long long)ch * kStateSize) * H;
@@ -255,11 +308,10 @@ __device__ __forceinline__ void l0_grad_mfma_block(const uint32_t* __restrict__ 
 }
 
 template <int DBG = 0>
-__global__ __launch_bounds__(256) void l0_grad_mfma_kernel(const uint32_t* __restrict__ gboards, const uint16_t* __restrict__ planes,
-                                                           long long plane_stride, int kpad, int n, int H, int chunk,
-                                                           float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t l0m_smem[];
-    l0_grad_mfma_block<DBG>(gboards, planes, plane_stride, kpad, n, H, chunk, partial, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, l0m_smem);
+__global__ __launch_bounds__(256) void l0_grad_mfma_kernel(const uint16_t* __restrict__ sel, const uint16_t* __restrict__ planes,
+                                                            long long plane_stride, int kpad, int H, int chunk, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char l0m_smem[];
+    l0_grad_mfma_block<DBG>(sel, planes, plane_stride, kpad, H, chunk, partial, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, l0m_smem);
 }
 
 }  // namespace xq

@@ -482,15 +482,17 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(ColsumJobs J) {   // 
 // weight-gradient GEMM of the layer above it and, first time round, the output-layer segmented sum.  Launch 2: the layer-0
 // segmented sum + the bias column sums.  Long blocks come first in the grid.  Every body is the block function of the stand-alone
 // kernel, so the results are bitwise those of the two-stream path (tests/test_dqn_gpu.py).
-enum { TAIL_DELTA = 1, TAIL_GRAD = 2, TAIL_OUT = 4, TAIL_COLSUM = 8, TAIL_L0 = 16 };
+enum { TAIL_DELTA = 1, TAIL_GRAD = 2, TAIL_OUT = 4, TAIL_COLSUM = 8, TAIL_L0 = 16, TAIL_SEL = 32 };
 struct TailArgs {
-    // grid order: [l0][grad][delta][out][colsum]; n_* = blocks of each part (0 = absent)
-    int n_l0, n_grad, n_delta, n_out, n_colsum;
+    // grid order: [l0][grad][delta][out][colsum][sel]; n_* = blocks of each part (0 = absent)
+    int n_l0, n_grad, n_delta, n_out, n_colsum, n_sel;
     GemmArgs grad;  int grad_gx, grad_gy;          // 64x64 tiles: grid (gx, gy, splits)
     GemmArgs delta; int delta_gx;                  // grid (gx, gy, 1)
     const int32_t* og_act; const float* og_dsc; const float* og_alast; int og_n, og_H, og_chunk; float* og_partial;   // grid (24, chunks)
     const uint32_t* l0_boards; const float* l0_delta; int l0_n, l0_H, l0_HS, l0_chunk, l0_nsets, l0_nch; float* l0_partial;   // (90, nch, H / HS)
     const uint16_t* l0_planes; long long l0_plane_stride; int l0_kpad, l0_ncb;      // != nullptr: the matrix-pipe form, grid (4, H / 32, nch)
+    const uint16_t* l0_sel;                        // ... and its selector half-words (xq_l0grad.hip.h)
+    const uint32_t* sel_boards; int sel_n, sel_kpad; uint16_t* sel_out;             // TAIL_SEL: those half-words being made, 64 samples per block
     ColsumJobs cj; int cj_gx, cj_gy;               // grid (gx, R, njobs)
 };
 // L0MFMA: the layer-0 blocks are the matrix-pipe form (xq_dqn_set_l0_grad_mode(1)) — an instantiation of its own: that body needs 180
@@ -505,8 +507,8 @@ __global__ __launch_bounds__(256) void td_tail_kernel(const TailArgs a) {
         if (b < a.n_l0) {
             if (L0MFMA) {
                 const int rest = b >> 2;
-                l0_grad_mfma_block<0>(a.l0_boards, a.l0_planes, a.l0_plane_stride, a.l0_kpad, a.l0_n, a.l0_H, a.l0_chunk, a.l0_partial, b & 3,
-                                      rest % a.l0_ncb, rest / a.l0_ncb, reinterpret_cast<uint32_t*>(tail_smem));
+                l0_grad_mfma_block<0>(a.l0_sel, a.l0_planes, a.l0_plane_stride, a.l0_kpad, a.l0_H, a.l0_chunk, a.l0_partial, b & 3,
+                                       rest % a.l0_ncb, rest / a.l0_ncb, reinterpret_cast<unsigned char*>(tail_smem));
                 return;
             }
             const int per = kSquares * a.l0_nch;
@@ -541,7 +543,12 @@ __global__ __launch_bounds__(256) void td_tail_kernel(const TailArgs a) {
         if (b < a.n_colsum) {
             const int per = a.cj_gx * a.cj_gy, r = b % per;
             colsum_partial_block(a.cj, r % a.cj_gx, r / a.cj_gx, b / per);
+            return;
         }
+        b -= a.n_colsum;
+    }
+    if (KINDS & TAIL_SEL) {
+        if (b < a.n_sel) l0_sel_block(a.sel_boards, a.sel_n, a.sel_kpad, a.sel_out, b, reinterpret_cast<uint32_t*>(tail_smem));
     }
 }
 
