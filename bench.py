@@ -57,7 +57,7 @@ CONFIGS = {
             prioritized=1, bf16=True),
 }
 from cn_chess_ai_amd.workmodel import (PEAK_F32_MFMA_TFLOPS, PEAK_BF16_MFMA_TFLOPS, PEAK_HBM_GBS, ENV_BYTES_PER_GAME,   # noqa: E402
-                                        ROCPROF_NAMES, step_work, price)   # (no torch, no HIP: plain arithmetic)
+                                        step_work, price, rocprof_kernel as wm_rocprof_kernel)   # (no torch, no HIP: plain arithmetic)
 
 
 def cpu_train_loop(seconds, net=(1260, 128, 8100)):
@@ -131,43 +131,52 @@ def cpu_baseline(seconds=15.0, reference_nn=False):
     return out
 
 
-def pmc_traffic(kernel_substring, config=2):
-    """HBM bytes per launch of a kernel from the newest committed rocprofv3 --pmc summary of this configuration
-    (profiles/*_pmc_hbm_traffic.json for configs[1], profiles/*_config<K>_pmc_hbm_traffic.json for the others; made by
-    tools/collect_profiles*.sh + tools/summarize_profiles.py on this same bench command: separate FETCH_SIZE / WRITE_SIZE passes,
-    bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction).  None if absent: PMC counters cannot be read from inside
-    the timed run."""
-    import glob
-    if config == 2:
-        files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")) if "_config" not in os.path.basename(f))
-    else:
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_config%d_pmc_hbm_traffic.json" % config)))
-    for path in reversed(files):
-        try:
-            data = json.load(open(path))
-        except Exception:
-            continue
-        for k, v in data.items():
-            if kernel_substring in k:
-                return v.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
-    return None, None
+_PROFILE_SET = {}
+
+
+def profile_set(config=2):
+    """The ONE committed profile set every offline figure of a bench line comes from: the newest rNN_x tag under profiles/ that has both
+    a kernel-stats CSV and a PMC summary for this configuration (cn_chess_ai_amd/workmodel.py::newest_profile_set).  No fallback to an
+    older set for a kernel the newest one does not hold (one line used to mix three builds): such a kernel gets
+    traffic = null, and tests/test_workmodel_cpu.py keeps the newest set complete."""
+    if config not in _PROFILE_SET:
+        from cn_chess_ai_amd.workmodel import newest_profile_set
+        best = newest_profile_set(ROOT, config)
+        data = None
+        if best:
+            try:
+                data = json.load(open(best[2]))
+            except Exception:
+                data = None
+        _PROFILE_SET[config] = (best, data)
+    return _PROFILE_SET[config]
+
+
+def pmc_traffic(kernel_prefix, config=2):
+    """HBM bytes per launch of a kernel instance (workmodel.rocprof_kernel's prefix) from the PMC summary of profile_set(config):
+    tools/collect_profiles*.sh + tools/summarize_profiles.py on this same bench command, separate FETCH_SIZE / WRITE_SIZE passes,
+    bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction.  (None, source) when the set does not hold the kernel: PMC
+    counters cannot be read from inside the timed run."""
+    from cn_chess_ai_amd.workmodel import match_kernel
+    best, data = profile_set(config)
+    if not best or not data:
+        return None, None
+    src = os.path.relpath(best[2], ROOT)
+    hits = [v for k, v in data.items() if match_kernel(k, kernel_prefix)]
+    if len(hits) != 1:
+        return None, src
+    return hits[0].get("hbm_bytes_per_launch"), src
 
 
 def env_instruction_mix(config=2, n_boards=8192):
     """Wave-instructions per board of env_kernel<SELFPLAY> AS THE TRAINING LOOP RUNS IT (Q-policy launch: reads the select head's
-    slabs, sums them, tanh) from the SQ_INSTS_* counters of the newest committed PMC summary of this configuration — the same file
-    `traffic` comes from, i.e. the same build and the same bench command as the newest kernel-stats set (the round-2
-    env-only profile priced a kernel that no longer runs).  None when that summary has no instruction counters for the kernel."""
-    import glob
-    if config == 2:
-        files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")) if "_config" not in os.path.basename(f))
-    else:
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_config%d_pmc_hbm_traffic.json" % config)))
-    if not files:
+    slabs, sums them, tanh) from the SQ_INSTS_* counters of profile_set(config) — the same file `traffic` comes from, i.e. the same build
+    and the same bench command as the kernel-stats set.  None when that summary has no instruction counters for the kernel."""
+    best, data = profile_set(config)
+    if not best or not data:
         return None
     try:
-        d = json.load(open(files[-1]))
-        sq = next(v["sq"] for k, v in d.items() if "env_kernel<2>" in k)
+        sq = next(v["sq"] for k, v in data.items() if "env_kernel<2>" in k)
         per = {k: sq.get("SQ_INSTS_" + k.upper(), 0.0) / n_boards for k in ("valu", "salu", "lds", "smem", "vmem")}
         if per["valu"] <= 0 or per["salu"] <= 0:
             return None
@@ -176,7 +185,7 @@ def env_instruction_mix(config=2, n_boards=8192):
         out["smem_counted"] = "SQ_INSTS_SMEM" in sq
         if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_WAIT_ANY") is not None:
             out["wait_any_frac_of_wave_cycles"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
-        out["source"] = os.path.relpath(files[-1], ROOT)
+        out["source"] = os.path.relpath(best[2], ROOT)
         return out
     except Exception:
         return None
@@ -414,7 +423,7 @@ def main():
                          "the all-reduce when there is more than one rank)")
     ap.add_argument("--no-td-tail", action="store_true",
                     help="A/B: the gradient kernels of the TD step one by one on two streams instead of the fused launches (xq_dqn_set_td_tail)")
-    ap.add_argument("--l0-grad", choices=("mfma", "segmented"), default="segmented",
+    ap.add_argument("--l0-grad", choices=("mfma", "segmented"), default="mfma",
                     help="A/B: layer-0 weight gradient as segmented sums (library default) or on the bf16 matrix pipe (exact 3-term split)")
     ap.add_argument("--no-variants", action="store_true", help="skip the variant legs (other TD net, full fp32 product): A/B runs")
     ap.add_argument("--repeats", type=int, default=5,
@@ -490,7 +499,7 @@ def main():
     t = xq.Trainer(cfg, stream=C.c_void_p(stream))
     t.dqn.set_qmax_mode(_capi.QMAX_SCREENED if args.qmax == "screened" else _capi.QMAX_FULL)
     t.dqn.set_l0_derive(not args.no_derive)       # layer-0 sums of s' from those of s (library default: off, the reference's order)
-    if args.l0_grad == "mfma": t.dqn.set_l0_grad_mode(1)
+    t.dqn.set_l0_grad_mode(1 if args.l0_grad == "mfma" else 0)
     if args.no_td_tail: t.dqn.set_td_tail(False)  # A/B: the gradient kernels one by one on two streams (library default: fused launches)
     if args.exchange_overlap >= 0: t.dqn.set_exchange_overlap(args.exchange_overlap)
     grads, comm, comm_error = None, None, ""
@@ -500,6 +509,8 @@ def main():
         # that reduces the partial sums, the all-reduce behind it, unfused SGD) — shows what that path costs besides the wire time
         comm = xd.Comm(rank=0, world=1)
         t.set_comm(comm)
+        if args.exchange_overlap < 0:        # one rank: xq_dqn_set_comm does not calibrate by itself; run the rule so that the line shows it
+            t.dqn.calibrate_exchange(float(os.environ.get("XQ_BENCH_EXCHANGE_THRESHOLD_US", "-1")))
         exchange = "RCCL behind the C ABI (one-rank rehearsal)"
     elif world == 1 or args.independent:
         t.dqn.set_fused_apply(True)          # nothing reads the gradient buffer between td_grads and apply_grads
@@ -763,14 +774,14 @@ def main():
             # (xq_screen.hip.h; MODE 0 = top-2 screen, 1 = arg-max, 2 = max); fp32: gemm_colmax_persistent_kernel<2, 2, 0, MODE>
             if bf16_pipe and LAYERS[-2] in (256, 512):
                 ku = LAYERS[-2] // 256
-                inst = "screen_top2_kernel<%d, %d, %d, 0>" % (ku, 2 // ku, 0 if screened_kernel else 1 if args.td_net == "double" else 2)
+                inst = "screen_top2_kernel<%d, %d, %d, 0>(" % (ku, 2 // ku, 0 if screened_kernel else 1 if args.td_net == "double" else 2)
             else:
-                inst = "gemm_colmax_persistent_kernel<2, 2, %d, %d>" % (1 if bf16_pipe else 0,
-                                                                         2 if screened_kernel else 1 if args.td_net == "double" else 0)
+                inst = "gemm_colmax_persistent_kernel<2, 2, %d, %d>(" % (1 if bf16_pipe else 0,
+                                                                          2 if screened_kernel else 1 if args.td_net == "double" else 0)
             tr, src = pmc_traffic(inst, args.config)
             what = ("exact screen of max_a' Q(s'): all outputs once on bf16 MFMA, top-2 per 32-output group" if screened_kernel else
                     "%s_a' Q(s')" % ("argmax" if args.td_net == "double" else "max"))
-            r = {"kernel": "%s (%s: 8100 x %d x %d, %s MFMA)" % (inst, what, minibatch, LAYERS[-2], "bf16" if bf16_pipe else "f32"),
+            r = {"kernel": "%s (%s: 8100 x %d x %d, %s MFMA)" % (inst.rstrip("("), what, minibatch, LAYERS[-2], "bf16" if bf16_pipe else "f32"),
                  "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                  "frac": ach / peak, "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, offline)",
                  "traffic_source": src, "avg_launch_ms": ms, "flops_per_launch": fl, "launches": st["launches"],
@@ -790,28 +801,12 @@ def main():
             line["roofline_qmax"] = gemm_roofline(g, iso.get("gemm_qmax_screen" if scr else "gemm_qmax_rowmax"), scr)
         # ---- every kernel of the step priced against its own bound ------------------------------------------------
         work = step_work(LAYERS, minibatch, n_games, plies, bf16=CFG["bf16"], bf16_bwd=CFG["bf16"] and not args.bf16_fp32_backward,
-                         td=args.td_net, screened=screened_live, derive=not args.no_derive, prioritized=bool(CFG["prioritized"]))
+                         td=args.td_net, screened=screened_live, derive=not args.no_derive, prioritized=bool(CFG["prioritized"]),
+                         l0_mfma=args.l0_grad == "mfma")
 
         def rocprof_kernel(name):
-            """substring of the kernel name rocprofv3 prints for a bracket name (None: several instances share the bracket)"""
-            Hl, dbl = LAYERS[-2], args.td_net == "double"
-            if name == "gemm_qmax_screen" or (name == "gemm_qmax_rowmax" and CFG["bf16"] and Hl in (256, 512)):
-                ku = Hl // 256
-                return "screen_top2_kernel<%d, %d, %d, 0>" % (ku, 2 // ku, 0 if name == "gemm_qmax_screen" else 1 if dbl else 2)
-            if name == "gemm_qmax_rowmax":
-                return "gemm_colmax_persistent_kernel<2, 2, %d, %d>" % (1 if CFG["bf16"] else 0, 1 if dbl else 0)
-            if name == "gemm_hidden_fwd" and not CFG["bf16"]:
-                chains = 3 if dbl else 2
-                big = ((minibatch + 127) // 128) * ((LAYERS[2] + 127) // 128) * chains >= 512
-                return "gemm_f32_kernel<0, 0, 1, %s, 0>" % ("2, 2" if big else "1, 1")
-            if name == "gemm_hidden_fwd@select" and not CFG["bf16"]:
-                if len(LAYERS) == 4:
-                    return "gemm_f32_kernel<0, 0, 4, 1, 1, 0>"  # one hidden product per ply, the select head riding on it
-                # deeper nets: the plain products and the head-riding last one share the bracket — traffic = their mean
-                return ["gemm_f32_kernel<0, 0, 1, 1, 1, 0>", "gemm_f32_kernel<0, 0, 4, 1, 1, 0>"]
-            if name == "qmax_refine":
-                return "qmax_refine2_kernel<" if Hl in (256, 512) else "qmax_refine_kernel<"
-            return ROCPROF_NAMES.get(name)
+            """the kernel instance(s) rocprofv3 prints for a bracket name (cn_chess_ai_amd/workmodel.py::rocprof_kernel)"""
+            return wm_rocprof_kernel(name, LAYERS, minibatch, td=args.td_net, bf16=CFG["bf16"], l0_mfma=args.l0_grad == "mfma", n_games=n_games)
 
         def chain_entry(name, avg_us, lps, live=None):
             e = {"kernel": name, "avg_us": avg_us, "launches_per_step": lps,
@@ -892,6 +887,24 @@ def main():
         a = stats.get("rccl_allreduce_grads")
         line["exchange"] = {"path": exchange, "rccl_behind_c_abi": comm is not None, "comm": comm_info,
                             "gradient_buffer_bytes": 4 * t.dqn.grad_buffer()[1]}
+        # where the select chain starts in a data-parallel step is decided by a measurement of the exchange (xq_dqn_calibrate_exchange:
+        # 20 all-reduces of the gradient buffer at xq_dqn_set_comm time, mean over the ranks against 41 us), not by the rank count
+        if comm is not None:
+            line["exchange"]["calibration"] = t.dqn.exchange_calibration()
+            if args.exchange_overlap >= 0 and line["exchange"]["calibration"] is not None:
+                line["exchange"]["calibration"]["overridden_by"] = "--exchange-overlap %d" % args.exchange_overlap
+        elif grads is not None and not args.independent:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(4):
+                xd.allreduce_gradients(grads, world)
+            ev0.record()
+            for _ in range(20):
+                xd.allreduce_gradients(grads, world)
+            ev1.record(); torch.cuda.synchronize()
+            line["exchange"]["calibration"] = {
+                "allreduce_us": 1e3 * ev0.elapsed_time(ev1) / 20, "threshold_us": 41.0, "late_start": False,
+                "rule": "torch.distributed path: the caller issues the collective between learn_grads and learn_apply, the select chain's "
+                        "start is not moved; behind the C ABI the same measurement decides (xq_dqn_calibrate_exchange)"}
         if a and a["launches"]:
             line["exchange"]["allreduce_avg_ms"] = a["ms"] / a["launches"]
             line["exchange"]["allreduce_launches_bracketed"] = a["launches"]
@@ -914,7 +927,7 @@ def main():
             ach = by / (ms * 1e-3) / 1e9
             line["roofline_env"] = {"kernel": "env_kernel<SELFPLAY> (movegen+select+move+reward+reset, %d boards)" % n_games,
                                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                    "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("env_kernel<2>", args.config)[0], "avg_launch_ms": ms,
+                                    "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("env_kernel<2>(", args.config)[0], "avg_launch_ms": ms,
                                     "bytes_per_launch": by, "launches": e["launches"],
                                     "launches_note": "HIP-event brackets on " + ("every launch" if args.bracket_all or args.profile_all else
                                                      "every 5th launch (the brackets sit on the collect stream: ~12 us per ply, which "

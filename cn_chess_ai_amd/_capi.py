@@ -128,6 +128,8 @@ PROTOTYPES = {
     "xq_dqn_set_td_tail": [_vp, _i],
     "xq_dqn_set_l0_grad_mode": [_vp, _i],
     "xq_dqn_set_exchange_overlap": [_vp, _i],
+    "xq_dqn_calibrate_exchange": [_vp, _d, _pd, _pi],
+    "xq_dqn_exchange_calibration": [_vp, _pi, _pd, _pd, _pi],
     "xq_dqn_qmax_stats": [_vp, C.POINTER(C.c_uint64)],
     "xq_dqn_qmax_guard": [_vp, _pu64, _pi],
     "xq_dqn_num_params": [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],

@@ -133,7 +133,7 @@ struct xq_dqn {
     uint16_t* l0_sel = nullptr;     size_t l0_sel_cap = 0;       // selector half-words of the minibatch's boards (xq_l0grad.hip.h)
     bool l0_split_done = false;                 // this step's layer-0 delta product wrote the planes in its epilogue
     bool l0_sel_done = false;                   // this step's selector words rode in an earlier fused launch
-    bool l0_mfma = false;                       // xq_dqn_set_l0_grad_mode (opt-in: faster alone, not inside the fused launch — DESIGN.md section 5)
+    bool l0_mfma = true;                        // xq_dqn_set_l0_grad_mode (default since round 5: xq_l0grad.hip.h)
     xq_comm* comm = nullptr;                    // xq_dqn_set_comm: bucketed RCCL all-reduce of the gradient buffer inside td_grads
     bool fused_apply = false;                   // xq_dqn_set_fused_apply: apply_grads may sum the layer-0 partials itself
     int l0_pending = 0;                         // > 0: that many layer-0 slabs wait in slabs_l0, not yet reduced into grads_td
@@ -155,6 +155,10 @@ struct xq_dqn {
     bool td_tail = true;                        // xq_dqn_set_td_tail
     int exchange_overlap = -1;                  // xq_dqn_set_exchange_overlap: -1 auto (on when the communicator has more than one rank), 0, 1
     bool late_gate = false;                     // this TD step records ev_qmax behind its gradients (see tail_gradients)
+    // xq_dqn_calibrate_exchange: mean duration of an all-reduce of the gradient buffer on this communicator, the threshold it was held
+    // against and the start of the select chain chosen from the two (exchange_overlap == -1 only)
+    bool exch_calibrated = false, exch_late = false;
+    double exch_allreduce_us = 0.0, exch_threshold_us = 0.0;
     size_t tail_lds = 0;  double tail_flops = 0, tail_bytes = 0;
 
     // partial-sum slabs may stay unreduced until the SGD kernel only when nothing (an all-reduce) reads the buffer in between
@@ -1675,7 +1679,8 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     // do anyway, and the gradient kernels have the chip to themselves.  On one GPU there is nothing to hide behind and the early start
     // is the faster one.
     d->late_gate = d->comm != nullptr && tail_eligible(d, n) &&
-                   (d->exchange_overlap == 1 || (d->exchange_overlap < 0 && comm_world(d->comm) > 1));
+                   (d->exchange_overlap == 1 ||
+                    (d->exchange_overlap < 0 && (d->exch_calibrated ? d->exch_late : comm_world(d->comm) > 1)));
     XQ_TRY(ensure_capacity(d, n));
     XQ_TRY(ensure_ext_capacity(d, n, dbl));
     const int nl = d->nl, Hl = d->hlast(), NO = d->nout();
@@ -1982,14 +1987,72 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     return XQ_OK;
 }
 
+// The late start of the select chain (beside the all-reduce instead of beside the gradient kernels) costs a step ~41 us when the
+// collective is free and wins by the part of the collective above that (0.2430 against 0.2021 ms with a one-rank
+// communicator, where the all-reduce launches nothing).
+static const double kExchangeThresholdUs = 41.0;
+
+int xq_dqn_calibrate_exchange(xq_dqn* d, double threshold_us, double* allreduce_us, int* late) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    if (!d->comm) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_calibrate_exchange: no communicator attached");
+    if (d->n_grads_td == 0) layout_td_grads(d);
+    // COLLECTIVE: every rank times the same 4 + 20 all-reduces of a scratch buffer of the gradient buffer's size on the handle's stream
+    float* scratch = nullptr;
+    XQ_HIP(hipMalloc(&scratch, d->n_grads_td * sizeof(float)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = XQ_OK;
+    float ms = 0.f;
+    const int reps = 20;
+    do {
+        if (hipMemsetAsync(scratch, 0, d->n_grads_td * sizeof(float), d->stream) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+            hipEventCreate(&e1) != hipSuccess) { rc = fail(XQ_ERR_RUNTIME, "xq_dqn_calibrate_exchange: HIP setup failed"); break; }
+        for (int i = 0; i < 4 && rc == XQ_OK; ++i) rc = comm_allreduce_on(d->comm, scratch, d->n_grads_td, d->stream);
+        if (rc != XQ_OK) break;
+        if (hipEventRecord(e0, d->stream) != hipSuccess) { rc = fail(XQ_ERR_RUNTIME, "hipEventRecord failed"); break; }
+        for (int i = 0; i < reps && rc == XQ_OK; ++i) rc = comm_allreduce_on(d->comm, scratch, d->n_grads_td, d->stream);
+        if (rc != XQ_OK) break;
+        if (hipEventRecord(e1, d->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+            rc = fail(XQ_ERR_RUNTIME, "xq_dqn_calibrate_exchange: timing failed");
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(d->stream);
+    (void)hipFree(scratch);
+    if (rc != XQ_OK) return rc;
+    // the ranks must agree (a rank that starts its select chain late while its neighbours start early only wastes what the rule
+    // saves): the decision is taken on the MEAN over the ranks, in integer nanoseconds so that every rank computes the same number
+    uint64_t ns = (uint64_t)((double)ms * 1e6 / reps + 0.5);
+    XQ_TRY(xq_comm_sum_u64(d->comm, &ns));
+    d->exch_allreduce_us = (double)ns / 1e3 / (double)comm_world(d->comm);
+    d->exch_threshold_us = threshold_us >= 0.0 ? threshold_us : kExchangeThresholdUs;
+    d->exch_late = d->exch_allreduce_us > d->exch_threshold_us;
+    d->exch_calibrated = true;
+    if (allreduce_us) *allreduce_us = d->exch_allreduce_us;
+    if (late) *late = d->exch_late ? 1 : 0;
+    return XQ_OK;
+}
+
+int xq_dqn_exchange_calibration(const xq_dqn* d, int* calibrated, double* allreduce_us, double* threshold_us, int* late) {
+    if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
+    if (calibrated) *calibrated = d->exch_calibrated ? 1 : 0;
+    if (allreduce_us) *allreduce_us = d->exch_allreduce_us;
+    if (threshold_us) *threshold_us = d->exch_threshold_us;
+    if (late) *late = d->exch_late ? 1 : 0;
+    return XQ_OK;
+}
+
 int xq_dqn_set_comm(xq_dqn* d, xq_comm* comm) {
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
     if (d->l0_pending > 0 || d->pend_wout.nslabs > 0 || d->pend_bh.nslabs > 0)
         return fail(XQ_ERR_RUNTIME, "xq_dqn_set_comm: a TD step is waiting for its apply_grads");
     d->comm = comm;
+    d->exch_calibrated = false;
+    // more than one rank: measure the exchange now (collective: every rank attaches its communicator at the same point of the program)
+    // and let the measurement, not the rank count, say where the select chain starts (the static guess cost 20 % at
+    // the one point it had been measured)
+    if (comm && comm_world(comm) > 1 && d->exchange_overlap < 0) XQ_TRY(xq_dqn_calibrate_exchange(d, -1.0, nullptr, nullptr));
     return XQ_OK;
 }
-
 int xq_allreduce_grads(xq_dqn* d, xq_comm* comm) {
     if (!d || !comm) return fail(XQ_ERR_INVALID_ARGUMENT, "null handle");
     if (d->l0_pending > 0 || d->pend_wout.nslabs > 0 || d->pend_bh.nslabs > 0)

@@ -223,7 +223,7 @@ DQN.set_td_tail = _set_td_tail
 
 
 def _set_l0_grad_mode(self, mode):
-    """Layer-0 weight gradient: 0 = segmented sums (library default), 1 = exact dense product on the bf16 matrix pipe (where the shape allows)."""
+    """Layer-0 weight gradient: 1 = exact dense product on the bf16 matrix pipe (library default, where the shape allows), 0 = segmented sums."""
     call("xq_dqn_set_l0_grad_mode", self._h, int(mode))
 
 
@@ -236,6 +236,28 @@ def _set_exchange_overlap(self, mode):
 
 
 DQN.set_exchange_overlap = _set_exchange_overlap
+
+
+def _calibrate_exchange(self, threshold_us=-1.0):
+    """COLLECTIVE: time 20 all-reduces of the gradient buffer on the attached communicator; the auto setting of set_exchange_overlap
+    then starts the select chain late iff their mean over the ranks exceeds threshold_us (< 0: the library's 41 us)."""
+    us, late = C.c_double(0.0), C.c_int(0)
+    call("xq_dqn_calibrate_exchange", self._h, float(threshold_us), C.byref(us), C.byref(late))
+    return {"allreduce_us": us.value, "late_start": bool(late.value)}
+
+
+def _exchange_calibration(self):
+    """what the last calibration (explicit, or xq_dqn_set_comm's with more than one rank) measured and chose; None: none yet"""
+    cal, late, us, thr = C.c_int(0), C.c_int(0), C.c_double(0.0), C.c_double(0.0)
+    call("xq_dqn_exchange_calibration", self._h, C.byref(cal), C.byref(us), C.byref(thr), C.byref(late))
+    if not cal.value:
+        return None
+    return {"allreduce_us": us.value, "threshold_us": thr.value, "late_start": bool(late.value),
+            "rule": "select chain starts behind the gradient kernels (beside the all-reduce) iff the measured all-reduce exceeds the threshold"}
+
+
+DQN.calibrate_exchange = _calibrate_exchange
+DQN.exchange_calibration = _exchange_calibration
 
 
 def _qmax_stats(self):

@@ -18,23 +18,91 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
-# bracket name -> substring of the kernel name rocprofv3 prints (per configuration where it differs)
+# bracket name -> the kernel instance rocprofv3 prints for it: base name + template arguments, matched as a PREFIX of the printed name
+# ("void xq::" stripped) so that a renamed kernel or a changed template argument fails the lookup instead of silently reading the figures
+# of an older build (`td_tail_kernel<30u>` no longer matched `td_tail_kernel<30u, false>`).  Fixed names first; the
+# configuration-dependent ones are in rocprof_kernel().
 ROCPROF_NAMES = {
-    "l0_forward_gather": "l0_forward_kernel<",
+    "l0_forward_gather": "l0_forward_kernel<",            # <false> fp32 net, <true> bf16 net: one instance per configuration
     "l0_forward_gather@select": "l0_forward_kernel<",
-    "gemm_qmax_rowmax": "gemm_colmax_persistent_kernel<",
-    "qmax_refine": "qmax_refine",
-    "td_target_delta": "td_delta_kernel",
-    "colmax_reduce": "colmax_reduce_kernel",
-    "td_tail_deltas": "td_tail_kernel<7u>",
-    "td_tail_l0": "td_tail_kernel<30u>",
-    "sgd_apply": "sgd_segments_kernel",
-    "env_selfplay_step": "env_kernel<2>",
+    "td_target_delta": "td_delta_kernel(",
+    "colmax_reduce": "colmax_reduce_kernel(",
+    "sgd_apply": "sgd_segments_kernel(",
+    "env_selfplay_step": "env_kernel<2>(",
     "target_sync_copy": "__amd_rocclr_copyBuffer",
-    "l0_grad_segsum": "l0_grad_kernel",
-    "out_grad_segsum": "out_grad_kernel",
-    "bias_grad_colsum": "colsum_partial_kernel",
+    "l0_grad_segsum": "l0_grad_kernel(",
+    "out_grad_segsum": "out_grad_kernel(",
+    "bias_grad_colsum": "colsum_partial_kernel(",
 }
+# td_tail_kernel<KINDS, L0MFMA>: KINDS = TAIL_DELTA 1 | TAIL_GRAD 2 | TAIL_OUT 4 | TAIL_COLSUM 8 | TAIL_L0 16 | TAIL_SEL 32 (xq_tail.hip.h)
+TAIL_DELTAS, TAIL_DELTAS_SEL, TAIL_L0 = 7, 39, 30
+
+
+def rocprof_kernel(name, layers, minibatch, td="online", bf16=False, l0_mfma=True, n_games=None):
+    """The kernel instance(s) of a bracket name as rocprofv3 prints them (prefix after "void xq::"), or None when the bracket has no
+    single kernel.  A list: several instances share the bracket (traffic = their mean)."""
+    Hl, dbl, k = layers[-2], td == "double", len(layers) - 2
+    mfma = l0_mfma and layers[1] % 64 == 0 and minibatch >= 256
+    if name == "gemm_qmax_screen" or (name == "gemm_qmax_rowmax" and bf16 and Hl in (256, 512)):
+        ku = Hl // 256
+        return "screen_top2_kernel<%d, %d, %d, 0>(" % (ku, 2 // ku, 0 if name == "gemm_qmax_screen" else 1 if dbl else 2)
+    if name == "gemm_qmax_rowmax":
+        return "gemm_colmax_persistent_kernel<2, 2, %d, %d>(" % (1 if bf16 else 0, 1 if dbl else 0)
+    if name == "gemm_hidden_fwd" and not bf16:
+        # whole tiles: the persistent walk, gemm_fwd_persistent_kernel<TM, TN, 2> (64 x 128 tiles at width 256, 128 x 128 at 512)
+        chains = 3 if dbl else 2
+        if minibatch % 128 == 0 and all(h % 128 == 0 for h in layers[2:-1]) and all(h % 32 == 0 for h in layers[1:-2]):
+            t128 = (minibatch // 128) * (layers[2] // 128) * chains
+            return "gemm_fwd_persistent_kernel<%s, 2>(" % ("2, 2" if t128 >= 512 else "1, 2")
+        big = ((minibatch + 127) // 128) * ((layers[2] + 127) // 128) * chains >= 512
+        return "gemm_f32_kernel<0, 0, 1, %s, 0>(" % ("2, 2" if big else "1, 1")
+    if name == "gemm_hidden_fwd@select" and not bf16:
+        if k == 2:
+            return "gemm_f32_kernel<0, 0, 4, 1, 1, 0>("       # one hidden product per ply, the select head riding on it
+        return ["gemm_f32_kernel<0, 0, 1, 1, 1, 0>(", "gemm_f32_kernel<0, 0, 4, 1, 1, 0>("]
+    if name == "qmax_refine":
+        return "qmax_refine2_kernel<" if Hl in (256, 512) else "qmax_refine_kernel<"
+    if name == "td_tail_l0":
+        return "td_tail_kernel<%du, %s>(" % (TAIL_L0, "true" if mfma else "false")
+    if name == "td_tail_deltas":
+        if k < 2:
+            return None
+        plain = "td_tail_kernel<%du, false>(" % TAIL_DELTAS
+        last = "td_tail_kernel<%du, false>(" % (TAIL_DELTAS_SEL if mfma else TAIL_DELTAS)    # the launch that makes delta_0 carries the selector words
+        return last if k == 2 else ([plain, last] if mfma else plain)
+    if name == "l0_grad_segsum" and mfma:
+        return "l0_grad_mfma_kernel<0>("
+    if name == "l0_delta_split":
+        return "delta_split_kernel("
+    if name == "l0_sel_words":
+        return "l0_sel_kernel("
+    return ROCPROF_NAMES.get(name)
+
+
+def match_kernel(printed, want):
+    """Does the kernel name rocprofv3 printed belong to the instance `want` (rocprof_kernel)?"""
+    p = printed
+    for pre in ("void ", "xq::"):
+        if p.startswith(pre):
+            p = p[len(pre):]
+    return p.startswith(want)
+
+
+def newest_profile_set(root, config=2):
+    """(tag, kernel_stats.csv, pmc_hbm_traffic.json) of the newest COMPLETE profile set of a configuration under profiles/ — both files
+    from the same rNN_x tag, i.e. the same build and bench command.  bench.py takes every `traffic` figure of a line from this one set
+    (or none): no mixing across builds."""
+    import glob, os, re
+    suffix = "" if config == 2 else "_config%d" % config
+    best = None
+    for pmc in glob.glob(os.path.join(root, "profiles", "r*_pmc_hbm_traffic.json")):
+        m = re.match(r"(r\d+_[a-z0-9]+)(_config\d+)?_pmc_hbm_traffic\.json$", os.path.basename(pmc))
+        if not m or (m.group(2) or "") != suffix:
+            continue
+        stats = os.path.join(root, "profiles", m.group(1) + suffix + "_kernel_stats.csv")
+        if os.path.exists(stats) and (best is None or m.group(1) > best[0]):
+            best = (m.group(1), stats, pmc)
+    return best
 
 
 def pick_splits(M, N, K):
@@ -47,7 +115,7 @@ def pick_splits(M, N, K):
 
 
 def step_work(layers, minibatch, n_games, plies=1, bf16=False, bf16_bwd=False, td="online", screened=True, derive=True,
-              prioritized=False):
+              prioritized=False, l0_mfma=True):
     """{bracket name: dict(flops, hbm_bytes, bound, peak, peak_unit, what)} for one training step of the given configuration."""
     h = list(layers[1:-1])
     H1, Hl, k = h[0], h[-1], len(h)
@@ -57,6 +125,7 @@ def step_work(layers, minibatch, n_games, plies=1, bf16=False, bf16_bwd=False, t
     fa = 2 if bf16 else 4                               # bytes of an activation the forward kernels read
     mm_peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     w = {}
+    mfma0 = l0_mfma and H1 % 64 == 0 and B >= 256       # layer-0 gradient on the matrix pipe (xq_l0grad.hip.h; library default)
 
     def put(name, flops, by, bound, what, peak=None):
         if bound == "mfma":
@@ -123,8 +192,16 @@ def step_work(layers, minibatch, n_games, plies=1, bf16=False, bf16_bwd=False, t
                 "fused launch: hidden delta product || weight-gradient product of the layer above || output-layer segmented sums")
         chunk = 2048 if B >= 16384 else 1024
         nch = (B + chunk - 1) // chunk
-        fl = 2.0 * B * 32 * H1
-        by = B * H1 * 4 + 48 * B + nch * STATE * H1 * 4
+        kpad = nch * chunk
+        if mfma0:
+            # one-hot^T x delta_0: 96 squares x 16 planes x H1 columns x kpad samples x 3 bf16 planes of delta_0 (what the pipe executes;
+            # the useful part is the ~32 occupied (square, piece) pairs per sample).  Bytes: the three planes and the selector words
+            # in, delta_0 itself for the bias sums, the chunk partial sums out.
+            fl = 2.0 * 96 * 16 * H1 * kpad * 3
+            by = 6.0 * H1 * kpad + 4.0 * 96 * kpad + B * H1 * 4 + nch * STATE * H1 * 4
+        else:
+            fl = 2.0 * B * 32 * H1
+            by = B * H1 * 4 + 48 * B + nch * STATE * H1 * 4
         if k == 2:                                       # the one weight-gradient product of a 2-hidden-layer net rides here
             sp = pick_splits(h[1], h[0], B)
             fl += 2.0 * h[1] * h[0] * B
@@ -135,8 +212,13 @@ def step_work(layers, minibatch, n_games, plies=1, bf16=False, bf16_bwd=False, t
         by += R * sum(h) * 4
         fl += B * sum(h)
         put("td_tail_l0", fl, by, "hbm",
-            "fused launch: layer-0 gradient as per-(square, piece) segmented sums of delta rows || "
+            "fused launch: layer-0 gradient " + ("as the exact product one-hot^T x delta_0 on the bf16 matrix pipe (3-term split) || "
+                                                 if mfma0 else "as per-(square, piece) segmented sums of delta rows || ")
             + ("hidden weight-gradient product || " if k == 2 else "") + "bias column sums")
+        if mfma0:
+            w["td_tail_l0"]["mfma_bf16_flops"] = 2.0 * 96 * 16 * H1 * kpad * 3
+            if "td_tail_deltas" in w:                    # the launch that makes delta_0 also writes its planes and the selector words
+                w["td_tail_deltas"]["hbm_bytes"] += (6.0 * H1 * kpad + 4.0 * 96 * kpad + 48 * B) / max(1, k - 1)
         slabs = nch * STATE * H1 + nch_out * (96 * Hl + 96) + R * sum(h)
         for l in range(1, k):
             slabs += pick_splits(h[l], h[l - 1], B) * h[l] * h[l - 1]
@@ -162,8 +244,15 @@ def step_work(layers, minibatch, n_games, plies=1, bf16=False, bf16_bwd=False, t
                 PEAK_BF16_MFMA_TFLOPS if bf16_bwd else PEAK_F32_MFMA_TFLOPS)
         chunk = 2048 if B >= 16384 else 1024
         nch = (B + chunk - 1) // chunk
-        put("l0_grad_segsum", 2.0 * B * 32 * H1, B * H1 * 4 + 48 * B + nch * STATE * H1 * 4, "hbm",
-            "layer-0 gradient as per-(square, piece) segmented sums of delta rows (L2 gather)")
+        if mfma0:
+            kpad = nch * chunk
+            put("l0_grad_segsum", 2.0 * 96 * 16 * H1 * kpad * 3, 6.0 * H1 * kpad + 4.0 * 96 * kpad + nch * STATE * H1 * 4, "mfma",
+                "layer-0 gradient as the exact product one-hot^T x delta_0 on the bf16 matrix pipe (3-term split)", PEAK_BF16_MFMA_TFLOPS)
+            put("l0_delta_split", 8.0 * B * H1, B * H1 * 4 + 6.0 * H1 * kpad, "hbm", "delta_0 -> three transposed bf16 planes (hi, mid, lo)")
+            put("l0_sel_words", 0.0, 48 * B + 4.0 * 96 * kpad, "hbm", "boards -> selector half-words of the one-hot operand")
+        else:
+            put("l0_grad_segsum", 2.0 * B * 32 * H1, B * H1 * 4 + 48 * B + nch * STATE * H1 * 4, "hbm",
+                "layer-0 gradient as per-(square, piece) segmented sums of delta rows (L2 gather)")
         put("out_grad_segsum", out_fl, out_by, "hbm", "output-layer gradient rows 0..95 as segmented sums by action")
         R = max(1, min(64, B // 64))
         put("bias_grad_colsum", float(B * sum(h)), B * sum(h) * 4 + R * sum(h) * 4, "hbm", "bias gradients: column sums of every hidden delta")

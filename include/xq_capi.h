@@ -284,11 +284,11 @@ int xq_dqn_set_l0_derive(xq_dqn* d, int on);
  * kernel that re-evaluates the screened maxima instead of by a launch of their own.  Results are bitwise identical either way. */
 int xq_dqn_set_td_tail(xq_dqn* d, int on);
 /* How the layer-0 weight gradient of a TD step (updateWeightsBiasesKernel on layer 0, dqn.cu:310-319, fed by the one-hot of
- * chessai.cpp:268-289) is computed.  0 (default): per-(square, piece) segmented sums of delta rows on the vector ALU.  1 (first hidden
- * width a multiple of 64, >= 256 samples; other shapes keep 0): the dense product one-hot^T x delta_0 on the bf16 matrix pipe, exact —
- * the one-hot operand is 0 / 1 and delta_0 is split into three bf16 values per fp32 (hi + mid + lo, every residual exact), products
- * exact, fp32 accumulation.  Same value up to the summation order (both within a few fp32 ulp of an fp64 evaluation).  Measured: 1 is the
- * faster kernel alone (31 against 40 us at 8192 x 256) and the slower step inside the fused launches, hence opt-in. */
+ * chessai.cpp:268-289) is computed.  1 (default; first hidden width a multiple of 64 and >= 256 samples, other shapes take 0): the dense
+ * product one-hot^T x delta_0 on the bf16 matrix pipe, exact — the one-hot operand is 0 / 1 and delta_0 is split into three bf16 values per
+ * fp32 (hi + mid + lo, every residual exact), products exact, fp32 accumulation.  0: per-(square, piece) segmented sums of delta rows on
+ * the vector ALU.  Same value up to the summation order (both within a few fp32 ulp of an fp64 evaluation).  Measured at 8192 x 256
+ * (round 5): 17 against 37 us alone, the headline step 0.1755 against 0.1833 ms. */
 int xq_dqn_set_l0_grad_mode(xq_dqn* d, int mode);
 /* XQ_QMAX_*: how the TD step finds max_a' Q(s',a').  XQ_QMAX_SCREENED applies to fp32 nets with XQ_TD_ONLINE_NET / XQ_TD_TARGET_NET
  * whose last hidden width is a multiple of 64 and whose product is large enough for the persistent GEMM (>= 512 tiles of 128 x 128);
@@ -410,10 +410,18 @@ int xq_comm_allreduce(xq_comm* c, float* buf_dev, size_t n_floats, void* hip_str
  * to no communicator. */
 int xq_dqn_set_comm(xq_dqn* d, xq_comm* comm);
 /* Where the event the trainer's select chain waits for is recorded in a data-parallel TD step (fp32 nets, fused launches).  0: behind
- * the max pass, as on one GPU (the select chain runs beside the gradient kernels).  1: behind the gradient kernels, in front of the
- * all-reduce (the select chain runs beside the exchange and hides it).  -1 (default): 1 when the communicator has more than one
- * rank, else 0.  No effect without a communicator.  Same results either way. */
+ * the max pass, as on one GPU (the select chain runs beside the gradient kernels; the all-reduce is exposed).  1: behind the gradient
+ * kernels, in front of the all-reduce (the select chain runs beside the exchange and hides it; costs ~41 us of overlap with the
+ * gradient kernels).  -1 (default): decided by MEASUREMENT — xq_dqn_set_comm with a communicator of more than one rank times 20
+ * all-reduces of the gradient buffer (xq_dqn_calibrate_exchange) and takes 1 iff their mean exceeds 41 us; one rank: 0.  No effect
+ * without a communicator.  Same results either way. */
 int xq_dqn_set_exchange_overlap(xq_dqn* d, int mode);
+/* COLLECTIVE (every rank of the attached communicator, same point of the program): times 4 + 20 all-reduces of a scratch buffer of the
+ * gradient buffer's size on the handle's stream, averages the mean over the ranks and sets the -1 (auto) choice above to "late" iff
+ * it exceeds threshold_us (< 0: the library's 41 us).  Works with one rank too (tests force both branches with the threshold).
+ * xq_dqn_exchange_calibration reads back what the last calibration measured and chose (calibrated = 0: none yet). */
+int xq_dqn_calibrate_exchange(xq_dqn* d, double threshold_us, double* allreduce_us, int* late);
+int xq_dqn_exchange_calibration(const xq_dqn* d, int* calibrated, double* allreduce_us, double* threshold_us, int* late);
 /* One all-reduce of the whole gradient buffer on the handle's stream, for callers that do not attach a communicator. */
 int xq_allreduce_grads(xq_dqn* d, xq_comm* comm);
 

@@ -307,9 +307,92 @@ int cmd_time(int argc, char** argv) {
     return 0;
 }
 
+// seq <in.bin> <out.bin> <seed> <lr> <gamma> <L0> ... <Ln> : K plies of the NN half of ChessAI::train's loop body (chessai.cpp:121-133) on the
+// reference's own runtime, the parameters carried from ply to ply:
+//     targetQ = getQValues(state);  targetQ[action.to] = done ? r : r + gamma * max(getQValues(nextState));  backpropagate(state, targetQ, lr)
+// in.bin: int32 K, then per ply 90 bytes state (piece codes 0..14 = plane + 1 of chessai.cpp:278-282), 90 bytes next state, int32 action.to,
+// float64 reward, int32 done.  Recorded per ply: Q(state)[0..95] and max Q(nextState) as the reference computed them BEFORE the update,
+// the target entry, every bias and a sample of layer 0's weights AFTER it (free of undefined reads), and 64 sampled weights of every layer
+// >= 1 (`ub_*`: they depend on the read of released memory, dqn.cu:371 / :441 — the generator compares them with the "released block still
+// holds the activation" model and records a flag per ply; a test asserts them only where the flag says the block was intact).
+int cmd_seq(int argc, char** argv) {
+    if (argc < 9) return 64;
+    FILE* in = std::fopen(argv[2], "rb");
+    if (!in) return 65;
+    g_out = std::fopen(argv[3], "wb");
+    if (!g_out) return 65;
+    const uint64_t seed = std::strtoull(argv[4], nullptr, 10);
+    const double lr = std::atof(argv[5]), gamma = std::atof(argv[6]);
+    std::vector<int> sizes;
+    for (int i = 7; i < argc; ++i) sizes.push_back(std::atoi(argv[i]));
+    const int nL = (int)sizes.size() - 1, IN = sizes.front(), OUT = sizes.back();
+    if (IN != 1260 || OUT < 96) return 64;
+    int32_t K = 0;
+    if (std::fread(&K, 4, 1, in) != 1 || K < 1 || K > 64) return 66;
+    NeuralNetwork nn(sizes);
+    fill_params(nn, seed);
+    auto onehot = [&](const unsigned char* codes) {
+        std::vector<double> x(IN, 0.0);
+        for (int sq = 0; sq < 90; ++sq) if (codes[sq]) x[sq * 14 + codes[sq] - 1] = 1.0;
+        return x;
+    };
+    const size_t nhid = nn.biasOffsets[nL - 1];
+    for (int t = 0; t < K; ++t) {
+        unsigned char s[90], s2[90]; int32_t a = 0, done = 0; double r = 0;
+        if (std::fread(s, 1, 90, in) != 90 || std::fread(s2, 1, 90, in) != 90 || std::fread(&a, 4, 1, in) != 1 || std::fread(&r, 8, 1, in) != 1 ||
+            std::fread(&done, 4, 1, in) != 1 || a < 0 || a >= 90) return 66;
+        const std::string tag = "ply" + std::to_string(t);
+        const std::vector<double> x = onehot(s), x2 = onehot(s2);
+        std::vector<double> target = nn.forward(x);                              // chessai.cpp:121
+        const std::vector<double> q2 = nn.forward(x2);                           // :126
+        double m = q2[0]; for (double v : q2) m = v > m ? v : m;
+        const double y = done ? r : r + gamma * m;                               // :122-128
+        put_f64(tag + "_q", std::vector<double>(target.begin(), target.begin() + 96));
+        put_f64(tag + "_maxq2_y", {m, y});
+        target[a] = y;
+        nn.backpropagate(x, target, lr);                                         // :133
+        nn.copyFromDevice();
+        put_f64(tag + "_hidden_biases", std::vector<double>(nn.host_biases.begin(), nn.host_biases.begin() + nhid));
+        put_f64(tag + "_out_biases", std::vector<double>(nn.host_biases.begin() + nhid, nn.host_biases.begin() + nhid + 96));
+        {
+            // layer 0: rows 0..15 x the columns of the occupied (square, piece) pairs of this ply's state
+            std::vector<double> w0;
+            std::vector<int32_t> cols;
+            for (int sq = 0; sq < 90; ++sq) if (s[sq]) cols.push_back(sq * 14 + s[sq] - 1);
+            for (int j = 0; j < 16; ++j) for (int i : cols) w0.push_back(nn.host_weights[nn.weightOffsets[0] + (size_t)j * IN + i]);
+            put_i32(tag + "_w0_cols", cols);
+            put_f64(tag + "_w0", w0);                                            // [16][cols]
+        }
+        for (int l = 1; l < nL; ++l) {
+            std::vector<double> val(64);
+            for (int i = 0; i < 64; ++i) {                                       // tests/refnn.py::sample_positions
+                const size_t row = (size_t)(u01(seed, 80 + l, 2 * i) * (sizes[l + 1] < 96 ? sizes[l + 1] : 96));
+                const size_t col = (size_t)(u01(seed, 80 + l, 2 * i + 1) * sizes[l]);
+                val[i] = nn.host_weights[nn.weightOffsets[l] + row * sizes[l] + col];
+            }
+            put_f64(tag + "_ub_w" + std::to_string(l), val);
+        }
+    }
+    // the net after the last ply answers the first state once more (the whole trajectory in 96 numbers)
+    {
+        std::rewind(in);
+        int32_t k2; unsigned char s[90];
+        if (std::fread(&k2, 4, 1, in) != 1 || std::fread(s, 1, 90, in) != 90) return 66;
+        const std::vector<double> q = nn.forward(onehot(s));
+        put_f64("final_q_of_first_state", std::vector<double>(q.begin(), q.begin() + 96));
+    }
+    std::fclose(in);
+    std::fclose(g_out);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
+    if (argc >= 2 && std::strcmp(argv[1], "seq") == 0) {
+        try { return cmd_seq(argc, argv); }
+        catch (const std::exception& e) { std::fprintf(stderr, "xqref_nn: %s\n", e.what()); return 70; }
+    }
     if (argc >= 2 && std::strcmp(argv[1], "time") == 0) {
         try { return cmd_time(argc, argv); }
         catch (const std::exception& e) { std::fprintf(stderr, "xqref_nn: %s\n", e.what()); return 70; }
@@ -319,6 +402,7 @@ int main(int argc, char** argv) {
         try { return cmd_nn(argc, argv); }
         catch (const std::exception& e) { std::fprintf(stderr, "xqref_nn: %s\n", e.what()); return 70; }
     }
-    std::fprintf(stderr, "usage: xqref_nn probe | nn <out.bin> <seed> <L0> <L1> ... <Ln> | time <iters> <L0> ... <Ln>\n");
+    std::fprintf(stderr, "usage: xqref_nn probe | nn <out.bin> <seed> <L0> <L1> ... <Ln> | seq <in.bin> <out.bin> <seed> <lr> <gamma> <L0> ... <Ln> | "
+                         "time <iters> <L0> ... <Ln>\n");
     return 64;
 }

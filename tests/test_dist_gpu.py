@@ -117,6 +117,39 @@ def test_rccl_path_behind_the_c_abi_world_size_one(tmp_path):
     assert e.value.code == 4
 
 
+def test_exchange_calibration_takes_both_branches_with_identical_results():
+    """xq_dqn_calibrate_exchange (VERDICT r4 Next #4): where the select chain of a data-parallel step starts is decided by a measurement of
+    the all-reduce, not by the rank count.  One-rank communicator, thresholds forced: 0 us => the measured collective is "long" => late
+    start (beside the all-reduce); 1e9 us => early start (beside the gradient kernels).  Same bits either way, and the same as the
+    explicit settings."""
+    import cn_chess_ai_amd as xq
+    from cn_chess_ai_amd import dist as xd
+    sizes = (1260, 64, 64, 8100)
+    cfg = xq.TrainerConfig(n_games=512, layer_sizes=sizes, replay_capacity=4096, minibatch=1024, td_net=0, target_sync_interval=3, seed=7,
+                           overlap_collect=1)
+    outs, cals = [], []
+    for thr, explicit in ((0.0, None), (1e9, None), (None, 0), (None, 1)):
+        t = xq.Trainer(cfg)
+        comm = xd.Comm(rank=0, world=1)
+        t.set_comm(comm)
+        assert t.dqn.exchange_calibration() is None              # one rank: xq_dqn_set_comm does not calibrate by itself
+        if thr is not None:
+            c = t.dqn.calibrate_exchange(thr)
+            cal = t.dqn.exchange_calibration()
+            assert cal["threshold_us"] == thr and cal["late_start"] == c["late_start"] == (thr == 0.0) and 0.0 < cal["allreduce_us"] < 5e4
+            cals.append(cal)
+        else:
+            t.dqn.set_exchange_overlap(explicit)
+        for _ in range(5):
+            t.learn_grads(); t.collect(); t.learn_apply(1)
+        outs.append(t.dqn.get_params() + (t.env.get_state()[0],))
+        assert comm.info()["collectives"] == 5 + (24 if thr is not None else 0) or comm.info()["collectives"] >= 5
+        t.close(); comm.close()
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
+    assert cals[0]["late_start"] is True and cals[1]["late_start"] is False
+
+
 def _rehearse(extra):
     import os
     import socket
@@ -173,6 +206,8 @@ def test_two_rank_rehearsal_on_one_gpu():
     ex = line["exchange"]
     assert ex["rccl_behind_c_abi"] is False and ex["path"].startswith("torch.distributed") and ex["comm"] is None
     assert ex["gradient_buffer_bytes"] == 4 * (1260 * 256 + 256 * 256 + 96 * 256 + 96 + 512)
+    # ... and what the exchange measured (the rule that places the select chain; here the torch path, so nothing is moved)
+    assert ex["calibration"]["allreduce_us"] > 0 and ex["calibration"]["threshold_us"] == 41.0 and ex["calibration"]["late_start"] is False
 
 
 def test_self_launch_reports_a_failed_rank():
