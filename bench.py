@@ -695,6 +695,23 @@ def main():
         if rank == 0:
             print(f"replicas identical on {world} ranks: {digest.tolist()}", file=sys.stderr)
 
+    torch_exchange_calibration = None
+    if comm is None and grads is not None and not args.independent:
+        # the torch.distributed path (gloo rehearsal / fallback): the same measurement the library makes behind the C ABI, on every rank
+        # (a collective), AFTER the replicas were compared — it sums the gradient buffer into itself
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        grads.zero_()
+        for _ in range(4):
+            xd.allreduce_gradients(grads, world)
+        ev0.record()
+        for _ in range(20):
+            xd.allreduce_gradients(grads, world)
+        ev1.record(); torch.cuda.synchronize()
+        torch_exchange_calibration = {
+            "allreduce_us": 1e3 * ev0.elapsed_time(ev1) / 20, "threshold_us": 41.0, "late_start": False,
+            "rule": "torch.distributed path: the caller issues the collective between learn_grads and learn_apply, the select chain's "
+                    "start is not moved; behind the C ABI the same measurement decides (xq_dqn_calibrate_exchange)"}
+
     if rank == 0:
         env_steps = world * n_games * plies * args.steps
         td_text = {"online": "online (max Q(s') from the online net, chessai.cpp:126)",
@@ -893,23 +910,8 @@ def main():
             line["exchange"]["calibration"] = t.dqn.exchange_calibration()
             if args.exchange_overlap >= 0 and line["exchange"]["calibration"] is not None:
                 line["exchange"]["calibration"]["overridden_by"] = "--exchange-overlap %d" % args.exchange_overlap
-        elif grads is not None and not args.independent:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for _ in range(4):
-                xd.allreduce_gradients(grads, world)
-            ev0.record()
-            for _ in range(20):
-                xd.allreduce_gradients(grads, world)
-            ev1.record(); torch.cuda.synchronize()
-            line["exchange"]["calibration"] = {
-                "allreduce_us": 1e3 * ev0.elapsed_time(ev1) / 20, "threshold_us": 41.0, "late_start": False,
-                "rule": "torch.distributed path: the caller issues the collective between learn_grads and learn_apply, the select chain's "
-                        "start is not moved; behind the C ABI the same measurement decides (xq_dqn_calibrate_exchange)"}
-        if a and a["launches"]:
-            line["exchange"]["allreduce_avg_ms"] = a["ms"] / a["launches"]
-            line["exchange"]["allreduce_launches_bracketed"] = a["launches"]
-            line["exchange"]["allreduce_note"] = ("HIP-event bracket around the collective on the handle's stream, every 4th step of the timed "
-                                                  "region: queueing + wire time as the TD step sees it")
+        elif torch_exchange_calibration is not None:
+            line["exchange"]["calibration"] = torch_exchange_calibration
         if qmax_info is not None:
             line["config"]["qmax"] = qmax_info
         if full_variant is not None:

@@ -80,6 +80,10 @@ PROTOTYPES = {
     "xq_stream_create": [_i, _i, _pvp],
     "xq_stream_destroy": [_vp],
     "xq_debug_stream_delay": [_vp, _i],
+    "xq_debug_stream_gate": [_vp, _i, _pvp],
+    "xq_debug_gate_release": [_vp],
+    "xq_debug_gate_destroy": [_vp],
+    "xq_stream_query": [_vp, _pi],
     "xq_debug_set_stream_ordering": [C.c_uint],
     "xq_env_stream": [_vp, _pvp],
     "xq_replay_stream": [_vp, _pvp],

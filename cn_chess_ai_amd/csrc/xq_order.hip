@@ -5,6 +5,7 @@
 #include "xq_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -98,9 +99,25 @@ __global__ void delay_kernel(unsigned long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
+// waits until the host raises *flag (xq_debug_gate_release) — or `ticks` of the 100 MHz wall clock have passed: an exit every wave
+// reaches whatever the host does
+__global__ void gate_kernel(const unsigned* flag, unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+// the diagnostics below switch synchronisation off / stall streams: refused unless the process asked for them
+static int debug_api_enabled(const char* what) {
+    const char* e = getenv("XQ_DEBUG_API");
+    if (e && e[0] == '1') return XQ_OK;
+    return fail(XQ_ERR_INVALID_ARGUMENT, "%s: the debug entry points are disabled (set XQ_DEBUG_API=1 in the environment of a test process)", what);
+}
+
 }  // namespace xq
 
 using namespace xq;
+
+struct xq_debug_gate { unsigned* host = nullptr; unsigned* dev = nullptr; };
 
 extern "C" {
 
@@ -134,7 +151,47 @@ int xq_stream_destroy(void* hip_stream) {
     return XQ_OK;
 }
 
+int xq_stream_query(void* hip_stream, int* idle) {
+    if (!idle) return fail(XQ_ERR_INVALID_ARGUMENT, "null pointer");
+    const hipError_t e = hipStreamQuery((hipStream_t)hip_stream);
+    if (e != hipSuccess && e != hipErrorNotReady) return fail(XQ_ERR_RUNTIME, "xq_stream_query: %s", hipGetErrorString(e));
+    *idle = e == hipSuccess ? 1 : 0;
+    return XQ_OK;
+}
+
+int xq_debug_stream_gate(void* hip_stream, int timeout_ms, void** gate_out) {
+    XQ_TRY(debug_api_enabled("xq_debug_stream_gate"));
+    if (!gate_out || timeout_ms < 1 || timeout_ms > 5000) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_debug_stream_gate: timeout 1..5000 ms");
+    xq_debug_gate* g = new xq_debug_gate();
+    if (hipHostMalloc((void**)&g->host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) { delete g; return fail(XQ_ERR_RUNTIME, "hipHostMalloc failed"); }
+    *g->host = 0u;
+    if (hipHostGetDevicePointer((void**)&g->dev, g->host, 0) != hipSuccess) { (void)hipHostFree(g->host); delete g; return fail(XQ_ERR_RUNTIME, "hipHostGetDevicePointer failed"); }
+    int rate_khz = 0;
+    unsigned long long per_ms = 100000;              // s_memrealtime: 100 MHz on gfx9
+    if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, 0) == hipSuccess && rate_khz > 0) per_ms = (unsigned long long)rate_khz;
+    hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, g->dev, per_ms * (unsigned long long)timeout_ms);
+    if (hipGetLastError() != hipSuccess) { (void)hipHostFree(g->host); delete g; return fail(XQ_ERR_RUNTIME, "gate launch failed"); }
+    *gate_out = g;
+    return XQ_OK;
+}
+
+int xq_debug_gate_release(void* gate) {
+    if (!gate) return fail(XQ_ERR_INVALID_ARGUMENT, "null gate");
+    __atomic_store_n(((xq_debug_gate*)gate)->host, 1u, __ATOMIC_RELEASE);
+    return XQ_OK;
+}
+
+int xq_debug_gate_destroy(void* gate) {             // after the gated stream has been synchronised
+    if (!gate) return XQ_OK;
+    xq_debug_gate* g = (xq_debug_gate*)gate;
+    __atomic_store_n(g->host, 1u, __ATOMIC_RELEASE);
+    (void)hipHostFree(g->host);
+    delete g;
+    return XQ_OK;
+}
+
 int xq_debug_stream_delay(void* hip_stream, int microseconds) {
+    XQ_TRY(debug_api_enabled("xq_debug_stream_delay"));
     if (microseconds < 0 || microseconds > 200000) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_debug_stream_delay: 0..200000 us");
     if (microseconds == 0) return XQ_OK;
     int rate_khz = 0;
@@ -147,6 +204,7 @@ int xq_debug_stream_delay(void* hip_stream, int microseconds) {
 }
 
 int xq_debug_set_stream_ordering(unsigned mask) {
+    if ((mask & ORD_ALL) != ORD_ALL) XQ_TRY(debug_api_enabled("xq_debug_set_stream_ordering"));      // switching ordering back ON is always allowed
     order_mask() = mask & ORD_ALL;
     return XQ_OK;
 }

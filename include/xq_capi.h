@@ -86,10 +86,19 @@ int xq_stream_destroy(void* hip_stream);
 /* Orders everything queued on waiting_stream from now on behind everything queued on producer_stream so far (one event record + one
  * wait; no host synchronisation) — for the device pointers the caller hands from one handle to another ("Stream ordering" above). */
 int xq_stream_wait_stream(void* waiting_stream, void* producer_stream);
-/* Diagnostics of the ordering tests.  xq_debug_stream_delay queues a kernel that spins for `microseconds` (<= 200000) on hip_stream, so
- * that a producer queued behind it is certainly still running when an unordered consumer starts.  xq_debug_set_stream_ordering: bit mask
- * of the ordering classes the library provides (default XQ_ORDER_ALL); process-wide. */
+/* idle = 1 when everything queued on the stream so far has completed (hipStreamQuery), without blocking. */
+int xq_stream_query(void* hip_stream, int* idle);
+/* Diagnostics of the ordering tests — REFUSED (XQ_ERR_INVALID_ARGUMENT) unless the process runs with XQ_DEBUG_API=1 in its environment:
+ * they stall streams and switch the library's synchronisation off.
+ * xq_debug_stream_gate queues a one-wave kernel on hip_stream that waits until the HOST calls xq_debug_gate_release (or timeout_ms, 1..5000,
+ * have passed: the kernel always ends): whatever is queued behind it is late by construction, not by a guess about durations.
+ * xq_debug_gate_destroy after the stream has been synchronised.  xq_debug_stream_delay queues a kernel that spins for `microseconds`
+ * (<= 200000).  xq_debug_set_stream_ordering: bit mask of the ordering classes the library provides (default XQ_ORDER_ALL);
+ * process-wide; setting it back to XQ_ORDER_ALL is always allowed. */
 enum { XQ_ORDER_RING_CONTENTS = 1, XQ_ORDER_RING_PRIORITIES = 2, XQ_ORDER_RING_DRAW = 4, XQ_ORDER_TRAINER_PARAMS = 8, XQ_ORDER_ALL = 15 };
+int xq_debug_stream_gate(void* hip_stream, int timeout_ms, void** gate);
+int xq_debug_gate_release(void* gate);
+int xq_debug_gate_destroy(void* gate);
 int xq_debug_stream_delay(void* hip_stream, int microseconds);
 int xq_debug_set_stream_ordering(unsigned mask);
 /* HIP-event timing on a given stream, for bench.py's roofline leg (ms between the two records). */

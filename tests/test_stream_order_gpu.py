@@ -2,15 +2,24 @@
 include/xq_capi.h.  No upstream analogue: the reference runs one stream and synchronises the device after every launch
 (dqn.cu:233-236), so its results are those of the fully synchronised leg below.
 
-Every case runs the same call sequence three times with env, replay ring and Q-net each on a stream of its own:
-  sync     : a device synchronisation after every call — the definition;
-  ordered  : no host synchronisation, the producer queued behind a 3 ms delay kernel (xq_debug_stream_delay) so that it is certainly
-             still running when the consumer is queued; must give the bits of `sync`;
-  unordered: the same with the ordering class under test switched off (xq_debug_set_stream_ordering); must NOT give them — the
-             case goes red if the ordering is removed from the library.
+Every case runs the same call sequence with env, replay ring and Q-net each on a stream of its own:
+  sync      : a device synchronisation after every call — the definition;
+  ordered   : no host synchronisation; the producer is queued behind a GATE — a kernel that waits until the host releases it
+              (xq_debug_stream_gate) — and a host timer releases the gate 0.1 ms / 30 ms after the producer was queued: until then the
+              producer CANNOT have run, whatever the kernels' durations.  Both must give the bits of `sync`;
+  unordered : the same (release after 50 ms) with the ordering class under test switched off (xq_debug_set_stream_ordering); must NOT give
+              them — the case goes red if the ordering is removed from the library.  This negative control needs producer and consumer on
+              different hardware queues (two streams that share one run in submission order: the consumer would sit behind the gate by
+              accident).  Every rig PROBES that (gate one stream, watch the others drain) and the negative control is SKIPPED, not
+              failed, where it does not hold.
 The unordered legs only ever read initialised, in-range data (stale slot lists, old transitions), never wild pointers.
 """
 import ctypes as C
+import os
+import threading
+import time
+
+os.environ.setdefault("XQ_DEBUG_API", "1")          # the gate / ordering switches are refused without it (include/xq_capi.h)
 
 import numpy as np
 import pytest
@@ -20,8 +29,9 @@ from test_dqn_gpu import CFG2_NET
 
 pytestmark = pytest.mark.gpu
 
-DELAY_US = 3000
 N, CAP = 1024, 4096
+GATE_TIMEOUT_MS = 1500                               # the gate kernel's own exit, should the host never release it
+LEG = {"name": "sync", "release_after_s": 0.0, "separate": True}
 
 
 @pytest.fixture(scope="module")
@@ -36,14 +46,64 @@ def dsync():
     torch.cuda.synchronize()
 
 
+class Gate:
+    """a kernel on `stream` that ends when release() is called (or after GATE_TIMEOUT_MS); release is armed on a host timer"""
+
+    def __init__(self, xq, stream, release_after_s):
+        self.xq, self.h, self.done = xq, C.c_void_p(), False
+        xq._capi.call("xq_debug_stream_gate", C.c_void_p(stream), GATE_TIMEOUT_MS, C.byref(self.h))
+        self.timer = threading.Timer(release_after_s, self.release)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def release(self):
+        if not self.done:
+            self.done = True
+            self.xq._capi.call("xq_debug_gate_release", self.h)
+
+    def destroy(self):
+        self.timer.cancel()
+        self.release()
+        dsync()
+        self.xq._capi.call("xq_debug_gate_destroy", self.h)
+
+
+def hold(xq, stream, gates):
+    """queue a gate on `stream` in the unsynchronised legs (nothing in the `sync` leg: its every call is followed by a device
+    synchronisation, which a closed gate would block)"""
+    if LEG["name"] != "sync":
+        gates.append(Gate(xq, stream, LEG["release_after_s"]))
+
+
+def idle(xq, stream):
+    v = C.c_int(0)
+    xq._capi.call("xq_stream_query", C.c_void_p(stream), C.byref(v))
+    return bool(v.value)
+
+
+def queues_are_separate(xq, streams):
+    """gate each stream in turn and watch a trivial kernel on the other two complete while the gate is closed"""
+    ok = True
+    for i, s in enumerate(streams):
+        g = Gate(xq, s, 0.2)
+        others = [t for j, t in enumerate(streams) if j != i]
+        for t in others:
+            xq._capi.call("xq_debug_stream_delay", C.c_void_p(t), 1)
+        t0 = time.time()
+        while time.time() - t0 < 0.1 and not all(idle(xq, t) for t in others):
+            time.sleep(0.0005)
+        ok = ok and all(idle(xq, t) for t in others) and not g.done
+        g.destroy()
+    return ok
+
+
 class Rig:
-    """env + ring + Q-net, each on a stream of its own — of three different PRIORITIES, so that no two of them share a hardware queue
-    (streams of one priority are multiplexed onto a few queues, and two streams that happen to share one run in submission order:
-    the unordered legs would then pass by accident, depending on how many streams earlier tests of the process created)."""
+    """env + ring + Q-net, each on a stream of its own — of three different PRIORITIES, which in practice puts them on different
+    hardware queues (streams of one priority are multiplexed onto a few queues); whether it did is probed, see the module docstring."""
 
     def __init__(self, xq, per=False, cap=CAP, n=N, prefill=2, env_nonblocking=False):
         self.xq = xq
-        self.streams = []
+        self.streams, self.gates = [], []
         for prio, nb in ((-1, 1 if env_nonblocking else 0), (1, 0), (0, 0)):
             h = C.c_void_p()
             xq._capi.call("xq_stream_create", prio, nb, C.byref(h))
@@ -76,27 +136,38 @@ class Rig:
             if per:
                 self.rp.per_rebuild()
                 dsync()
+        if LEG["name"] == "unordered":
+            LEG["separate"] = LEG["separate"] and queues_are_separate(xq, [self.env.stream(), self.rp.stream(), self.d.stream()])
 
     def delay(self, stream):
-        self.xq._capi.call("xq_debug_stream_delay", C.c_void_p(stream), DELAY_US)
+        hold(self.xq, stream, self.gates)
 
     def close(self):
+        for g in self.gates:
+            g.destroy()
         dsync()
         self.d.close(); self.rp.close(); self.env.close()
         for h in self.streams:
             self.xq._capi.call("xq_stream_destroy", h)
 
 
-def legs(xq, cls, body):
-    """body(rig_factory, sync: bool) -> comparable result; returns (sync, ordered, unordered)."""
-    out = []
+def run_leg(xq, name, mask, release_after_s, body, arg):
+    LEG.update(name=name, release_after_s=release_after_s)
+    xq._capi.call("xq_debug_set_stream_ordering", mask)
     try:
-        for sync, mask in ((True, xq._capi.ORDER_ALL), (False, xq._capi.ORDER_ALL), (False, xq._capi.ORDER_ALL & ~cls)):
-            xq._capi.call("xq_debug_set_stream_ordering", mask)
-            out.append(body(sync))
+        return body(arg)
     finally:
         xq._capi.call("xq_debug_set_stream_ordering", xq._capi.ORDER_ALL)
-    return out
+        LEG.update(name="sync")
+
+
+def legs(xq, cls, body):
+    """body(sync: bool) -> comparable result; returns (sync, [ordered at 0.1 ms, ordered at 30 ms], unordered, queues separate?)."""
+    ALL = xq._capi.ORDER_ALL
+    LEG["separate"] = True
+    return (run_leg(xq, "sync", ALL, 0.0, body, True),
+            [run_leg(xq, "ordered", ALL, 0.0001, body, False), run_leg(xq, "ordered", ALL, 0.03, body, False)],
+            run_leg(xq, "unordered", ALL & ~cls, 0.05, body, False), LEG["separate"])
 
 
 def same(a, b):
@@ -106,8 +177,11 @@ def same(a, b):
 
 
 def check(res):
-    sync, ordered, unordered = res
-    assert same(sync, ordered), "unsynchronised loop differs from the synchronised one"
+    sync, ordered, unordered, separate = res
+    for o in ordered:
+        assert same(sync, o), "unsynchronised loop differs from the synchronised one"
+    if not separate:
+        pytest.skip("producer and consumer streams share a hardware queue on this box: the ordering-off leg would pass by accident")
     assert not same(sync, unordered), "the case does not exercise the ordering it is named after"
 
 
@@ -282,8 +356,9 @@ def test_parameters_rewritten_between_trainer_iterations(xq):
         t.replay.sample(256, host=False)                                # (allocates the slot list: not inside the sequence under test)
         dsync()
         stream = t.dqn.stream()
+        gates = []
         for _ in range(2):
-            xq._capi.call("xq_debug_stream_delay", C.c_void_p(stream), DELAY_US)
+            hold(xq, stream, gates)
             t.replay.sample(256, host=False)                            # the caller's own update, asynchronous on the handle's stream
             t.dqn.td_grads_replay(t.replay, 256, td_net=0, mode=0)
             t.dqn.apply_grads(0.5, 1.0)                                 # a large step: the greedy moves change
@@ -292,6 +367,8 @@ def test_parameters_rewritten_between_trainer_iterations(xq):
             t.step(1)
             if sync:
                 dsync()
+        for g in gates:
+            g.destroy()
         dsync()
         boards, meta = t.env.get_state()
         w, b = t.dqn.get_params()
@@ -337,4 +414,8 @@ def test_stream_wait_stream_orders_raw_pointer_exchanges(xq, direction):
             out = [q.cpu().numpy()]
         r.close()
         return out
-    check([body("sync"), body("wait"), body("nothing")])
+    ALL = xq._capi.ORDER_ALL
+    LEG["separate"] = True
+    check((run_leg(xq, "sync", ALL, 0.0, body, "sync"),
+           [run_leg(xq, "ordered", ALL, 0.0001, body, "wait"), run_leg(xq, "ordered", ALL, 0.03, body, "wait")],
+           run_leg(xq, "unordered", ALL, 0.05, body, "nothing"), LEG["separate"]))
