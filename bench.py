@@ -602,8 +602,13 @@ def main():
                 if k["name"] == nm and k["launches"]:
                     chain[nm] = dict(avg_us=1e3 * k["ms"] / k["launches"], launches_per_step=k["launches"] / args.chain_steps)
         torch.cuda.synchronize()
+    # candidates for `roofline`: the kernels ON the step's dependency chain — the handle's stream, and the select chain too when an
+    # update has several plies (then the plies are the long pole).  With one ply per update the select chain runs beside the TD step,
+    # ends before it and reads stretched by the co-scheduling (35 us against 15-28 alone): its share is not the step's.
+    def on_chain(k):
+        return plies > 1 or not (k.endswith("@select") or k == "env_selfplay_step")
     per_step_us = {k: v["avg_us"] * v["launches_per_step"] for k, v in chain.items()
-                   if v["launches_per_step"] >= 0.5 and k != "rccl_allreduce_grads"}       # (a target sync every 10th step is not a step kernel)
+                   if v["launches_per_step"] >= 0.5 and k != "rccl_allreduce_grads" and on_chain(k)}   # (a target sync every 10th step is not a step kernel)
     dominant = max(per_step_us, key=per_step_us.get) if per_step_us else None
     live_names = [n for n in (dominant, "gemm_qmax_screen", "gemm_qmax_rowmax", "env_selfplay_step", "rccl_allreduce_grads") if n]
     t.dqn.kernel_filter(sorted(set(live_names)) if dominant else None)
@@ -880,8 +885,9 @@ def main():
                 dom = next(e for e in entries if e["kernel"] == dominant)
                 st = stats.get(dominant)
                 r = {"kernel": "%s = %s (%s)" % (dominant, dom.get("rocprof_kernel"), dom.get("what", "")),
-                     "why_this_kernel": "largest share of the timed step among all kernels of both streams (%.0f %%); rounds 1-3 priced the "
-                                        "max_a' Q(s',a') product here, now `roofline_qmax`" % (100 * dom["share_of_step"]),
+                     "why_this_kernel": "largest share of the timed step among the kernels on its dependency chain (%.0f %%; the handle's "
+                                        "stream%s)" % (100 * dom["share_of_step"], " and the select chain: several plies per update" if plies > 1 else
+                                                       "; the select chain runs beside it with slack"),
                      "bound": dom.get("bound"), "peak": dom.get("peak"), "unit": dom.get("unit"), "traffic": dom.get("traffic"),
                      "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, offline)", "traffic_source": dom.get("traffic_source"),
                      "share_of_step": dom["share_of_step"], "launches_per_step": dom["launches_per_step"]}

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
                                 sum = z == 0 ? t : sum + t;
                             }
                         }
-                        return tanhf(qbias[e] + sum);
+                        return qbias[e] + sum;                                       // pre-activation: tanh below, on the candidates only
                     };
                     S.q[lane] = q_pre(0);
                     if (lane < 26) S.q[64 + lane] = q_pre(1);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
                             if (z + 3 < P.q_nslabs) t += p[(z + 2) * P.q_slab_stride] + p[(z + 3) * P.q_slab_stride];
                             sum = z == 0 ? t : sum + t;
                         }
-                        return tanhf(P.q_bias[j] + sum);
+                        return P.q_bias[j] + sum;
                     };
                     S.q[lane] = q_of(lane);
                     if (lane < 26) S.q[64 + lane] = q_of(64 + lane);
@@ -170,8 +170,14 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams P) {
                 wave_sync();
                 const float NEG = -__builtin_inff();
                 float v0 = NEG, v1 = NEG;
-                if (lane < n_moves) v0 = S.q[S.moves[lane] % 90];             // q[action.to], dqn.cpp:47
-                if (lane + 64 < n_moves) v1 = S.q[S.moves[lane + 64] % 90];
+                // q[action.to], dqn.cpp:47.  From slabs S.q holds the head's PRE-activations and tanh (libm's, the output layer's: same
+                // argument, same bits as a tanh per output) is taken of the candidates' values only: one pass over the wave for the usual
+                // <= 64 moves instead of two passes over the 90 outputs (~40 vector instructions each)
+                const bool pre = P.q_slabs != nullptr;
+                if (lane < n_moves) { v0 = S.q[S.moves[lane] % 90]; if (pre) v0 = tanhf(v0); }
+                if (n_moves > 64) {                                            // (wave-uniform)
+                    if (lane + 64 < n_moves) { v1 = S.q[S.moves[lane + 64] % 90]; if (pre) v1 = tanhf(v1); }
+                }
                 if (!(v0 == v0)) v0 = NEG;                                     // NaN never wins `q > maxQ`
                 if (!(v1 == v1)) v1 = NEG;
                 const float ma = wave_max(v0), mb = wave_max(v1);

@@ -28,6 +28,13 @@ K = len(Z["action_to"])
 GOOD = int(Z["first_bad_ply"][0])          # plies [0, GOOD) ran with the released block intact
 
 
+def onehot(codes):
+    """chessai.cpp:268-289: index sq * 14 + (piece code - 1)"""
+    x = np.zeros(SIZES[0])
+    x[[sq * 14 + int(c) - 1 for sq, c in enumerate(codes) if c]] = 1.0
+    return x
+
+
 def test_the_recorded_run_is_usable():
     assert SIZES == [1260, 128, 8100] and K == 16 and (LR, GAMMA) == (0.001, 0.99)
     assert GOOD >= 8, "the allocator handed the released block on too early in the recorded run: regenerate the fixture"
@@ -75,7 +82,7 @@ def test_hip_td_path_follows_the_reference_trajectory():
     nhid = SIZES[1]
     worst_q = worst_y = 0.0
     for t in range(GOOD):
-        x = np.zeros(SIZES[0]); x[[sq * 14 + c - 1 for sq, c in enumerate(Z["states"][t]) if c]] = 1.0
+        x = onehot(Z["states"][t])
         q = d.getQValues(x)
         worst_q = max(worst_q, np.abs(q[:96] - Z[f"ply{t}_q"]).max())
         qsa, y = d.td_update(Z["states"][t][None], Z["next_states"][t][None], Z["action_to"][t:t + 1], Z["reward"][t:t + 1], Z["done"][t:t + 1],
@@ -85,6 +92,6 @@ def test_hip_td_path_follows_the_reference_trajectory():
         assert np.abs(gb[:nhid] - Z[f"ply{t}_hidden_biases"]).max() < 2e-5 and np.abs(gb[nhid:nhid + 96] - Z[f"ply{t}_out_biases"]).max() < 2e-5
     assert worst_q < 1e-4 and worst_y < 1e-4 * max(1.0, np.abs(Z["reward"]).max()), (worst_q, worst_y)
     if GOOD == K:
-        x = np.zeros(SIZES[0]); x[[sq * 14 + c - 1 for sq, c in enumerate(Z["states"][0]) if c]] = 1.0
+        x = onehot(Z["states"][0])
         assert np.abs(d.getQValues(x)[:96] - Z["final_q_of_first_state"]).max() < 1e-4          # after 16 updates
     d.close()

@@ -41,6 +41,9 @@ def census(tag, updates):
     rec = {"at": tag, "updates": updates, "boards": n, "pieces_per_board": r_now / n, "rows_segmented": r_now, "rows_majority_complement": r_min,
            "ratio": r_min / max(r_now, 1), "squares_where_a_piece_is_the_majority": int((cls[1:].max(0) > cls[0]).sum()),
            "mean_share_of_the_commonest_piece_on_squares_above_30pct": home_keep}
+    occ = np.sort(occupied.astype(np.float64) / n)[::-1]
+    rec["occupancy_sorted_top"] = [round(float(x), 3) for x in occ[:56]]
+    rec["rows_outside_the_top_k_squares"] = {str(k): int(round(float(occ[k:].sum() * n))) for k in (24, 32, 40, 48, 56, 64, 72)}
     print(json.dumps(rec), flush=True)
     return rec
 
