@@ -994,7 +994,7 @@ static int l0_gradient(xq_dqn* d, int n, float* dst) {
         d->tail_open = was_open;
         XQ_HIP(hipGetLastError());
         const size_t shmem = l0m_lds_bytes();
-        const double fl = 2.0 * 96 * 16 * (double)H * kpad * 3, by = 6.0 * H * kpad + 2.0 * need_sel + 4.0 * nchunks * len;
+        const double fl = 2.0 * 80 * 16 * (double)H * kpad * 3, by = 6.0 * H * kpad + 2.0 * need_sel + 4.0 * nchunks * len;
         if (d->tail_open) {
             TailArgs& T = *d->tail;
             T.l0_n = n; T.l0_H = H; T.l0_chunk = chunk; T.l0_nch = nchunks; T.l0_partial = out;

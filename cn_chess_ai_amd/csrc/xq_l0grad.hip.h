@@ -8,9 +8,11 @@
 //   * the one-hot operand is 0 / 1 — exact in bf16;
 //   * delta0 = hi + mid + lo with three bf16 values per fp32 (8 + 8 + 8 significant bits; each residual is formed exactly in fp32), so
 //     every product is exact and the MFMA accumulates in fp32: the result differs from a sequential fp32 sum only by summation order.
-// v_mfma_f32_16x16x32_bf16 with M = 16 columns of delta0, N = 16 planes of ONE square (14 used), K = 32 samples; a wave owns 2 column
-// tiles x 6 squares (12 accumulators); the four waves of a block take four groups of 6 squares and the SAME 32 columns, whose operand
-// tile goes global -> LDS once per block (50 MB through L2 per step).  Grid 4 square groups x H/32 column blocks x n/1024 chunks.
+// v_mfma_f32_16x16x32_bf16 with M = 16 columns of delta0, N = 16 consecutive ROWS of gW0^T (row = square * 14 + plane: the 1260 rows are
+// packed into 79 tiles of 16 — a tile spans two or three squares — instead of 90 squares x 16 planes with two planes idle: 17 % fewer
+// MFMAs), K = 32 samples; a wave owns 2 column tiles x 5 row tiles (10 accumulators); the four waves of a block take 20 consecutive row
+// tiles and the SAME 32 columns, whose operand tile goes global -> LDS once per block (50 MB through L2 per step).  Grid 4 row groups
+// x H/32 column blocks x n/1024 chunks.
 // The first form (round 4; 28.7 us alone at 8192 x 256, profiles/r04_g_*) derived the one-hot operand from nibble code words in
 // registers; its loop was ISSUE-bound, not matrix-pipe-bound: per 32-sample k-step and wave 36 MFMAs (576 cycles) sat beside ~180
 // vector instructions — 78 to derive six one-hot fragments (13 each), ~80 accumulator-register moves the compiler made of rotating
@@ -23,16 +25,18 @@
 //   * the selector words travel like the delta tile: global -> LDS by LDS-DMA, [square][k-octet][encoding][8 samples] so that a
 //     fragment is one conflict-free ds_read_b128 — the block has no transposition prologue (6 of the old kernel's 28 us);
 //   * 64 samples per barrier (two MFMA k-steps), a ring of three stages, every fragment read issued one k-step ahead of its MFMAs.
-// Per k-step and wave: 36 MFMAs, 24 v_perm, 12 ds_read_b128.
+// Per k-step and wave: 30 MFMAs, 20 v_perm, 11 ds_read_b128.
 #pragma once
 
 #include "xq_gemm.hip.h"
 
 namespace xq {
 
-constexpr int kL0mRS = 6;                 // squares per wave
+constexpr int kL0mRS = 5;                 // 16-row tiles per wave
 constexpr int kL0mRC = 2;                 // 16-column tiles per wave
-constexpr int kL0mSqB = 4 * kL0mRS;        // squares per block: 24; 4 groups cover squares 0..95 (90..95: empty)
+constexpr int kL0mRowsB = 4 * kL0mRS * 16; // rows of gW0^T per block: 320; 4 row groups cover rows 0..1279 (1260..1279: nothing)
+constexpr int kL0mSqB = 24;               // squares whose selector words a block stages: rows 320 g .. 320 g + 319 lie on squares
+                                          // floor(320 g / 14) .. + 23
 constexpr int kL0mCols = 16 * kL0mRC;      // columns per block: 32
 constexpr int kL0mStageK = 64;            // samples per stage
 constexpr int kL0mAPieces = 2 * 3 * kL0mRC;            // (k-step, plane, 16-column tile) x 1 KB = 16 columns x 32 k
@@ -127,8 +131,8 @@ __global__ __launch_bounds__(256) void delta_split_kernel(const float* __restric
     delta_split_block(d0, n, H, planes, plane_stride, kpad, (int)blockIdx.x, (int)blockIdx.y, tile);
 }
 
-// One block: square group `sqg` (24 squares), column block `cb` (32 columns), sample chunk `ch` (`chunk` samples, a multiple of 64).
-// smem: l0m_lds_bytes(), 1-KB aligned.  partial: [chunks][1260][H].  Wave w owns squares 24 sqg + 6 w .. + 5 and all 32 columns.
+// One block: row group `sqg` (rows 320 sqg .. + 319 of gW0^T), column block `cb` (32 columns), sample chunk `ch` (`chunk` samples, a
+// multiple of 64).  smem: l0m_lds_bytes().  partial: [chunks][1260][H].  Wave w owns row tiles 20 sqg + 5 w .. + 4 and all 32 columns.
 template <int DBG = 0>
 __device__ __forceinline__ void l0_grad_mfma_block(const uint16_t* __restrict__ sel, const uint16_t* __restrict__ planes,
                                                     long long plane_stride, int kpad, int H, int chunk, float* __restrict__ partial,
@@ -157,7 +161,7 @@ __device__ __forceinline__ void l0_grad_mfma_block(const uint16_t* __restrict__ 
         for (int i = 3; i < 5; ++i) {
             const int sp = i == 3 ? wid : 4 + (wid & 1), kk = sp / 3, q = sp - 3 * kk;
             piece[i] = kL0mAPieces + sp;
-            const int sq = sqg * kL0mSqB + q * 8 + (lane >> 3), gg = (lane >> 1) & 3, enc = lane & 1;
+            const int sq = (sqg * kL0mRowsB) / 14 + q * 8 + (lane >> 3), gg = (lane >> 1) & 3, enc = lane & 1;
             voff[i] = (unsigned)((((long long)sq * octs + (c0 >> 3) + kk * 4 + gg) * 2 + enc) * 16);
         }
     }
@@ -181,20 +185,26 @@ __device__ __forceinline__ void l0_grad_mfma_block(const uint16_t* __restrict__ 
     for (int c = 0; c < kL0mRC; ++c)
 #pragma unroll
         for (int j = 0; j < kL0mRS; ++j) acc[c][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // per-lane table of v_perm_b32: byte `idx` of the 8-byte table {S0 : S1} = 0x40 (the high byte of bf16 2.0); selector 0 (empty
-    // square, a piece of the other encoding, every LOW byte of a half-word) picks byte 0 = 0.  Lane n is plane n of its squares (the
-    // MFMA's N index): planes 0..6 = pieces 1..7 (encoding 0, index n + 1), planes 7..13 = pieces 8..14 (encoding 1, index n - 6);
-    // lanes 14 and 15 have index 8: an all-zero table.
-    const int enc = m >= 7 ? 1 : 0;
-    const int idx = m >= 14 ? 8 : (enc ? m - 6 : m + 1);
-    const uint32_t tlo = idx < 4 ? 0x40u << (8 * idx) : 0u, thi = (idx >= 4 && idx < 8) ? 0x40u << (8 * (idx - 4)) : 0u;
-    // fragment offsets inside a stage
-    const unsigned aoff = (unsigned)(m * 64 + ((g ^ ((m >> 1) & 3)) << 4));
+    // per-lane tables of v_perm_b32, one per row tile: lane n of tile j is row r = 320 sqg + 16 (5 w + j) + n of gW0^T = plane r % 14 of
+    // square r / 14.  Byte `idx` of the 8-byte table {S0 : S1} = 0x40 (the high byte of bf16 2.0); selector 0 (empty square, a piece of
+    // the other encoding, every LOW byte of a half-word) picks byte 0 = 0.  Planes 0..6 = pieces 1..7 (encoding 0, index plane + 1), planes
+    // 7..13 = pieces 8..14 (encoding 1, index plane - 6); rows >= 1260 have index 8: an all-zero table.
+    // fragment offsets inside a stage: the delta fragment as before; the selector fragment of tile j is the lane's OWN square's 16 bytes
+    // [octet g][encoding] (the lanes of a tile read two or three squares).
+    uint32_t tlo[kL0mRS], thi[kL0mRS];
     unsigned soff[kL0mRS];
+    const unsigned aoff = (unsigned)(m * 64 + ((g ^ ((m >> 1) & 3)) << 4));
+    const int sq0 = (sqg * kL0mRowsB) / 14;
 #pragma unroll
     for (int j = 0; j < kL0mRS; ++j) {
-        const int sqw = wid * kL0mRS + j;
-        soff[j] = (unsigned)((kL0mAPieces + (sqw >> 3)) * 1024 + (sqw & 7) * 128 + g * 32 + enc * 16);
+        const int r = sqg * kL0mRowsB + (wid * kL0mRS + j) * 16 + m;
+        const int sq = r / 14, pl = r - sq * 14;
+        const int enc = pl >= 7 ? 1 : 0;
+        const int idx = r >= kStateSize ? 8 : (enc ? pl - 6 : pl + 1);
+        tlo[j] = idx < 4 ? 0x40u << (8 * idx) : 0u;
+        thi[j] = (idx >= 4 && idx < 8) ? 0x40u << (8 * (idx - 4)) : 0u;
+        const int sl = min(sq - sq0, kL0mSqB - 1);
+        soff[j] = (unsigned)((kL0mAPieces + (sl >> 3)) * 1024 + (sl & 7) * 128 + g * 32 + enc * 16);
     }
     // ---- the loop: ONE barrier per 64-sample stage, placed in the middle of the stage ------------------------------------------------
     // Stage st's fragments are read one k-step ahead of their MFMAs: k-step 1's at the top of the stage (under k-step 0's MFMAs),
@@ -203,24 +213,25 @@ __device__ __forceinline__ void l0_grad_mfma_block(const uint16_t* __restrict__ 
     // buffer stage st - 1 was read from; every wave's last read of that buffer (k-step 1 of stage st - 1, requested at the top of that
     // stage) returned before the barrier in the middle of stage st - 1.
     struct Frags { bf16x8 a[kL0mRC][3]; uint4 sw[kL0mRS]; };
-    // the 12 fragment reads of a k-step in the order their consumers come: selector word of square 0 (the previous k-step's last group
+    // the 11 fragment reads of a k-step in the order their consumers come: selector word of tile 0 (the previous k-step's last group
     // turns it into a one-hot), then plane by plane
+    constexpr int kReads = 6 + kL0mRS;
     auto read_frag = [&](Frags& f, unsigned boff, int kk, int i) {
         const unsigned char* sp = smem + boff;
-        constexpr int kind[12] = {0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 0, 0};      // 0: selector word, 1: delta fragment
-        constexpr int arg[12] = {0, 0, 1, 1, 2, 3, 2, 4, 5, 3, 4, 5};       // square j, or t * 2 + c
+        constexpr int kind[kReads] = {0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 0};     // 0: selector word, 1: delta fragment
+        constexpr int arg[kReads] = {0, 0, 1, 1, 2, 3, 2, 4, 5, 3, 4};      // tile j, or t * 2 + c
         if (kind[i] == 0) f.sw[arg[i]] = *reinterpret_cast<const uint4*>(sp + kk * 3 * 1024 + soff[arg[i]]);
         else f.a[arg[i] & 1][arg[i] >> 1] = *reinterpret_cast<const bf16x8*>(sp + (kk * 6 + arg[i]) * 1024 + aoff);
     };
     auto read_frags = [&](Frags& f, unsigned boff, int kk) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) read_frag(f, boff, kk, i);
+        for (int i = 0; i < kReads; ++i) read_frag(f, boff, kk, i);
     };
-    auto onehot2 = [&](uint32_t x, uint32_t y, uint32_t& ox, uint32_t& oy) {
+    auto onehot2 = [&](int j, uint32_t x, uint32_t y, uint32_t& ox, uint32_t& oy) {
         if (DBG == 3 || DBG == 6) { ox = x; oy = y; }
-        else { ox = __builtin_amdgcn_perm(thi, tlo, x); oy = __builtin_amdgcn_perm(thi, tlo, y); }
+        else { ox = __builtin_amdgcn_perm(thi[j], tlo[j], x); oy = __builtin_amdgcn_perm(thi[j], tlo[j], y); }
     };
-    // one k-step: 6 groups (squares) x 3 MFMA pairs (planes) on the wave's 12 accumulators.  Between the pairs, pinned there by
+    // one k-step: 5 groups (row tiles) x 3 MFMA pairs (planes) on the wave's 10 accumulators.  Between the pairs, pinned there by
     // sched_barrier: the one-hot operand of the NEXT group (v_perm_b32 x 2 per pair; the next square of this k-step, or square 0 of
     // `nxt`), and side(pair) — ONE of the next k-step's fragment reads or ONE LDS-DMA piece.  An MFMA holds the vector issue for 8 of its
     // 16 cycles, so a pair has room for ~16 cycles of other instructions; left alone hipcc puts a k-step's 24 v_perm, its 12 reads and
@@ -233,20 +244,21 @@ __device__ __forceinline__ void l0_grad_mfma_block(const uint16_t* __restrict__ 
         for (int j = 0; j < kL0mRS; ++j) {
             const bf16x8 b = __builtin_bit_cast(bf16x8, o);
             const uint4 nx = j + 1 < kL0mRS ? f.sw[j + 1] : nxt.sw[0];
+            const int jn = j + 1 < kL0mRS ? j + 1 : 0;
             uint4 on;
             if (DBG == 2) {                                      // no MFMAs: their operands stay alive, nothing else changes
                 asm volatile("" : "+v"(acc[0][j]), "+v"(acc[1][j]) : "v"(f.a[0][0]), "v"(f.a[1][0]), "v"(f.a[0][1]), "v"(f.a[1][1]), "v"(f.a[0][2]), "v"(f.a[1][2]), "v"(b));
-                onehot2(nx.x, nx.y, on.x, on.y); onehot2(nx.z, nx.w, on.z, on.w);
+                onehot2(jn, nx.x, nx.y, on.x, on.y); onehot2(jn, nx.z, nx.w, on.z, on.w);
                 side(3 * j); side(3 * j + 1); side(3 * j + 2);
             } else {
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %4, %1"
                              : "+v"(acc[0][j]), "+v"(acc[1][j]) : "v"(f.a[0][0]), "v"(f.a[1][0]), "v"(b));
-                onehot2(nx.x, nx.y, on.x, on.y);
+                onehot2(jn, nx.x, nx.y, on.x, on.y);
                 side(3 * j);
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %4, %1"
                              : "+v"(acc[0][j]), "+v"(acc[1][j]) : "v"(f.a[0][1]), "v"(f.a[1][1]), "v"(b));
-                onehot2(nx.z, nx.w, on.z, on.w);
+                onehot2(jn, nx.z, nx.w, on.z, on.w);
                 side(3 * j + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %4, %1"
@@ -266,42 +278,45 @@ __device__ __forceinline__ void l0_grad_mfma_block(const uint16_t* __restrict__ 
     read_frags(f0, 0u, 0);
     if (DBG == 6) read_frags(f1, 0u, 1);
     uint4 o;
-    onehot2(f0.sw[0].x, f0.sw[0].y, o.x, o.y);
-    onehot2(f0.sw[0].z, f0.sw[0].w, o.z, o.w);
+    onehot2(0, f0.sw[0].x, f0.sw[0].y, o.x, o.y);
+    onehot2(0, f0.sw[0].z, f0.sw[0].w, o.z, o.w);
     asm volatile("s_nop 1" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
     unsigned b_cur = 0u, b_nxt = (unsigned)kL0mStageB, b_far = 2u * kL0mStageB;
     for (int st = 0; st < nst; ++st) {
         // (the last two stages request 64 / 128 samples past the chunk — the next chunk, the next column or the slack behind the arrays —
         // into buffers nobody reads any more)
+        // (15 slots per k-step: 11 reads, then LDS-DMA pieces — four of stage st + 2's five here, the fifth in the second k-step)
         kstep(f0, f1, o, [&](int p) {
             if (DBG == 6) return;
-            if (p < 12) read_frag(f1, b_cur, 1, p);
-            else if (p < 17 && DBG != 4) issue1(st + 2, b_far, p - 12);
+            if (p < kReads) read_frag(f1, b_cur, 1, p);
+            else if (p < kReads + 4 && DBG != 4) issue1(st + 2, b_far, p - kReads);
         });
-        if (DBG != 4 && DBG != 6) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");        // stage st + 1 has landed (this wave's pieces)
+        // stage st + 1 has landed (this wave's pieces): all but the four youngest operations — stage st + 2's first four — are done
+        if (DBG != 4 && DBG != 6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // my reads of stage st have returned
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         kstep(f1, f0, o, [&](int p) {
             if (DBG == 6) return;
-            if (p < 12) read_frag(f0, b_nxt, 0, p);
+            if (p < kReads) read_frag(f0, b_nxt, 0, p);
+            else if (p == kReads && DBG != 4) issue1(st + 2, b_far, 4);
         });
         const unsigned t = b_cur; b_cur = b_nxt; b_nxt = b_far; b_far = t;
     }
     // no DMA may still be writing LDS when the block ends; and the last MFMAs' results need 8+ wait states before anything but an
     // accumulating MFMA reads them (hipcc does not know the statements above were MFMAs)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-    // D: lane (n = lane & 15, g): plane n of every square, columns 16 c + 4 g .. + 3 of the block's 32
-    if (m < 14) {
+    // D: lane (n = lane & 15, g): row n of every row tile, columns 16 c + 4 g .. + 3 of the block's 32
+    {
         float* out = partial + ((long long)ch * kStateSize) * H;
 #pragma unroll
         for (int j = 0; j < kL0mRS; ++j) {
-            const int sq = sqg * kL0mSqB + wid * kL0mRS + j;
-            if (sq >= kSquares) continue;
+            const int r = sqg * kL0mRowsB + (wid * kL0mRS + j) * 16 + m;
+            if (r >= kStateSize) continue;
 #pragma unroll
             for (int c = 0; c < kL0mRC; ++c) {
                 const f32x4 v = acc[c][j];
-                *reinterpret_cast<float4*>(out + (long long)(sq * 14 + m) * H + cb * kL0mCols + 16 * c + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(out + (long long)r * H + cb * kL0mCols + 16 * c + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
     }

@@ -194,10 +194,10 @@ def step_work(layers, minibatch, n_games, plies=1, bf16=False, bf16_bwd=False, t
         nch = (B + chunk - 1) // chunk
         kpad = nch * chunk
         if mfma0:
-            # one-hot^T x delta_0: 96 squares x 16 planes x H1 columns x kpad samples x 3 bf16 planes of delta_0 (what the pipe executes;
+            # one-hot^T x delta_0: 80 tiles of 16 rows of gW0^T (1260 rows packed) x H1 columns x kpad samples x 3 bf16 planes of delta_0 (what the pipe executes;
             # the useful part is the ~32 occupied (square, piece) pairs per sample).  Bytes: the three planes and the selector words
             # in, delta_0 itself for the bias sums, the chunk partial sums out.
-            fl = 2.0 * 96 * 16 * H1 * kpad * 3
+            fl = 2.0 * 80 * 16 * H1 * kpad * 3
             by = 6.0 * H1 * kpad + 4.0 * 96 * kpad + B * H1 * 4 + nch * STATE * H1 * 4
         else:
             fl = 2.0 * B * 32 * H1
@@ -216,7 +216,7 @@ def step_work(layers, minibatch, n_games, plies=1, bf16=False, bf16_bwd=False, t
                                                  if mfma0 else "as per-(square, piece) segmented sums of delta rows || ")
             + ("hidden weight-gradient product || " if k == 2 else "") + "bias column sums")
         if mfma0:
-            w["td_tail_l0"]["mfma_bf16_flops"] = 2.0 * 96 * 16 * H1 * kpad * 3
+            w["td_tail_l0"]["mfma_bf16_flops"] = 2.0 * 80 * 16 * H1 * kpad * 3
             if "td_tail_deltas" in w:                    # the launch that makes delta_0 also writes its planes and the selector words
                 w["td_tail_deltas"]["hbm_bytes"] += (6.0 * H1 * kpad + 4.0 * 96 * kpad + 48 * B) / max(1, k - 1)
         slabs = nch * STATE * H1 + nch_out * (96 * Hl + 96) + R * sum(h)
@@ -246,7 +246,7 @@ def step_work(layers, minibatch, n_games, plies=1, bf16=False, bf16_bwd=False, t
         nch = (B + chunk - 1) // chunk
         if mfma0:
             kpad = nch * chunk
-            put("l0_grad_segsum", 2.0 * 96 * 16 * H1 * kpad * 3, 6.0 * H1 * kpad + 4.0 * 96 * kpad + nch * STATE * H1 * 4, "mfma",
+            put("l0_grad_segsum", 2.0 * 80 * 16 * H1 * kpad * 3, 6.0 * H1 * kpad + 4.0 * 96 * kpad + nch * STATE * H1 * 4, "mfma",
                 "layer-0 gradient as the exact product one-hot^T x delta_0 on the bf16 matrix pipe (3-term split)", PEAK_BF16_MFMA_TFLOPS)
             put("l0_delta_split", 8.0 * B * H1, B * H1 * 4 + 6.0 * H1 * kpad, "hbm", "delta_0 -> three transposed bf16 planes (hi, mid, lo)")
             put("l0_sel_words", 0.0, 48 * B + 4.0 * 96 * kpad, "hbm", "boards -> selector half-words of the one-hot operand")

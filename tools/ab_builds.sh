@@ -3,8 +3,8 @@
 # usage: tools/ab_builds.sh TAG CONFIG [rounds] [steps]
 TAG=${1:-ab}; CFG=${2:-2}; R=${3:-3}; STEPS=${4:-300}
 for i in $(seq 1 $R); do
-  python3 bench.py --config $CFG --steps $STEPS --warmup 20 --no-cpu-baseline --no-variants --repeats 3 > gpurun_out/${TAG}_new_$i.json 2>/dev/null
-  XQ_LIBXQHIP=tools/_build/prev/libxqhip.so python3 bench.py --config $CFG --steps $STEPS --warmup 20 --no-cpu-baseline --no-variants --repeats 3 > gpurun_out/${TAG}_prev_$i.json 2>/dev/null
+  python3 bench.py --config $CFG --steps $STEPS --warmup 20 --no-cpu-baseline --no-variants --no-facade --no-chain --repeats 3 > gpurun_out/${TAG}_new_$i.json 2>/dev/null
+  XQ_LIBXQHIP=tools/_build/prev/libxqhip.so python3 bench.py --config $CFG --steps $STEPS --warmup 20 --no-cpu-baseline --no-variants --no-facade --no-chain --repeats 3 > gpurun_out/${TAG}_prev_$i.json 2>/dev/null
 done
 python3 - <<PY
 import json, glob
