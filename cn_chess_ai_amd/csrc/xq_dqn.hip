@@ -1009,7 +1009,7 @@ static int l0_gradient(xq_dqn* d, int n, float* dst) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(l0_grad_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
                 granted = true;
             }
-            hipLaunchKernelGGL(l0_grad_mfma_kernel<0>, dim3(4, H / kL0mCols, nchunks), dim3(256), shmem, d->cur, d->l0_sel, d->l0_planes, plane_stride,
+            hipLaunchKernelGGL(l0_grad_mfma_kernel<0>, dim3(H / kL0mCols, 4, nchunks), dim3(256), shmem, d->cur, d->l0_sel, d->l0_planes, plane_stride,
                                kpad, H, chunk, out);
             XQ_HIP(hipGetLastError());
         }
@@ -1630,7 +1630,8 @@ static int tail_gradients_impl(xq_dqn* d, int n, float* const* outs, float* G, i
     // two hidden layers: the one weight-gradient product runs beside the layer-0 sums (L2-bound) rather than beside the delta product
     // (both MFMA-bound, and the select chain's Q head is on the chip at that time): 0.2065 against 0.2086 ms per step of the headline
     // bench; three hidden layers (bench --config 4): no difference, kept beside the delta products
-    const bool defer_grad = nl == 3;
+    static const bool grad_early = getenv("XQ_TAIL_GRAD_EARLY") != nullptr;     // A/B switch (tools/ab_env.sh)
+    const bool defer_grad = nl == 3 && !grad_early;
     int waiting = -1;
     for (int l = nl - 3; l >= 0; --l) {
         tail_begin(d);

@@ -326,7 +326,9 @@ template <int DBG = 0>
 __global__ __launch_bounds__(256) void l0_grad_mfma_kernel(const uint16_t* __restrict__ sel, const uint16_t* __restrict__ planes,
                                                             long long plane_stride, int kpad, int H, int chunk, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char l0m_smem[];
-    l0_grad_mfma_block<DBG>(sel, planes, plane_stride, kpad, H, chunk, partial, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, l0m_smem);
+    // grid (H / 32, 4, chunks): the column block is the fastest index, so that an XCD (workgroups round-robin in linear order) keeps to
+    // its own columns' planes
+    l0_grad_mfma_block<DBG>(sel, planes, plane_stride, kpad, H, chunk, partial, (int)blockIdx.y, (int)blockIdx.x, (int)blockIdx.z, l0m_smem);
 }
 
 }  // namespace xq

@@ -81,7 +81,7 @@ __device__ __forceinline__ void scr_dma4(const void* base, unsigned o0, unsigned
 // ---- pieces of the main loop (all indices that select registers are template arguments: static indexing, no scratch) ----
 // k-steps [SBEG, SBEG + SCNT) of one unit: per step 2 ds_read_b128 (row tiles) and 2 NS MFMAs; the reads of step s + 1 are issued
 // before the MFMAs of step s.  fr = this lane's fragment offset inside a unit (see the kernel), buf = the unit's LDS buffer.
-template <int KU, int NS, int KUI, int SBEG, int SCNT>
+template <int KU, int NS, int KUI, int SBEG, int SCNT, bool M16 = false>
 __device__ __forceinline__ void scr_mma(const unsigned char* buf, unsigned fr, const bf16x8 (&bfrag)[NS][16 * KU], f32x16 (&acc)[2][NS]) {
     bf16x8 af[2][2];
 #pragma unroll
@@ -95,8 +95,20 @@ __device__ __forceinline__ void scr_mma(const unsigned char* buf, unsigned fr, c
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < NS; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bfrag[j][KUI * 16 + s], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NS; ++j) {
+                if (M16) {
+                    // TIMING PROBE ONLY (tools/screen_probe.hip, DBG & 16; the values are meaningless): the same matrix-pipe cycles, operand
+                    // registers and LDS reads as the line below, issued as two v_mfma_f32_16x16x32_bf16 — does the chip hold a higher clock
+                    // on that shape inside this loop (MI355X_MICROARCH.md, DVFS give-back item 7)?
+                    f32x4 c0 = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, c1 = {acc[i][j][4], acc[i][j][5], acc[i][j][6], acc[i][j][7]};
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s & 1][i], bfrag[j][KUI * 16 + s], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s & 1][i], bfrag[j][KUI * 16 + s], c1, 0, 0, 0);
+                    acc[i][j][0] = c0[0]; acc[i][j][1] = c0[1]; acc[i][j][2] = c0[2]; acc[i][j][3] = c0[3];
+                    acc[i][j][4] = c1[0]; acc[i][j][5] = c1[1]; acc[i][j][6] = c1[2]; acc[i][j][7] = c1[3];
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bfrag[j][KUI * 16 + s], acc[i][j], 0, 0, 0);
+                }
+            }
     }
 }
 // accumulators of a chunk = its rows' biases (the first MFMA of every tile adds onto them): one ds_read_b128 per 4 rows
@@ -164,7 +176,7 @@ __device__ __forceinline__ void scr_wait_landed(bool more, bool stored) {
 }
 
 // DBG (tools/screen_probe.hip only; 0 in the library): 1 = no fold (stores one accumulator element), 2 = no activation loads,
-// 4 = no LDS-DMA in the loop, 8 = s_memtime / s_memrealtime stamps into a.dbg
+// 4 = no LDS-DMA in the loop, 8 = s_memtime / s_memrealtime stamps into a.dbg, 16 = timing probe of the 16x16x32 MFMA shape (scr_mma)
 template <int KU, int NS, int MODE = SCR_TOP2, int DBG = 0>
 __global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
     constexpr int NSTORES = (MODE == SCR_MAX ? 1 : 2) * NS;     // partial stores of one wave per finished chunk
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
         asm volatile("" : "+v"(fr));                             // opaque: keeps the 16 per-step offsets out of 16 loop-invariant registers
         const unsigned char* buf = lds + (u % NBUF) * kScrUnitBytes;
         if (ku == 0) scr_bias_init<NS>(bias_s + cl * 64 + 4 * h, acc);
-        scr_mma<KU, NS, ku, 0, 16>(buf, fr, bfrag, acc);
+        scr_mma<KU, NS, ku, 0, 16, (DBG & 16) != 0>(buf, fr, bfrag, acc);
         if (ku == KU - 1) {
             scr_fold<NS, MODE, DBG>(acc, a.P1, a.P2, (long long)(2 * (c_first + cl) + h) * a.ldp + ocol, 64 * (c_first + cl) + 4 * h, bmax);
             stored = true;

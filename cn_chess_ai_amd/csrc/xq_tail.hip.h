@@ -506,9 +506,12 @@ __global__ __launch_bounds__(256) void td_tail_kernel(const TailArgs a) {
     if (KINDS & TAIL_L0) {
         if (b < a.n_l0) {
             if (L0MFMA) {
-                const int rest = b >> 2;
-                l0_grad_mfma_block<0>(a.l0_sel, a.l0_planes, a.l0_plane_stride, a.l0_kpad, a.l0_H, a.l0_chunk, a.l0_partial, b & 3,
-                                       rest % a.l0_ncb, rest / a.l0_ncb, reinterpret_cast<unsigned char*>(tail_smem));
+                // column block = b mod (H / 32): workgroups go to the 8 XCDs round-robin in linear order, so every XCD streams ITS columns'
+                // planes (1/8 of the 12.6 MB at H = 256: L2-resident) for all row groups and chunks, instead of every XCD streaming half of
+                // all planes (PMC: 125 MB of fabric reads per launch with the row group fastest)
+                const int rest = b / a.l0_ncb;
+                l0_grad_mfma_block<0>(a.l0_sel, a.l0_planes, a.l0_plane_stride, a.l0_kpad, a.l0_H, a.l0_chunk, a.l0_partial, rest & 3,
+                                       b % a.l0_ncb, rest >> 2, reinterpret_cast<unsigned char*>(tail_smem));
                 return;
             }
             const int per = kSquares * a.l0_nch;

@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
     grant(l0_grad_mfma_kernel<4>); grant(l0_grad_mfma_kernel<6>);
     auto selk = [&] { hipLaunchKernelGGL(l0_sel_kernel, dim3(kpad / 64), dim3(256), 0, 0, dB, n, kpad, dS); };
     auto split = [&] { hipLaunchKernelGGL(delta_split_kernel, dim3(kpad / 64, H / 64), dim3(256), 0, 0, dD, n, H, dP, plane_stride, kpad); };
-    auto mfma = [&] { hipLaunchKernelGGL(l0_grad_mfma_kernel<0>, dim3(4, H / kL0mCols, nch), dim3(256), lds, 0, dS, dP, plane_stride, kpad, H, chunk, dOut); };
+    auto mfma = [&] { hipLaunchKernelGGL(l0_grad_mfma_kernel<0>, dim3(H / kL0mCols, 4, nch), dim3(256), lds, 0, dS, dP, plane_stride, kpad, H, chunk, dOut); };
     selk(); split(); mfma(); CK(hipDeviceSynchronize());
     std::vector<float> out((size_t)nch * 1260 * H);
     CK(hipMemcpy(out.data(), dOut, out.size() * 4, hipMemcpyDeviceToHost));
@@ -80,7 +80,7 @@ int main(int argc, char** argv) {
         printf("  all three            : %7.2f us\n", time20([&] { selk(); split(); mfma(); }));
     }
     auto dbg = [&](auto kern, const char* what) {
-        auto fn = [&] { hipLaunchKernelGGL(kern, dim3(4, H / kL0mCols, nch), dim3(256), lds, 0, dS, dP, plane_stride, kpad, H, chunk, dOut); };
+        auto fn = [&] { hipLaunchKernelGGL(kern, dim3(H / kL0mCols, 4, nch), dim3(256), lds, 0, dS, dP, plane_stride, kpad, H, chunk, dOut); };
         printf("  ablation %-44s: %7.2f us\n", what, time20(fn));
     };
     dbg(l0_grad_mfma_kernel<1>, "prologue + epilogue only (no stages)");

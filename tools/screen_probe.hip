@@ -126,6 +126,9 @@ int main(int argc, char** argv) {
           timeit("+ per-range maxima and activation norms (what the library runs)", [&] { launch_new<1, 2, 0>(x, 0); }); }
         { ScreenArgs x = a; x.A = dA; x.a_frag = 0; timeit("row-major activations", [&] { launch_new<1, 2, 0>(x, 0); }); }
         { ScreenArgs x = a; x.xcd_rows = 1; timeit("full kernel, XCD = row ranges", [&] { launch_new<1, 2, 0>(x, 0); }); }
+        timeit("TIMING ONLY: two v_mfma_f32_16x16x32_bf16 per 32x32x16 (same pipe cycles, meaningless values)", [&] { launch_new<1, 2, 16>(a, 0); });
+        timeit("full kernel again", [&] { launch_new<1, 2, 0>(a, 0); });
+        timeit("TIMING ONLY: 16x16x32 again", [&] { launch_new<1, 2, 16>(a, 0); });
         timeit("no fold", [&] { launch_new<1, 2, 1>(a, 0); });
         timeit("no activation loads", [&] { launch_new<1, 2, 2>(a, 0); });
         timeit("no fold, no activation loads", [&] { launch_new<1, 2, 3>(a, 0); });
