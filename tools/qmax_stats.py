@@ -20,6 +20,7 @@ cfg = xq.TrainerConfig(n_games=8192, layer_sizes=layers, replay_capacity=1 << 20
 t = xq.Trainer(cfg, stream=C.c_void_p(ts.cuda_stream))
 t.dqn.set_qmax_mode(_capi.QMAX_SCREENED)
 t.dqn.set_fused_apply(True)
+t.dqn.set_l0_derive(True)
 t.random_plies(300)
 for _ in range(128):
     t.collect()
