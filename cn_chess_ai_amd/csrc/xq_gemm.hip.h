@@ -123,7 +123,7 @@ __device__ __forceinline__ void stage_load(const GemmArgs& g, const float* __res
     constexpr int NV = ROWS / 32;          // float4 per thread
     constexpr int TPR = ROWS / 4;          // threads per k-row of an m-contiguous tile
     constexpr int KPP = 256 / TPR;         // k-rows per pass
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x & 255;     // (a 512-thread block = two 4-wave groups working side by side: tools/f32_fwd_probe.hip)
     if (FAST && LAYOUT == L_KCONTIG) {
         const float* p = X + (long long)(rows0 + (tid >> 3)) * ld + k0 + (tid & 7) * 4;
 #pragma unroll
@@ -188,7 +188,7 @@ __device__ __forceinline__ void stage_load(const GemmArgs& g, const float* __res
 template <int LAYOUT, int ROWS>
 __device__ __forceinline__ void stage_store(float* __restrict__ Xs, const float4 (&v)[ROWS / 32]) {
     constexpr int NV = ROWS / 32, TPR = ROWS / 4, KPP = 256 / TPR, LDM = ROWS + 4;
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x & 255;     // (a 512-thread block = two 4-wave groups working side by side: tools/f32_fwd_probe.hip)
     if (LAYOUT == L_KCONTIG) {
         const int kq = (tid & 7) * 4;
 #pragma unroll
@@ -274,7 +274,7 @@ template <int AL, int BL, int TM, int TN, bool FAST, int DT = DT_F32>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* __restrict__ As, float* __restrict__ Bs, int m0, int n0,
                                               int kbeg, int kend, f32x16 (&acc)[TM][TN]) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x & 255;     // (a 512-thread block = two 4-wave groups working side by side: tools/f32_fwd_probe.hip)
     const int lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;

@@ -522,8 +522,10 @@ __global__ __launch_bounds__(256) void td_tail_kernel(const TailArgs a) {
     }
     if (KINDS & TAIL_GRAD) {
         if (b < a.n_grad) {
-            const int per = a.grad_gx * a.grad_gy, r = b % per;
-            gemm_f32_block<L_MCONTIG, L_MCONTIG, EPI_STORE, 1, 1>(a.grad, r % a.grad_gx, r / a.grad_gx, b / per, tail_smem, tail_smem + g_tile_floats(64));
+            // the k-slab is the fastest index: workgroups go to the XCDs round-robin in linear order, so an XCD keeps to ITS eighth of the
+            // samples (both operands: 2 MB) for all tiles, instead of every XCD pulling every slab of both operands through the fabric
+            const int per = a.grad_gx * a.grad_gy, nz = a.n_grad / per, z = b % nz, r = b / nz;
+            gemm_f32_block<L_MCONTIG, L_MCONTIG, EPI_STORE, 1, 1>(a.grad, r % a.grad_gx, r / a.grad_gx, z, tail_smem, tail_smem + g_tile_floats(64));
             return;
         }
         b -= a.n_grad;

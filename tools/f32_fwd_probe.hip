@@ -30,6 +30,59 @@ template <int TM, int TN, int WPE> static void run_persistent(const char* name, 
     const double flop = 2.0 * g.M * g.N * g.K * (g.grouped ? g.grouped : 1);
     printf("  %-40s grid %4d (%d tiles)   : %7.2f us  %6.1f TFLOP/s = %.3f of 157.3\n", name, grid, total, ms * 50, flop / (ms / 20 * 1e-3) / 1e12, flop / (ms / 20 * 1e-3) / 157.3e12);
 }
+// VERDICT r4 Next #2: two waves per SIMD WITHOUT a second tile per CU — a 512-thread block per 128 x 128 tile, waves 0-3 take the first half
+// of the k range, waves 4-7 the second (each group with its own operand LDS, the loop of gemm_mainloop unchanged), the two accumulator sets
+// are added through LDS and every group finishes HALF of the tile (bias + tanh).  Same k association inside a half; the halves are added last.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_f32_ksplit_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float ks_smem[];
+    constexpr int TILE = g_tile_floats(128);
+    const int grp = (int)threadIdx.x >> 8, tid = (int)threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, wm = wid >> 1, wn = wid & 1;
+    float* As = ks_smem + grp * 2 * TILE;
+    float* Bs = As + TILE;
+    const int m0 = (int)blockIdx.x * 128, n0 = (int)blockIdx.y * 128;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    const int kh = g.K / 2;
+    gemm_mainloop<L_KCONTIG, L_KCONTIG, 2, 2, true>(g, As, Bs, m0, n0, grp * kh, (grp + 1) * kh, acc);
+    __syncthreads();
+    // exchange: group 0 finishes row tiles i = 0 of every wave's 64 x 64 quadrant, group 1 row tiles i = 1; each hands the other half over
+    float* red = ks_smem;                                     // [2 groups][2 j][16 q][256 threads]
+    const int give = grp == 0 ? 1 : 0, keep = 1 - give;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[((grp * 2 + j) * 16 + q) * 256 + tid] = acc[give][j][q];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + r;
+        const float bias = g.bias[n];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float v = acc[keep][j][q] + red[(((1 - grp) * 2 + j) * 16 + q) * 256 + tid];
+            if (EPI == EPI_BIAS_TANH) v = tanh_hidden(v + bias);
+            g.C[(long long)(m0 + wm * 64 + keep * 32 + 4 * h + (q & 3) + 8 * (q >> 2)) * g.ldc + n] = v;
+        }
+    }
+}
+template <int EPI = EPI_BIAS_TANH> static void run_ksplit(const char* name, GemmArgs g, hipEvent_t e0, hipEvent_t e1) {
+    const size_t lds = (size_t)4 * g_tile_floats(128) * sizeof(float);
+    CK(hipFuncSetAttribute((const void*)gemm_f32_ksplit_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid(g.M / 128, g.N / 128);
+    auto fn = [&] { hipLaunchKernelGGL((gemm_f32_ksplit_kernel<EPI>), grid, dim3(512), lds, 0, g); };
+    fn(); fn();
+    float ms = 0;
+    hipEventRecord(e0, 0); for (int i = 0; i < 20; ++i) fn(); hipEventRecord(e1, 0); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 2.0 * g.M * g.N * g.K;
+    printf("  %-40s grid %4d x %d (512 thr, %zu KB LDS): %7.2f us  %6.1f TFLOP/s = %.3f of 157.3\n", name, grid.x, grid.y, lds / 1024, ms * 50, flop / (ms / 20 * 1e-3) / 1e12, flop / (ms / 20 * 1e-3) / 157.3e12);
+}
 static double max_diff(const float* dX, const float* dY, size_t n) {
     std::vector<float> x(n), y(n);
     CK(hipMemcpy(x.data(), dX, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(y.data(), dY, n * 4, hipMemcpyDeviceToHost));
@@ -52,6 +105,15 @@ int main(int argc, char** argv) {
     run<2, 1>("128 x 64 tiles", g, e0, e1);
     run<1, 2>("64 x 128 tiles", g, e0, e1);
     run<2, 2>("128 x 128 tiles", g, e0, e1);
+    {   // the in-block k split against the tile kernel: same product (the two halves of k are added last: not bitwise the same sum)
+        float* dC3; CK(hipMalloc(&dC3, a.size() * 4));
+        GemmArgs k = g; k.C = dC3;
+        run_ksplit<EPI_BIAS_TANH>("128 x 128 tile, k split over 8 waves", k, e0, e1);
+        run<1, 1>("64 x 64 tiles (again)", g, e0, e1);
+        run_ksplit<EPI_BIAS_TANH>("128 x 128 tile, k split over 8 waves", k, e0, e1);
+        printf("  k-split against the 64 x 64 tile kernel: max |diff| %.3g\n", max_diff(dC, dC3, a.size()));
+        CK(hipFree(dC3));
+    }
     run<1, 1, EPI_STORE>("64 x 64 tiles, plain store (no tanh)", g, e0, e1);
     run<2, 1, EPI_STORE>("128 x 64 tiles, plain store (no tanh)", g, e0, e1);
     run<2, 2, EPI_STORE>("128 x 128 tiles, plain store (no tanh)", g, e0, e1);
