@@ -72,6 +72,23 @@ __global__ __launch_bounds__(512) void gemm_f32_ksplit_kernel(const GemmArgs g) 
         }
     }
 }
+// the 64 x 64 tile kernel allowed MORE waves per SIMD than the library's amdgpu_waves_per_eu(1, 2): all tiles of an 8192 x 512 product (1024 = 4 per CU)
+// resident at once, prologues and epilogues of some under the loops of others
+template <int EPI, int WMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, WMAX))) void gemm_f32_occ_kernel(const GemmArgs g_in) {
+    __shared__ __attribute__((aligned(16))) float As[g_tile_floats(64)];
+    __shared__ __attribute__((aligned(16))) float Bs[g_tile_floats(64)];
+    gemm_f32_block<L_KCONTIG, L_KCONTIG, EPI, 1, 1, DT_F32>(g_in, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, As, Bs);
+}
+template <int EPI, int WMAX> static void run_occ(const char* name, GemmArgs g, hipEvent_t e0, hipEvent_t e1) {
+    dim3 grid(g.M / 64, g.N / 64, g.grouped ? g.grouped : 1);
+    auto fn = [&] { hipLaunchKernelGGL((gemm_f32_occ_kernel<EPI, WMAX>), grid, dim3(256), 0, 0, g); };
+    fn(); fn();
+    float ms = 0;
+    hipEventRecord(e0, 0); for (int i = 0; i < 20; ++i) fn(); hipEventRecord(e1, 0); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 2.0 * g.M * g.N * g.K * (g.grouped ? g.grouped : 1);
+    printf("  %-40s grid %4d x %d x %d: %7.2f us  %6.1f TFLOP/s = %.3f of 157.3\n", name, grid.x, grid.y, grid.z, ms * 50, flop / (ms / 20 * 1e-3) / 1e12, flop / (ms / 20 * 1e-3) / 157.3e12);
+}
 template <int EPI = EPI_BIAS_TANH> static void run_ksplit(const char* name, GemmArgs g, hipEvent_t e0, hipEvent_t e1) {
     const size_t lds = (size_t)4 * g_tile_floats(128) * sizeof(float);
     CK(hipFuncSetAttribute((const void*)gemm_f32_ksplit_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -113,6 +130,11 @@ int main(int argc, char** argv) {
         run_ksplit<EPI_BIAS_TANH>("128 x 128 tile, k split over 8 waves", k, e0, e1);
         printf("  k-split against the 64 x 64 tile kernel: max |diff| %.3g\n", max_diff(dC, dC3, a.size()));
         CK(hipFree(dC3));
+        run_occ<EPI_BIAS_TANH, 2>("64 x 64 tiles, <= 2 waves per SIMD (library)", g, e0, e1);
+        run_occ<EPI_BIAS_TANH, 3>("64 x 64 tiles, <= 3 waves per SIMD", g, e0, e1);
+        run_occ<EPI_BIAS_TANH, 4>("64 x 64 tiles, <= 4 waves per SIMD", g, e0, e1);
+        run_occ<EPI_BIAS_TANH, 2>("64 x 64 tiles, <= 2 waves per SIMD (again)", g, e0, e1);
+        run_occ<EPI_BIAS_TANH, 4>("64 x 64 tiles, <= 4 waves per SIMD (again)", g, e0, e1);
     }
     run<1, 1, EPI_STORE>("64 x 64 tiles, plain store (no tanh)", g, e0, e1);
     run<2, 1, EPI_STORE>("128 x 64 tiles, plain store (no tanh)", g, e0, e1);
