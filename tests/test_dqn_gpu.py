@@ -813,11 +813,13 @@ def test_hidden_tanh_accuracy(xq):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sizes,n", [(CFG2_NET, 1100), ([1260, 64, 8100], 300)])
+@pytest.mark.parametrize("sizes,n", [(CFG2_NET, 1100), ([1260, 64, 8100], 300), (CFG2_NET, 2048), ([1260, 512, 512, 8100], 1024), ([1260, 128, 128, 8100], 3072)])
 def test_layer0_gradient_on_the_matrix_pipe_matches_the_segmented_sums(xq, trace, sizes, n):
     """xq_dqn_set_l0_grad_mode(1): gW0 = one-hot^T x delta_0 as a bf16 MFMA product with delta_0 split exactly into three bf16 values
     (xq_l0grad.hip.h).  Same TD step, both modes: every parameter outside layer 0 bit-identical, layer 0 equal up to the summation
-    order (<= two fp32 ulps of the stored weight), and the matrix-pipe update itself within PTOL of the fp64 oracle."""
+    order (<= two fp32 ulps of the stored weight), and the matrix-pipe update itself within PTOL of the fp64 oracle.
+    Shapes: 1100 samples = a partial chunk (zero-padded planes, split kernel of its own); 2048 / 3072 = whole chunks (planes written by the
+    delta product's epilogue, selector words riding in fused launch 1); widths 64 / 128 / 256 / 512 = 2 / 4 / 8 / 16 column blocks."""
     S, A, R, D, S2 = transitions(trace, valid_indices(trace, n, seed=6))
     R = R / 1000.0
     lr, scale = 0.05, 1.0 / n
