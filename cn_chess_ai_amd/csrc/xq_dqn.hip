@@ -2023,6 +2023,7 @@ int xq_dqn_calibrate_exchange(xq_dqn* d, double threshold_us, double* allreduce_
     // the ranks must agree (a rank that starts its select chain late while its neighbours start early only wastes what the rule
     // saves): the decision is taken on the MEAN over the ranks, in integer nanoseconds so that every rank computes the same number
     uint64_t ns = (uint64_t)((double)ms * 1e6 / reps + 0.5);
+    if (ns == 0) ns = 1;                             // (a one-rank all-reduce launches nothing: two back-to-back event records)
     XQ_TRY(xq_comm_sum_u64(d->comm, &ns));
     d->exch_allreduce_us = (double)ns / 1e3 / (double)comm_world(d->comm);
     d->exch_threshold_us = threshold_us >= 0.0 ? threshold_us : kExchangeThresholdUs;
