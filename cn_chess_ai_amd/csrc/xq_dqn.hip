@@ -18,6 +18,7 @@
 // segmented sums), xq_tail.hip.h (TD delta, gradient sums, fused launches, SGD), xq_refine.hip.h (screening pass 2), xq_l0grad.hip.h
 // (layer-0 gradient on the matrix pipe), xq_gemm*.hip.h and xq_screen.hip.h (matrix-pipe products).
 #include "xq_internal.h"
+#include <hip/hip_ext.h>
 #include "xq_gemm.hip.h"
 #include "xq_screen.hip.h"
 #include "xq_gemm_dma.hip.h"
@@ -44,6 +45,7 @@ struct xq_dqn {
     int ncu = 256;                              // compute units of the device (persistent-kernel grid = 2 per CU)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_delta = nullptr;
     hipEvent_t ev_qmax = nullptr;               // recorded behind the column-max GEMM of the last TD step (trainer: collect starts here)
+    hipEvent_t fwd_stop_ev = nullptr;           // set: the last grouped forward product of chain_boards completes this event itself (taken = reset)
     float* params[2] = {nullptr, nullptr};
     uint64_t params_version = 0;                // ++ whenever an operation that rewrites parameters is queued (xq_trainer: is ev_params still current?)
     // bf16 Q-net (xq_dqn_set_precision): bf16 shadow of the WEIGHTS of both nets, same element order as params[] (biases stay fp32);
@@ -579,13 +581,17 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
                 g.k_chunk = g.K; g.a_vec = g.b_vec = 1;
                 ProfScope ps(d, "gemm_hidden_fwd", 2.0 * n * (double)g.N * g.K * groups,
                              4.0 * groups * ((double)n * g.K + (double)g.N * g.K + (double)n * g.N));
+                // the event the trainer's select chain waits for rides on this kernel's own completion signal when it is the last of
+                // the chains (no marker packet on the stream: ~1.5 us less than a record, tools/sync_probe.hip variant 5)
+                hipEvent_t stop = (l == d->nl - 2 && d->cur == d->stream) ? d->fwd_stop_ev : nullptr;
+                if (stop) d->fwd_stop_ev = nullptr;
                 if (t128 >= 512) {
-                    hipLaunchKernelGGL((gemm_fwd_persistent_kernel<2, 2, 2>), dim3(std::min(t128, 2 * d->ncu)), dim3(256), 0, d->cur, g, n / 128,
-                                       g.N / 128, t128);
+                    hipExtLaunchKernelGGL((gemm_fwd_persistent_kernel<2, 2, 2>), dim3(std::min(t128, 2 * d->ncu)), dim3(256), 0, d->cur, nullptr, stop, 0,
+                                          g, n / 128, g.N / 128, t128);
                 } else {
                     const int total = (n / 64) * (g.N / 128) * groups;
-                    hipLaunchKernelGGL((gemm_fwd_persistent_kernel<1, 2, 2>), dim3(std::min(total, 2 * d->ncu)), dim3(256), 0, d->cur, g, n / 64,
-                                       g.N / 128, total);
+                    hipExtLaunchKernelGGL((gemm_fwd_persistent_kernel<1, 2, 2>), dim3(std::min(total, 2 * d->ncu)), dim3(256), 0, d->cur, nullptr, stop, 0,
+                                          g, n / 64, g.N / 128, total);
                 }
                 XQ_HIP(hipGetLastError());
                 continue;
@@ -1044,9 +1050,14 @@ static int l0_gradient(xq_dqn* d, int n, float* dst) {
     return XQ_OK;
 }
 
-static int sgd_apply(xq_dqn* d, const SegTable& t, double alpha) {
+static int sgd_apply(xq_dqn* d, SegTable t, double alpha) {
+    static const bool vec_ok4 = [] { const char* e = getenv("XQ_SGD_SCALAR"); return !(e && e[0] == '1'); }();
     long long mx = 0;
-    for (int i = 0; i < t.nseg; ++i) mx = std::max(mx, t.len[i]);
+    for (int i = 0; i < t.nseg; ++i) {
+        const uintptr_t bits = (uintptr_t)t.dst[i] | (uintptr_t)t.src[i] | ((uintptr_t)t.dst_bf[i] << 1);   // the bf16 shadow: 8-byte pieces
+        t.vec4[i] = vec_ok4 && (bits & 15) == 0 && (t.len[i] & 3) == 0 && (t.nslabs[i] <= 0 || (t.stride[i] & 3) == 0);
+        mx = std::max(mx, t.vec4[i] ? t.len[i] / 4 : t.len[i]);
+    }
     const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>((mx + 255) / 256, 1024));
     ProfScope ps(d, t.reduce_only ? "reduce_slabs" : "sgd_apply", 0, 0);
     hipLaunchKernelGGL(sgd_segments_kernel, dim3(bx, t.nseg), dim3(256), 0, d->cur, t, (float)alpha);
@@ -1114,10 +1125,10 @@ static int dqn_init(xq_dqn* d, const int* layer_sizes, int n_sizes, double learn
             d->ncu = prop.multiProcessorCount;
     }
     XQ_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
-    XQ_HIP(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
-    XQ_HIP(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
-    XQ_HIP(hipEventCreateWithFlags(&d->ev_delta, hipEventDisableTiming));
-    XQ_HIP(hipEventCreateWithFlags(&d->ev_qmax, hipEventDisableTiming));
+    XQ_HIP(hipEventCreateWithFlags(&d->ev_fork, stream_event_flags()));
+    XQ_HIP(hipEventCreateWithFlags(&d->ev_join, stream_event_flags()));
+    XQ_HIP(hipEventCreateWithFlags(&d->ev_delta, stream_event_flags()));
+    XQ_HIP(hipEventCreateWithFlags(&d->ev_qmax, stream_event_flags()));
     // + 128 rows of the widest layer: the persistent column-max GEMM reads whole 128-row tiles of W_out (rows beyond the
     // last output are masked in its epilogue, but must be readable)
     int widest = 0;
@@ -1750,15 +1761,21 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
     ChainJob jobs[3] = {{XQ_NET_ONLINE, boards, outs, outs_bf, d->gboards, nullptr, false},
                         {sel_net, next_boards, touts, touts_bf, nullptr, screened ? d->scr_ab : nullptr, scr_new || bf_frag},
                         {XQ_NET_TARGET, next_boards, t2outs, t2outs_bf, nullptr, nullptr, false}};
-    XQ_TRY(chain_boards(d, jobs, dbl ? 3 : 2, slots, n, screened ? &shadow : nullptr));
+    const bool gate_early = (screened || bf) && !d->late_gate;
+    // (same-box A/B, 3 x 3 x 300 steps: 0.1740 -> 0.1728 ms; XQ_FORK_STOP_EVENT=0 records a marker instead)
+    static const bool stop_event_fork = [] { const char* e = getenv("XQ_FORK_STOP_EVENT"); return !(e && e[0] == '0'); }();
+    d->fwd_stop_ev = (gate_early && stop_event_fork) ? d->ev_qmax : nullptr;
+    const int chain_rc = chain_boards(d, jobs, dbl ? 3 : 2, slots, n, screened ? &shadow : nullptr);
+    const bool fork_recorded = gate_early && stop_event_fork && d->fwd_stop_ev == nullptr;
+    d->fwd_stop_ev = nullptr;
+    XQ_TRY(chain_rc);
     // The select chain of the trainer starts HERE when max_a' Q(s',a') runs on the bf16 matrix pipe (screening pass of an fp32 net, or
     // the output layer of a bf16 net): its layer-0 gather (L2-bound) then runs beside the screening pass (matrix-pipe-bound) and
     // is gone when the refine kernel — a chain of dependent memory round trips that the gather doubles in length — starts.  Same-box
     // A/B, round 4 (3 x 300 steps per leg): behind the screening pass 0.1946-0.1969 ms, here 0.1888-0.1937; behind the layer-0 gather of
     // this step 0.1886-0.1896 against 0.1914-0.1921; at the very top of the step no difference; --config 4 / 5 -0.3 % / -0.9 %.
     // The full fp32 product keeps the chip to itself: there the chain starts behind it (below).
-    const bool gate_early = (screened || bf) && !d->late_gate;
-    if (gate_early) XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
+    if (gate_early && !fork_recorded) XQ_HIP(hipEventRecord(d->ev_qmax, d->stream));
     int zparts = kReduceParts;
     if (screened) {
         const int tiles_m = (NO + 127) / 128, total = tiles_m * ((n + 127) / 128);

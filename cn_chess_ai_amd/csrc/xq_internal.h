@@ -13,6 +13,15 @@ namespace xq {
 enum : unsigned { ORD_RING_CONTENTS = 1u, ORD_RING_PRIORITIES = 2u, ORD_RING_DRAW = 4u, ORD_TRAINER_PARAMS = 8u, ORD_ALL = 15u };
 inline unsigned& order_mask() { static unsigned m = ORD_ALL; return m; }
 
+// Flags of an event that only ever orders one device stream behind another (hipStreamWaitEvent; never hipEventSynchronize / Query):
+// no timing and no system-scope fence when it completes — the consumer is a kernel on the same device, which acquires at device scope
+// like any kernel behind another.  Measured (tools/sync_probe.hip): a record costs the recording stream 6.9 instead of 9.4 us between
+// 6-us kernels; same-box A/B of the step 0.1739 -> 0.1715 ms.  XQ_EVENT_SYSFENCE=1 restores the fence (A/B knob).
+inline unsigned stream_event_flags() {
+    static const unsigned f = [] { const char* e = getenv("XQ_EVENT_SYSFENCE"); return (unsigned)hipEventDisableTiming | ((e && e[0] == '1') ? 0u : (unsigned)hipEventDisableSystemFence); }();
+    return f;
+}
+
 // One device resource and the streams that touched it last.  read(s) orders s behind the last write; write(s) orders s behind the
 // last write and behind every read since.  The event is recorded LAZILY — on the producer's stream at the moment a consumer on another
 // stream shows up (streams run in order, so a record made later still lies behind the producer's work) — because a record costs the

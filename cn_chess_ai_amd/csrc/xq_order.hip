@@ -32,7 +32,7 @@ SharedResource::~SharedResource() {
 // (callers hold registry_mutex())
 int SharedResource::order_behind(hipStream_t waiter, hipStream_t producer) {
     if (waiter == producer || !(order_mask() & cls)) return XQ_OK;
-    if (!ev) XQ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (!ev) XQ_HIP(hipEventCreateWithFlags(&ev, stream_event_flags()));
     // lazily: behind everything the producer's stream holds by now.  A record that fails means the producer's stream is gone (a caller
     // destroyed a stream it had lent to a handle without xq_stream_destroy / the handle's destroy, which strike it from here): a
     // destroyed stream has finished its work, so its entry is dropped and there is nothing left to wait for — the error is not kept.
@@ -124,7 +124,7 @@ extern "C" {
 int xq_stream_wait_stream(void* waiting_stream, void* producer_stream) {
     if (waiting_stream == producer_stream) return XQ_OK;
     hipEvent_t ev = nullptr;
-    XQ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    XQ_HIP(hipEventCreateWithFlags(&ev, stream_event_flags()));
     hipError_t e = hipEventRecord(ev, (hipStream_t)producer_stream);
     if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiting_stream, ev, 0);
     (void)hipEventDestroy(ev);                       // released once the wait has passed

@@ -97,9 +97,9 @@ static int trainer_init(xq_trainer* t, const xq_trainer_config* cfg, void* hip_s
         // (one ply per update with the select chain most urgent: no difference on the headline bench, -0.5 % on bench --config 5)
         const int prio = cfg->collects_per_update > 1 ? hi : lo;
         XQ_HIP(hipStreamCreateWithPriority(&t->cstream, hipStreamNonBlocking, prio));
-        XQ_HIP(hipEventCreateWithFlags(&t->ev_params, hipEventDisableTiming));
-        XQ_HIP(hipEventCreateWithFlags(&t->ev_collect, hipEventDisableTiming));
-        XQ_HIP(hipEventCreateWithFlags(&t->ev_grads, hipEventDisableTiming));
+        XQ_HIP(hipEventCreateWithFlags(&t->ev_params, stream_event_flags()));
+        XQ_HIP(hipEventCreateWithFlags(&t->ev_collect, stream_event_flags()));
+        XQ_HIP(hipEventCreateWithFlags(&t->ev_grads, stream_event_flags()));
         XQ_HIP(hipEventRecord(t->ev_params, t->stream));      // orders the first collect after the handles' initialisation
         t->params_event_stale = false;
         t->params_version = dqn_params_version(t->dqn);

@@ -45,8 +45,18 @@ int main() {
     if (flag) { CK(hipExtMallocWithFlags((void**)&flag2, 8, hipMallocSignalMemory)); CK(hipMemset(flag2, 0, 8)); }
     hipEvent_t evB; CK(hipEventCreateWithFlags(&evB, hipEventDisableTiming));
     //   5  K1 launched with hipExtLaunchKernelGGL(..., stopEvent = ev): the event rides on K1's own completion signal, no marker packet
+    // event flags: round 5 asks whether the record's system-scope release is what costs the recording stream its ~6 us
+    const unsigned evflags[3] = { hipEventDisableTiming, hipEventDisableTiming | hipEventDisableSystemFence, hipEventDisableTiming | hipEventReleaseToDevice };
+    const char* evnames[3] = { "DisableTiming", "DisableTiming|DisableSystemFence", "DisableTiming|ReleaseToDevice" };
+    for (int fl = 0; fl < 3; ++fl)
     for (int variant = 0; variant < 6; ++variant) {
         if ((variant == 2 || variant == 3) && !flag) continue;
+        if (fl > 0 && variant != 1 && variant != 4 && variant != 5) continue;
+        if (fl > 0 && variant == 1) {
+            printf("event flags: %s\n", evnames[fl]);
+            CK(hipEventDestroy(ev)); CK(hipEventDestroy(evB));
+            CK(hipEventCreateWithFlags(&ev, evflags[fl])); CK(hipEventCreateWithFlags(&evB, evflags[fl]));
+        }
         for (int warm = 0; warm < 2; ++warm) {
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(t0, A));
