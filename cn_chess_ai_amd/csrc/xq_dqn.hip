@@ -1325,7 +1325,7 @@ static int chain_dense(xq_dqn* d, int net, const float* x, int n, float* const* 
     g.B = d->w0t(net); g.ldb = d->L[1];
     g.C = outs[0]; g.ldc = d->L[1];
     g.bias = d->bl(net, 0);
-    g.libm_tanh = 1;                     // layer 0 takes libm's tanhf on BOTH routes (the packed-board gather kernels call it too): a dense
+    g.libm_tanh = !XQ_L0_FAST_TANH;      // layer 0 takes the SAME tanh on both routes (tanh_l0 in the packed-board gather kernels): a dense
                                          // one-hot and the board it encodes then differ by summation order only
     XQ_GEMM((launch_gemm<L_KCONTIG, L_MCONTIG, EPI_BIAS_TANH>(d, g, 1, "gemm_l0_dense_fwd")));
     for (int l = 1; l + 1 < d->nl; ++l) {

@@ -97,6 +97,19 @@ __global__ __launch_bounds__(256) void screen_shadow_kernel(ShadowJob S) {
     screen_shadow_block(S, (int)blockIdx.x, nrm);
 }
 
+// tanh of layer 0 on every route (the gather kernels here, the dense-input product of chain_dense): tanh_hidden, like the hidden layers
+// (same-box A/B of the step: 0.1706 -> 0.1697 ms).  XQ_L0_FAST_TANH=0 restores libm's tanhf on both routes (A/B builds).
+#ifndef XQ_L0_FAST_TANH
+#define XQ_L0_FAST_TANH 1
+#endif
+__device__ __forceinline__ float tanh_l0(float x) {
+#if XQ_L0_FAST_TANH
+    return tanh_hidden(x);
+#else
+    return tanhf(x);
+#endif
+}
+
 struct L0Jobs {
     const uint32_t* boards[kMaxChains];
     const float* W0T[kMaxChains];
@@ -118,7 +131,7 @@ struct L0Jobs {
 // BF16: rows come from the bf16 shadow (half the L2 traffic of this gather), the sum runs in fp32, the result is rounded to bf16.
 template <bool BF16>
 __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, int n, int H) {
-    __shared__ int rows[4][96];
+    __shared__ __attribute__((aligned(16))) int rows[4][96];
     if ((int)blockIdx.y == J.nrows) {                   // block-uniform: the screening shadow rides in the same grid
         if ((int)blockIdx.x < J.shadow.nblocks) screen_shadow_block(J.shadow, (int)blockIdx.x, reinterpret_cast<float*>(&rows[0][0]));
         return;
@@ -151,8 +164,8 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // s' from s: the squares whose piece code differs (a move changes two), in ascending order, as (row to take out, row to put in);
     // boards that are not a move apart (an unused slot, a foreign pair) get the full row list of s' instead
-    __shared__ int dpair[4][8][2];
-    __shared__ int rows2[4][96];
+    __shared__ __attribute__((aligned(16))) int dpair[4][8][2];
+    __shared__ __attribute__((aligned(16))) int rows2[4][96];
     int nd = -1, cnt2 = 0;                                // nd = -1: nothing derived here; nd > 8: cnt2 rows in rows2
     if (J.derive_next && job == 0) {
         const uint32_t* bw2 = J.boards[1] + (long long)srow * kBoardWords;
@@ -268,6 +281,17 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
         for (int col = lane * 4; col < H; col += 256) {
             float4 acc = *reinterpret_cast<const float4*>(b0 + col);
             int i = 0;
+            if (!BF16) {                                // fp32: eight rows per round trip, their codes read 16 bytes at a time
+                for (; i + 8 <= cnt; i += 8) {
+                    const int4 ca = *reinterpret_cast<const int4*>(&rows[wid][i]), cb = *reinterpret_cast<const int4*>(&rows[wid][i + 4]);
+                    const float4 w0 = load4(ca.x, col), w1 = load4(ca.y, col), w2 = load4(ca.z, col), w3 = load4(ca.w, col);
+                    const float4 w4 = load4(cb.x, col), w5 = load4(cb.y, col), w6 = load4(cb.z, col), w7 = load4(cb.w, col);
+                    acc.x = (((((((acc.x + w0.x) + w1.x) + w2.x) + w3.x) + w4.x) + w5.x) + w6.x) + w7.x;
+                    acc.y = (((((((acc.y + w0.y) + w1.y) + w2.y) + w3.y) + w4.y) + w5.y) + w6.y) + w7.y;
+                    acc.z = (((((((acc.z + w0.z) + w1.z) + w2.z) + w3.z) + w4.z) + w5.z) + w6.z) + w7.z;
+                    acc.w = (((((((acc.w + w0.w) + w1.w) + w2.w) + w3.w) + w4.w) + w5.w) + w6.w) + w7.w;
+                }
+            }
             for (; i + 4 <= cnt; i += 4) {
                 const float4 w0 = load4(rows[wid][i], col), w1 = load4(rows[wid][i + 1], col);
                 const float4 w2 = load4(rows[wid][i + 2], col), w3 = load4(rows[wid][i + 3], col);
@@ -280,7 +304,7 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
                 const float4 w = load4(rows[wid][i], col);
                 acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
             }
-            float4 t = make_float4(tanhf(acc.x), tanhf(acc.y), tanhf(acc.z), tanhf(acc.w));
+            float4 t = make_float4(tanh_l0(acc.x), tanh_l0(acc.y), tanh_l0(acc.z), tanh_l0(acc.w));
             if (BF16) {
                 const uint16_t q0 = bf16_bits(t.x), q1 = bf16_bits(t.y), q2 = bf16_bits(t.z), q3 = bf16_bits(t.w);
                 *reinterpret_cast<uint2*>(out_bf + (long long)b * H + col) = make_uint2((uint32_t)q0 | ((uint32_t)q1 << 16), (uint32_t)q2 | ((uint32_t)q3 << 16));
@@ -303,7 +327,7 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
                     a2 = *reinterpret_cast<const float4*>(b0 + col);
                     for (int k = 0; k < cnt2; ++k) { const float4 w = load4(rows2[wid][k], col); a2.x += w.x; a2.y += w.y; a2.z += w.z; a2.w += w.w; }
                 }
-                const float4 t2 = make_float4(tanhf(a2.x), tanhf(a2.y), tanhf(a2.z), tanhf(a2.w));
+                const float4 t2 = make_float4(tanh_l0(a2.x), tanh_l0(a2.y), tanh_l0(a2.z), tanh_l0(a2.w));
                 if (J.out_bf[1]) {
                     const uint16_t q0 = bf16_bits(t2.x), q1 = bf16_bits(t2.y), q2 = bf16_bits(t2.z), q3 = bf16_bits(t2.w);
                     *reinterpret_cast<uint2*>(J.out_bf[1] + (J.out_bf_frag ? scr_afrag_index(b, col, H) : (long long)b * H + col)) =
@@ -317,7 +341,7 @@ __global__ __launch_bounds__(256) void l0_forward_kernel(L0Jobs J, SlotSrc src, 
             float acc = b0[col];
             for (int i = 0; i < cnt; ++i)
                 acc += BF16 ? bf16_to_float(W0B[(long long)rows[wid][i] * H + col]) : W0T[(long long)rows[wid][i] * H + col];
-            float t = tanhf(acc);
+            float t = tanh_l0(acc);
             if (BF16) { const uint16_t q = bf16_bits(t); out_bf[(long long)b * H + col] = q; t = bf16_to_float(q); }
             if (out) out[(long long)b * H + col] = t;
         }
@@ -393,7 +417,7 @@ __global__ __launch_bounds__(256) void l0_select_kernel(const uint32_t* __restri
             }
         }
         *reinterpret_cast<float4*>(z1 + (long long)b * H + col) = acc;
-        *reinterpret_cast<float4*>(out + (long long)b * H + col) = make_float4(tanhf(acc.x), tanhf(acc.y), tanhf(acc.z), tanhf(acc.w));
+        *reinterpret_cast<float4*>(out + (long long)b * H + col) = make_float4(tanh_l0(acc.x), tanh_l0(acc.y), tanh_l0(acc.z), tanh_l0(acc.w));
     }
     if (lane < kBoardWords) pw[lane] = bw[lane];
 }

@@ -24,6 +24,8 @@ cfg = xq.TrainerConfig(n_games=8192, layer_sizes=(1260, 256, 256, 8100), replay_
 t = xq.Trainer(cfg, stream=C.c_void_p(ts.cuda_stream))
 t.dqn.set_qmax_mode(_capi.QMAX_SCREENED)
 t.dqn.set_fused_apply(True)
+t.synchronize()
+START = t.env.get_state()[0][0].copy()               # the env starts from chessboard.cpp:8-29's position
 t.random_plies(300)
 for _ in range(128):
     t.collect()
@@ -41,6 +43,11 @@ def census(tag, updates):
     rec = {"at": tag, "updates": updates, "boards": n, "pieces_per_board": r_now / n, "rows_segmented": r_now, "rows_majority_complement": r_min,
            "ratio": r_min / max(r_now, 1), "squares_where_a_piece_is_the_majority": int((cls[1:].max(0) > cls[0]).sum()),
            "mean_share_of_the_commonest_piece_on_squares_above_30pct": home_keep}
+    # rows that are the START position's piece on its own square (what a gather kernel could keep in LDS: 32 rows)
+    if START is not None:
+        hot = int(((boards == START[None, :]) & (boards != 0)).sum())
+        rec["rows_of_the_start_position"] = hot
+        rec["share_of_start_rows"] = hot / max(r_now, 1)
     occ = np.sort(occupied.astype(np.float64) / n)[::-1]
     rec["occupancy_sorted_top"] = [round(float(x), 3) for x in occ[:56]]
     rec["rows_outside_the_top_k_squares"] = {str(k): int(round(float(occ[k:].sum() * n))) for k in (24, 32, 40, 48, 56, 64, 72)}
