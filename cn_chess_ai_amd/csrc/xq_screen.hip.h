@@ -46,7 +46,8 @@ struct ScreenArgs {
     int cpr;                // chunks per row range
     int panels, ranges;     // grid = panels * ranges
     int a_frag;             // 1: A is stored in B-fragment order (scr_afrag_index) instead of row-major [sample][K]
-    int xcd_rows;           // 1: the blocks of one XCD share ROW RANGES (weight stream from that L2); 0: they share SAMPLE PANELS
+    int xcd_rows;           // 1: the blocks of one XCD share ROW RANGES (weight stream from that L2); 0: they share SAMPLE PANELS;
+                            // 2: an XCD takes half of the row ranges and a quarter of the panels (ranges % 2 == 0, panels % 4 == 0, 8 | grid)
     unsigned long long* dbg;  // DBG & 8 (probe only): [grid][8] stamps
 };
 
@@ -193,8 +194,15 @@ __global__ __launch_bounds__(512) void screen_top2_kernel(const ScreenArgs a) {
     const int nb = (int)gridDim.x;
     int lin = (int)blockIdx.x;
     if ((nb & 7) == 0) lin = ((int)blockIdx.x & 7) * (nb >> 3) + ((int)blockIdx.x >> 3);
-    const int range = a.xcd_rows ? lin / a.panels : lin % a.ranges;
-    const int panel = a.xcd_rows ? lin - range * a.panels : lin / a.ranges;
+    int range = a.xcd_rows ? lin / a.panels : lin % a.ranges;
+    int panel = a.xcd_rows ? lin - range * a.panels : lin / a.ranges;
+    if (a.xcd_rows == 2) {
+        // XCD x = (half of the row ranges, quarter of the sample panels): every XCD streams HALF of W and a QUARTER of the activations from
+        // HBM (16.4 + 8.4 MB at 8100 x 256 x 8192) instead of all of W and an eighth of the activations (33 + 4.2 MB)
+        const int x = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3, r2 = a.ranges >> 1, p4 = a.panels >> 2;
+        range = (x >> 2) * r2 + q % r2;
+        panel = (x & 3) * p4 + q / r2;
+    }
     const int c_first = range * a.cpr;
     const int nch = min(a.cpr, a.nchunks - c_first);             // chunks of this block (>= 1 by construction of the grid)
     const int U = nch * KU;                                      // units to stream
@@ -326,6 +334,8 @@ inline void screen_geometry(int NO, int n, int K, int ncu, ScreenArgs& a) {
     if (ranges > a.nchunks) ranges = a.nchunks;
     a.cpr = (a.nchunks + ranges - 1) / ranges;
     a.ranges = (a.nchunks + a.cpr - 1) / a.cpr;
+    a.xcd_rows = ((a.ranges & 1) == 0 && (a.panels & 3) == 0) ? 2 : 0;
+    if (const char* e = getenv("XQ_SCREEN_XCD")) { if (e[0] == '0') a.xcd_rows = 0; else if (e[0] == '1') a.xcd_rows = 1; }     // A/B knob
 }
 inline size_t screen_lds_bytes(const ScreenArgs& a) { return (size_t)kScrBufs * kScrUnitBytes + (size_t)a.cpr * 64 * sizeof(float); }
 inline int screen_padded_samples(int n, int K) { const int SB = K == 256 ? 512 : 256; return (n + SB - 1) / SB * SB; }
