@@ -783,7 +783,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     if (t >= total) return;
     const int stride = (int)gridDim.x;
     struct Tile { const float* A; const float* B; float* C; const float* bias; uint16_t* Cb; int m0, n0; };
+    // workgroups go to the 8 XCDs round-robin (the grid is a multiple of 8, so a block's whole walk stays on one XCD): the tiles_n tiles
+    // that share a row panel of A are given to ONE XCD — list position L = 8 q + x is tile (row panel 8 (q / tiles_n) + x, column
+    // q % tiles_n) — instead of tiles_n different ones, each of which fetched the panel from HBM (PMC: 55 MB per launch against 38
+    // compulsory at 8192 x 256 x 256 x 2, the activations read twice; four times at 512 wide)
+    const bool xcd_walk = (total % (8 * tiles_n)) == 0 && (stride & 7) == 0;
     auto decode = [&](int tt) {
+        if (xcd_walk) { const int x = tt & 7, q = tt >> 3; tt = ((q / tiles_n) * 8 + x) * tiles_n + q % tiles_n; }
         const int grp = tt / per_group, rem = tt - grp * per_group;
         Tile x;
         x.A = grp == 0 ? g.A : g.Ax[grp - 1]; x.B = grp == 0 ? g.B : g.Bx[grp - 1]; x.C = grp == 0 ? g.C : g.Cx[grp - 1];

@@ -509,9 +509,13 @@ __global__ __launch_bounds__(256) void td_tail_kernel(const TailArgs a) {
                 // column block = b mod (H / 32): workgroups go to the 8 XCDs round-robin in linear order, so every XCD streams ITS columns'
                 // planes (1/8 of the 12.6 MB at H = 256: L2-resident) for all row groups and chunks, instead of every XCD streaming half of
                 // all planes (PMC: 125 MB of fabric reads per launch with the row group fastest)
-                const int rest = b / a.l0_ncb;
-                l0_grad_mfma_block<0>(a.l0_sel, a.l0_planes, a.l0_plane_stride, a.l0_kpad, a.l0_H, a.l0_chunk, a.l0_partial, rest & 3,
-                                       b % a.l0_ncb, rest >> 2, reinterpret_cast<unsigned char*>(tail_smem));
+                // ... unless the chunks themselves go round the XCDs (8 | chunks): the CHUNK is then the fastest index, XCD x keeps to the planes
+                // AND the selector words of its own chunks (1.6 + 0.4 MB of 12.6 + 3.1), nothing is read by two XCDs — with the column block
+                // fastest every XCD read all the selector words (25 MB per launch instead of 3.1)
+                int rest = b / a.l0_ncb, cb = b % a.l0_ncb, sqg = rest & 3, ch = rest >> 2;
+                if ((a.l0_nch & 7) == 0) { ch = b % a.l0_nch; rest = b / a.l0_nch; cb = rest % a.l0_ncb; sqg = rest / a.l0_ncb; }
+                l0_grad_mfma_block<0>(a.l0_sel, a.l0_planes, a.l0_plane_stride, a.l0_kpad, a.l0_H, a.l0_chunk, a.l0_partial, sqg, cb, ch,
+                                       reinterpret_cast<unsigned char*>(tail_smem));
                 return;
             }
             const int per = kSquares * a.l0_nch;
