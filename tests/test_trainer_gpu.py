@@ -7,6 +7,7 @@
     the two streams would show up as a difference.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -447,3 +448,25 @@ def test_bench_composition_against_the_oracle_directly(xq):
     # ... and the step was not a no-op on that row
     assert np.abs(w3[row] - w2[row]).max() > 0
     t.close()
+
+
+def test_timing_knobs_do_not_change_a_bit(xq):
+    """INTEGRATION.md lists the environment variables the library reads as A/B knobs for TIMING (event flags, the fork as a stop event, the SGD
+    kernel's load width, the screening pass's block -> XCD map, the weight-gradient product's launch): six updates of the bench's schedule at 2048
+    games give the same weights, boards, Q(s,a) and targets, bit for bit, under each of them.  One child process per setting (read once per process)."""
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "knob_probe.py")
+    got = {}
+    for knob in ("", "XQ_EVENT_SYSFENCE=1", "XQ_FORK_STOP_EVENT=0", "XQ_SGD_SCALAR=1", "XQ_SCREEN_XCD=0", "XQ_SCREEN_XCD=1", "XQ_TAIL_GRAD_EARLY=1"):
+        env = dict(os.environ)
+        if knob:
+            k, v = knob.split("=")
+            env[k] = v
+        out = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("KNOB_PROBE")]
+        assert out.returncode == 0 and line, (knob, out.stdout[-400:], out.stderr[-800:])
+        _, digest, screened = line[0].split()
+        assert int(screened) == 6, (knob, screened)            # every update took the screened route
+        got[knob] = digest
+    assert len(set(got.values())) == 1, got
