@@ -191,17 +191,20 @@ struct ProfScope {
     // (while a fused tail launch is being assembled nothing is launched, so nothing is bracketed: tail_launch has its own scope)
     // A launch on a stream that is neither the handle's nor its side stream belongs to the select chain of the self-play loop (the
     // trainer's collect stream): same kernels, other shapes, off the critical path — bracketed under "<name>@select".
-    ProfScope(xq_dqn* d, const char* name, double fl, double by) : p(d->prof), s(d->cur), flops(fl), bytes(by) {
+    // attach: the scope is ONE kernel launch that takes start() / stop() as its own events (hipExtLaunchKernelGGL): kernel-exact time
+    ProfScope(xq_dqn* d, const char* name, double fl, double by, bool attach = false) : p(d->prof), s(d->cur), flops(fl), bytes(by) {
         h = -1;
         if (d->tail_open || !p.enabled) return;
         if (d->cur != d->stream && d->cur != d->side) {
             char nm[48];
             snprintf(nm, sizeof nm, "%s@select", name);
-            h = p.begin(nm, s);
+            h = p.begin(nm, s, attach);
         } else {
-            h = p.begin(name, s);
+            h = p.begin(name, s, attach);
         }
     }
+    hipEvent_t start() const { return h >= 0 ? p.recs[h].a : nullptr; }
+    hipEvent_t stop() const { return h >= 0 ? p.recs[h].b : nullptr; }
     ~ProfScope() { p.end(h, s, flops, bytes); }
 };
 
@@ -1797,9 +1800,10 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
                 XQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(screen_top2_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 d->scr_new_kernel_ready = true;
             }
-            ProfScope ps(d, "gemm_qmax_screen", 2.0 * NO * (double)n * Hl, 2.0 * ((double)NO * Hl + (double)n * Hl) + 8.0 * G * n);
-            if (Hl == 256) hipLaunchKernelGGL((screen_top2_kernel<1, 2>), dim3(a.panels * a.ranges), dim3(512), lds, d->cur, a);
-            else hipLaunchKernelGGL((screen_top2_kernel<2, 1>), dim3(a.panels * a.ranges), dim3(512), lds, d->cur, a);
+            // (bracketed by its own start / stop events: the live figure is the kernel's duration as rocprofv3 reports it)
+            ProfScope ps(d, "gemm_qmax_screen", 2.0 * NO * (double)n * Hl, 2.0 * ((double)NO * Hl + (double)n * Hl) + 8.0 * G * n, true);
+            if (Hl == 256) hipExtLaunchKernelGGL((screen_top2_kernel<1, 2>), dim3(a.panels * a.ranges), dim3(512), lds, d->cur, ps.start(), ps.stop(), 0, a);
+            else hipExtLaunchKernelGGL((screen_top2_kernel<2, 1>), dim3(a.panels * a.ranges), dim3(512), lds, d->cur, ps.start(), ps.stop(), 0, a);
             XQ_HIP(hipGetLastError());
         } else {
             GemmArgs g; memset(&g, 0, sizeof g);
@@ -1881,12 +1885,14 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         a.ldp = screen_padded_samples(n, Hl);
         part_ld = a.ldp; n_part = 2 * a.nchunks;
         const size_t lds = screen_lds_bytes(a);
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;     // (the launch's own start / stop events when it is being timed)
         auto launch = [&](auto kern) {
             static bool ready = false;       // per instantiation
             if (!ready) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); ready = true; }
-            hipLaunchKernelGGL(kern, dim3(a.panels * a.ranges), dim3(512), lds, d->cur, a);
+            hipExtLaunchKernelGGL(kern, dim3(a.panels * a.ranges), dim3(512), lds, d->cur, ev0, ev1, 0, a);
         };
-        ProfScope ps(d, "gemm_qmax_rowmax", 2.0 * NO * (double)n * Hl, 2.0 * ((double)NO * Hl + (double)n * Hl) + 8.0 * n_part * n);
+        ProfScope ps(d, "gemm_qmax_rowmax", 2.0 * NO * (double)n * Hl, 2.0 * ((double)NO * Hl + (double)n * Hl) + 8.0 * n_part * n, true);
+        ev0 = ps.start(); ev1 = ps.stop();
         if (Hl == 256) { if (dbl) launch(screen_top2_kernel<1, 2, SCR_ARG>); else launch(screen_top2_kernel<1, 2, SCR_MAX>); }
         else { if (dbl) launch(screen_top2_kernel<2, 1, SCR_ARG>); else launch(screen_top2_kernel<2, 1, SCR_MAX>); }
         XQ_HIP(hipGetLastError());

@@ -137,7 +137,7 @@ namespace xq {
 // HIP-event profiler: brackets individual launches on the handle's stream (bench.py roofline leg).  Disabled = free.
 struct Profiler {
     struct Cat { char name[48]; double flops = 0, bytes = 0; int launches = 0; float ms = 0; };
-    struct Rec { int cat; hipEvent_t a, b; };
+    struct Rec { int cat; hipEvent_t a, b; bool attached; };   // attached: a / b are the start / stop events of the kernel's own launch
     struct Span { char name[48]; float start_ms, end_ms; };      // relative to the first bracket of the batch (live timeline)
     std::vector<Span> spans;
     bool enabled = false;
@@ -173,7 +173,10 @@ struct Profiler {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e; (void)hipEventCreate(&e); return e;
     }
-    int begin(const char* name, hipStream_t s) {
+    // attach: the caller hands recs[h].a / .b to hipExtLaunchKernelGGL as the launch's start / stop events — the elapsed time is then the
+    // kernel's own (what rocprofv3 reports), with no marker packets on the stream; otherwise the pair is recorded around the scope
+    // (one or more launches; reads ~6.5 us more than a single kernel, tools/sync_probe.hip)
+    int begin(const char* name, hipStream_t s, bool attach = false) {
         if (!enabled) return -1;
         if (roofline_only) {
             if (only.empty()) set_only("gemm_qmax_rowmax,gemm_qmax_screen,env_selfplay_step");
@@ -183,14 +186,14 @@ struct Profiler {
             const int period = sample_period > 1 ? sample_period + o->period_add : 1;
             if (period > 1 && (o->phase++ % period) != 0) return -1;
         }
-        Rec r; r.cat = cat_id(name); r.a = get_event(); r.b = get_event();
-        (void)hipEventRecord(r.a, s);
+        Rec r; r.cat = cat_id(name); r.a = get_event(); r.b = get_event(); r.attached = attach;
+        if (!attach) (void)hipEventRecord(r.a, s);
         recs.push_back(r);
         return (int)recs.size() - 1;
     }
     void end(int h, hipStream_t s, double flops, double bytes) {
         if (h < 0) return;
-        (void)hipEventRecord(recs[h].b, s);
+        if (!recs[h].attached) (void)hipEventRecord(recs[h].b, s);
         Cat& c = cats[recs[h].cat];
         c.flops += flops; c.bytes += bytes; c.launches += 1;
     }
