@@ -134,9 +134,8 @@ def cpu_baseline(seconds=15.0, reference_nn=False):
 _PROFILE_SET = {}
 
 
-# kernels whose live figure is the kernel's OWN duration: the library launches them with their start / stop events attached
-# (hipExtLaunchKernelGGL; csrc/xq_dqn.hip ProfScope(..., attach)), so no recorded bracket — and none of its ~6.5 us — is in it
-KERNEL_EXACT = {"gemm_qmax_screen", "gemm_qmax_rowmax"}
+# a kernel_stats entry with exact == launches: every launch was timed by the kernel's OWN start / stop events (the library launches single-kernel
+# brackets with hipExtLaunchKernelGGL; csrc/xq_dqn.hip ProfScope(..., attach)) — no recorded bracket, and none of its ~6.5 us, is in the figure
 KERNEL_EXACT_NOTE = "the kernel's own start / stop events (no bracket overhead; agrees with rocprofv3's duration)"
 
 
@@ -606,7 +605,8 @@ def main():
             torch.cuda.synchronize()
             for k in t.dqn.kernel_stats(enable=0):
                 if k["name"] == nm and k["launches"]:
-                    chain[nm] = dict(avg_us=1e3 * k["ms"] / k["launches"], launches_per_step=k["launches"] / args.chain_steps)
+                    chain[nm] = dict(avg_us=1e3 * k["ms"] / k["launches"], launches_per_step=k["launches"] / args.chain_steps,
+                                     exact=k.get("exact", 0) == k["launches"])
         torch.cuda.synchronize()
     # candidates for `roofline`: the kernels ON the step's dependency chain — the handle's stream, and the select chain too when an
     # update has several plies (then the plies are the long pole).  With one ply per update the select chain runs beside the TD step,
@@ -813,13 +813,13 @@ def main():
                  "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                  "frac": ach / peak, "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, offline)",
                  "traffic_source": src, "avg_launch_ms": ms, "flops_per_launch": fl, "launches": st["launches"],
-                 "launches_note": (KERNEL_EXACT_NOTE if screened_kernel else "HIP-event brackets") + " inside the timed region, on " +
+                 "launches_note": (KERNEL_EXACT_NOTE if st.get("exact", 0) == st["launches"] else "HIP-event brackets") + " inside the timed region, on " +
                                   ("every launch" if args.bracket_all or args.profile_all else
                                    "every 4th launch (--bracket-all for every launch)")}
             # context for the difference between avg_launch_ms and rocprofv3's kernel duration (profiles/): a pair of RECORDED events around a
             # kernel that does nothing reads this much — it is in every bracketed figure and NOT subtracted; the screening pass carries its own
             # start / stop events instead (hipExtLaunchKernelGGL), so its figure IS the kernel's duration
-            r["hip_event_bracket_of_an_empty_kernel_ms"] = 0.0 if screened_kernel else bracket_ms
+            r["hip_event_bracket_of_an_empty_kernel_ms"] = 0.0 if st.get("exact", 0) == st["launches"] else bracket_ms
             if iso_st and iso_st["launches"]:
                 r["isolated_avg_launch_ms"] = iso_st["ms"] / iso_st["launches"]
                 r["isolated_frac"] = fl / (iso_st["ms"] / iso_st["launches"] * 1e-3) / 1e12 / peak
@@ -873,11 +873,12 @@ def main():
             sel_us = sum(e["avg_us"] * e["launches_per_step"] for e in sel)
             for e in entries:
                 e["share_of_step"] = e["avg_us"] * e["launches_per_step"] / step_us
-                if e["kernel"] in KERNEL_EXACT:
+                if chain.get(e["kernel"], {}).get("exact"):
                     e["timing"] = KERNEL_EXACT_NOTE
             line["roofline_chain"] = {
-                "how": "each kernel measured IN the training loop with only its own HIP-event bracket in it (%d untimed steps per kernel, "
-                       "between the settle steps and the timed region); a bracket reads ~%.1f us more than the kernel itself "
+                "how": "each kernel measured IN the training loop with nothing else being timed (%d untimed steps per kernel, between the settle steps "
+                       "and the timed region).  Entries with `timing`: the launch carries its own start / stop events, avg_us IS the kernel's duration; "
+                       "the others are pairs of recorded events around the launch(es), which read ~%.1f us more than the kernel "
                        "(hip_event_bracket_of_an_empty_kernel_us); algorithmic FLOPs / compulsory HBM bytes: cn_chess_ai_amd/workmodel.py = "
                        "DESIGN.md section 5; traffic: rocprofv3 PMC of the same command (profiles/)" % (args.chain_steps, 1e3 * bracket_ms),
                 "hip_event_bracket_of_an_empty_kernel_us": 1e3 * bracket_ms,
@@ -885,7 +886,7 @@ def main():
                 "handle_stream": crit, "handle_stream_sum_us": crit_us,
                 "handle_stream_unaccounted_us": step_us - crit_us,
                 "handle_stream_unaccounted_note": "step time minus the sum of the kernels queued on the handle's stream: cross-stream waits "
-                                                  "(collect fork / join), kernel boundaries, minus the bracket overhead contained in every avg_us",
+                                                  "(collect fork / join) and kernel boundaries (minus the bracket overhead of entries without `timing`)",
                 "collect_stream": sel, "collect_stream_sum_us": sel_us,
                 "collect_stream_note": "runs beside the TD step (one ply per update: ends before the gradients do) — or IS the long pole of "
                                        "the step when an update has several plies",
@@ -906,10 +907,10 @@ def main():
                     ms = st["ms"] / st["launches"]
                     ach, frac = price(wk, 1e3 * ms)
                     r.update(achieved=ach, frac=frac, avg_launch_ms=ms, launches=st["launches"],
-                             launches_note=(KERNEL_EXACT_NOTE if dominant in KERNEL_EXACT else "HIP-event brackets") + " inside the timed region, on " +
+                             launches_note=(KERNEL_EXACT_NOTE if st.get("exact", 0) == st["launches"] else "HIP-event brackets") + " inside the timed region, on " +
                                            ("every launch" if args.bracket_all or args.profile_all else "every 4th launch"),
                              flops_per_launch=wk["flops"], hbm_bytes_per_launch=wk["hbm_bytes"],
-                             hip_event_bracket_of_an_empty_kernel_ms=0.0 if dominant in KERNEL_EXACT else bracket_ms)
+                             hip_event_bracket_of_an_empty_kernel_ms=0.0 if st.get("exact", 0) == st["launches"] else bracket_ms)
                 elif wk:
                     r.update(achieved=dom.get("achieved"), frac=dom.get("frac"), avg_launch_ms=1e-3 * dom["avg_us"],
                              launches_note="from the per-kernel leg (no live bracket landed in the timed region)")

@@ -49,7 +49,7 @@ class KernelSpan(C.Structure):
 
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("ms", C.c_float), ("launches", C.c_int), ("flops", C.c_double),
-                ("bytes", C.c_double)]
+                ("bytes", C.c_double), ("exact_launches", C.c_int), ("reserved", C.c_int)]
 
 
 class TrainerConfig(C.Structure):

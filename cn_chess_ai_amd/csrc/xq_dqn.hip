@@ -480,9 +480,9 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
     const bool bf = d->bf16();
     if (njobs == 1 && jobs[0].sel_keep && !bf && !shadow && !src.implicit && !src.slots) {
         const int H = d->L[1];
-        ProfScope ps(d, "l0_forward_gather", 2.0 * n * 32 * H, (double)n * (96 + (jobs[0].sel_keep == 2 ? 4.0 : 32.0) * H * 4 + H * 12));
+        ProfScope ps(d, "l0_forward_gather", 2.0 * n * 32 * H, (double)n * (96 + (jobs[0].sel_keep == 2 ? 4.0 : 32.0) * H * 4 + H * 12), true);
         xq_dqn::SelKeep& K = d->sel_keep[d->cur == d->stream ? 0 : 1];
-        hipLaunchKernelGGL(l0_select_kernel, dim3((n + 3) / 4), dim3(256), 0, d->cur, jobs[0].boards, K.prev_boards, d->w0t(jobs[0].net),
+        hipExtLaunchKernelGGL(l0_select_kernel, dim3((n + 3) / 4), dim3(256), 0, d->cur, ps.start(), ps.stop(), 0, jobs[0].boards, K.prev_boards, d->w0t(jobs[0].net),
                            d->bl(jobs[0].net, 0), K.z1, jobs[0].outs[0], n, H, jobs[0].sel_keep == 2 ? 1 : 0);
         XQ_HIP(hipGetLastError());
     } else
@@ -515,10 +515,10 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
                 XQ_HIP(hipGetLastError());
             }
         }
-        ProfScope ps(d, "l0_forward_gather", 2.0 * njobs * n * 32 * H, (double)njobs * n * (48 + 32.0 * H * (bf ? 2 : 4) + H * 4));
+        ProfScope ps(d, "l0_forward_gather", 2.0 * njobs * n * 32 * H, (double)njobs * n * (48 + 32.0 * H * (bf ? 2 : 4) + H * 4), true);
         // (grid rows: the job rows that are really gathered, then the shadow row; the kernel tests blockIdx.y == J.nrows for it)
-        if (bf) hipLaunchKernelGGL(l0_forward_kernel<true>, dim3((n + 3) / 4, J.nrows), dim3(256), 0, d->cur, J, src, n, H);
-        else hipLaunchKernelGGL(l0_forward_kernel<false>, dim3((n + 3) / 4, J.nrows + (ride ? 1 : 0)), dim3(256), 0, d->cur, J, src, n, H);
+        if (bf) hipExtLaunchKernelGGL(l0_forward_kernel<true>, dim3((n + 3) / 4, J.nrows), dim3(256), 0, d->cur, ps.start(), ps.stop(), 0, J, src, n, H);
+        else hipExtLaunchKernelGGL(l0_forward_kernel<false>, dim3((n + 3) / 4, J.nrows + (ride ? 1 : 0)), dim3(256), 0, d->cur, ps.start(), ps.stop(), 0, J, src, n, H);
         XQ_HIP(hipGetLastError());
     }
     for (int l = 1; l + 1 < d->nl; ++l) {
@@ -562,8 +562,8 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
                 g.head_W = d->wl(jobs[0].net, d->nl - 1); g.head_ldw = g.N;
                 g.head_slabs = jobs[0].head_slabs; g.head_slab_stride = (long long)n * 96; g.head_ld = 96;
                 if (!g.a_vec || !g.b_vec || !vec_ok(g.head_W, g.head_ldw)) return fail(XQ_ERR_RUNTIME, "select head: unaligned operand");
-                ProfScope ps(d, "gemm_hidden_fwd", 2.0 * n * g.N * (g.K + 96.0), 4.0 * ((double)n * g.K + (double)g.N * g.K + (double)(g.N / 64) * n * 96));
-                hipLaunchKernelGGL((gemm_f32_kernel<L_KCONTIG, L_KCONTIG, EPI_HEAD, 1, 1>), dim3(n / 64, g.N / 64, 1), dim3(256), 0, d->cur, g);
+                ProfScope ps(d, "gemm_hidden_fwd", 2.0 * n * g.N * (g.K + 96.0), 4.0 * ((double)n * g.K + (double)g.N * g.K + (double)(g.N / 64) * n * 96), true);
+                hipExtLaunchKernelGGL((gemm_f32_kernel<L_KCONTIG, L_KCONTIG, EPI_HEAD, 1, 1>), dim3(n / 64, g.N / 64, 1), dim3(256), 0, d->cur, ps.start(), ps.stop(), 0, g);
                 XQ_HIP(hipGetLastError());
                 continue;
             }
@@ -583,17 +583,20 @@ static int chain_boards(xq_dqn* d, const ChainJob* jobs, int njobs, SlotSrc src,
                 const int t128 = (n / 128) * (g.N / 128) * groups;
                 g.k_chunk = g.K; g.a_vec = g.b_vec = 1;
                 ProfScope ps(d, "gemm_hidden_fwd", 2.0 * n * (double)g.N * g.K * groups,
-                             4.0 * groups * ((double)n * g.K + (double)g.N * g.K + (double)n * g.N));
+                             4.0 * groups * ((double)n * g.K + (double)g.N * g.K + (double)n * g.N), true);
                 // the event the trainer's select chain waits for rides on this kernel's own completion signal when it is the last of
                 // the chains (no marker packet on the stream: ~1.5 us less than a record, tools/sync_probe.hip variant 5)
-                hipEvent_t stop = (l == d->nl - 2 && d->cur == d->stream) ? d->fwd_stop_ev : nullptr;
+                // (a launch that is being timed carries the profiler's events instead: the fork is then recorded by the caller)
+                hipEvent_t stop = (l == d->nl - 2 && d->cur == d->stream && !ps.stop()) ? d->fwd_stop_ev : nullptr;
                 if (stop) d->fwd_stop_ev = nullptr;
+                hipEvent_t start = ps.start();
+                if (ps.stop()) stop = ps.stop();
                 if (t128 >= 512) {
-                    hipExtLaunchKernelGGL((gemm_fwd_persistent_kernel<2, 2, 2>), dim3(std::min(t128, 2 * d->ncu)), dim3(256), 0, d->cur, nullptr, stop, 0,
+                    hipExtLaunchKernelGGL((gemm_fwd_persistent_kernel<2, 2, 2>), dim3(std::min(t128, 2 * d->ncu)), dim3(256), 0, d->cur, start, stop, 0,
                                           g, n / 128, g.N / 128, t128);
                 } else {
                     const int total = (n / 64) * (g.N / 128) * groups;
-                    hipExtLaunchKernelGGL((gemm_fwd_persistent_kernel<1, 2, 2>), dim3(std::min(total, 2 * d->ncu)), dim3(256), 0, d->cur, nullptr, stop, 0,
+                    hipExtLaunchKernelGGL((gemm_fwd_persistent_kernel<1, 2, 2>), dim3(std::min(total, 2 * d->ncu)), dim3(256), 0, d->cur, start, stop, 0,
                                           g, n / 64, g.N / 128, total);
                 }
                 XQ_HIP(hipGetLastError());
@@ -1062,8 +1065,8 @@ static int sgd_apply(xq_dqn* d, SegTable t, double alpha) {
         mx = std::max(mx, t.vec4[i] ? t.len[i] / 4 : t.len[i]);
     }
     const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>((mx + 255) / 256, 1024));
-    ProfScope ps(d, t.reduce_only ? "reduce_slabs" : "sgd_apply", 0, 0);
-    hipLaunchKernelGGL(sgd_segments_kernel, dim3(bx, t.nseg), dim3(256), 0, d->cur, t, (float)alpha);
+    ProfScope ps(d, t.reduce_only ? "reduce_slabs" : "sgd_apply", 0, 0, true);
+    hipExtLaunchKernelGGL(sgd_segments_kernel, dim3(bx, t.nseg), dim3(256), 0, d->cur, ps.start(), ps.stop(), 0, t, (float)alpha);
     XQ_HIP(hipGetLastError());
     return XQ_OK;
 }
@@ -1535,14 +1538,14 @@ static int tail_launch(xq_dqn* d, bool last, const char* name) {
     const TailArgs& T = *d->tail;
     const long long total = (long long)T.n_l0 + T.n_grad + T.n_delta + T.n_out + T.n_colsum + T.n_sel;
     if (total <= 0) return XQ_OK;
-    ProfScope ps(d, name, d->tail_flops, d->tail_bytes);
+    ProfScope ps(d, name, d->tail_flops, d->tail_bytes, true);      // one launch: timed by its own start / stop events
     auto launch = [&](auto kern) {
         static size_t granted = 48 * 1024;            // per instantiation
         if (d->tail_lds > granted) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
             granted = 64 * 1024;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), d->tail_lds, d->cur, T);
+        hipExtLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), d->tail_lds, d->cur, ps.start(), ps.stop(), 0, T);
     };
     if (last && T.l0_planes != nullptr) launch(td_tail_kernel<TAIL_L0 | TAIL_GRAD | TAIL_OUT | TAIL_COLSUM, true>);
     else if (last) launch(td_tail_kernel<TAIL_L0 | TAIL_GRAD | TAIL_OUT | TAIL_COLSUM>);
@@ -1829,12 +1832,12 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         // then have the chip to itself, 17 instead of 27-34 us — the select chain ends after the gradients and the step waits for
         // it: 0.197 -> 0.207 ms)
         {
-            ProfScope ps(d, "qmax_refine", 2.0 * n * Hl * 3, 12.0 * G * n + 4.0 * n * Hl);
+            ProfScope ps(d, "qmax_refine", 2.0 * n * Hl * 3, 12.0 * G * n + 4.0 * n * Hl, true);      // one launch: its own start / stop events
             const size_t lds = (size_t)G * kRefineSamples * (sizeof(uint32_t) + sizeof(uint16_t));
             const dim3 grid((n + kRefineSamples - 1) / kRefineSamples);
             auto launch = [&](auto kern) {
-                hipLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, d->scr_p1, d->scr_p2, G, n, ldp, touts[nl - 2], Hl, d->wl(sel_net, nl - 1),
-                                   d->bl(sel_net, nl - 1), NO, d->scr_wmax, parity, d->zmax, d->scr_stats);
+                hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, ps.start(), ps.stop(), 0, d->scr_p1, d->scr_p2, G, n, ldp, touts[nl - 2], Hl,
+                                      d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, d->scr_wmax, parity, d->zmax, d->scr_stats);
             };
             const bool small = G <= 8 * 32;
             if (scr_new) {
@@ -1852,8 +1855,9 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
                     T.dtop = d->deltas[lt]; T.dsc = d->dsc; T.act = d->act_mb; T.qsa = d->qsa; T.yv = d->yv; T.lossv = d->lossv;
                 }
                 auto launch2 = [&](auto kern) {
-                    hipLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, d->scr_R, scr_ranges, scr_gpr, d->scr_p1, d->scr_p2, G, n, ldp, d->scr_na,
-                                       touts[nl - 2], Hl, d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, d->scr_wmax, parity, d->zmax, d->scr_stats, T);
+                    hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, ps.start(), ps.stop(), 0, d->scr_R, scr_ranges, scr_gpr, d->scr_p1, d->scr_p2, G, n,
+                                          ldp, d->scr_na, touts[nl - 2], Hl, d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, d->scr_wmax, parity, d->zmax,
+                                          d->scr_stats, T);
                 };
                 if (td_fused) launch2(qmax_refine2_kernel<256, true>);
                 else if (Hl == 256) launch2(qmax_refine2_kernel<256>); else launch2(qmax_refine2_kernel<512>);
@@ -2227,7 +2231,7 @@ int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_st
             const Profiler::Cat& c = d->prof.cats[i];
             memset(&stats[n], 0, sizeof stats[n]);
             strncpy(stats[n].name, c.name, sizeof stats[n].name - 1);
-            stats[n].ms = c.ms; stats[n].launches = c.launches; stats[n].flops = c.flops; stats[n].bytes = c.bytes;
+            stats[n].ms = c.ms; stats[n].launches = c.launches; stats[n].flops = c.flops; stats[n].bytes = c.bytes; stats[n].exact_launches = c.exact;
         }
     }
     if (n_stats) *n_stats = n;

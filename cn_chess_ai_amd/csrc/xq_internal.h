@@ -136,7 +136,7 @@ namespace xq {
 
 // HIP-event profiler: brackets individual launches on the handle's stream (bench.py roofline leg).  Disabled = free.
 struct Profiler {
-    struct Cat { char name[48]; double flops = 0, bytes = 0; int launches = 0; float ms = 0; };
+    struct Cat { char name[48]; double flops = 0, bytes = 0; int launches = 0; int exact = 0; float ms = 0; };   // exact: launches timed by their own events
     struct Rec { int cat; hipEvent_t a, b; bool attached; };   // attached: a / b are the start / stop events of the kernel's own launch
     struct Span { char name[48]; float start_ms, end_ms; };      // relative to the first bracket of the batch (live timeline)
     std::vector<Span> spans;
@@ -195,7 +195,7 @@ struct Profiler {
         if (h < 0) return;
         if (!recs[h].attached) (void)hipEventRecord(recs[h].b, s);
         Cat& c = cats[recs[h].cat];
-        c.flops += flops; c.bytes += bytes; c.launches += 1;
+        c.flops += flops; c.bytes += bytes; c.launches += 1; c.exact += recs[h].attached ? 1 : 0;
     }
     void collect() {
         if (!recs.empty()) spans.clear();

@@ -182,7 +182,7 @@ class DQN:
         n = C.c_int32()
         call("xq_dqn_kernel_stats", self._h, int(enable), arr, 64, C.byref(n))
         return [dict(name=arr[i].name.decode(), ms=arr[i].ms, launches=arr[i].launches, flops=arr[i].flops,
-                     bytes=arr[i].bytes) for i in range(n.value)]
+                     bytes=arr[i].bytes, exact=arr[i].exact_launches) for i in range(n.value)]
 
 
 def _kernel_filter(self, names=None):

@@ -375,7 +375,10 @@ int xq_dqn_last_td_values(xq_dqn* d, int n, float* q_sa_host, float* y_host);
  * enable: -1 leave, 0 off, 1 on, 2 on + clear, 3 on + clear but bracket only the TD step's dominant GEMM (gemm_qmax_rowmax /
  * gemm_qmax_screen) and env_selfplay_step, 4 = 3 with the GEMM bracketed on every 4th launch only (a pair of event records
  * drains the stream's queue: ~10 us per bracket). */
-typedef struct { char name[48]; float ms; int launches; double flops; double bytes; } xq_kernel_stat;
+/* exact_launches: how many of `launches` were timed by the kernel's OWN start / stop events (single-kernel brackets, launched with
+ * hipExtLaunchKernelGGL): their ms is the kernel's duration as a profiler reports it; the others are pairs of recorded events around the
+ * launch(es), which read ~6.5 us more per bracket. */
+typedef struct { char name[48]; float ms; int launches; double flops; double bytes; int exact_launches; int reserved; } xq_kernel_stat;
 int xq_dqn_kernel_stats(xq_dqn* d, int enable, xq_kernel_stat* stats, int max_stats, int* n_stats);
 /* Which launches enable = 3 / 4 bracket: a comma-separated list of bracket names as xq_dqn_kernel_stats reports them (launches of the
  * self-play loop's select chain on the trainer's collect stream carry the suffix "@select"; "rccl_allreduce_grads" = the gradient
