@@ -948,9 +948,8 @@ def main():
                                     "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("env_kernel<2>(", args.config)[0], "avg_launch_ms": ms,
                                     "bytes_per_launch": by, "launches": e["launches"],
-                                    "launches_note": "HIP-event brackets on " + ("every launch" if args.bracket_all or args.profile_all else
-                                                     "every 5th launch (the brackets sit on the collect stream: ~12 us per ply, which "
-                                                     "is the critical chain when an update has several plies)")}
+                                    "launches_note": (KERNEL_EXACT_NOTE if e.get("exact", 0) == e["launches"] else "HIP-event brackets") + " on " +
+                                                     ("every launch" if args.bracket_all or args.profile_all else "every 5th launch")}
             mix = env_instruction_mix(args.config, n_games) if n_games == CFG["games"] else None
             if mix:
                 # the bound that actually applies: instruction issue.  Floor = the larger of the VALU issue time (a wave64 VALU

@@ -442,6 +442,9 @@ static int ensure_screen_capacity(xq_dqn* d, int n) {
         if (d->scr_na) XQ_HIP(hipFree(d->scr_na));
         XQ_HIP(hipMalloc(&d->scr_R, (size_t)((NO + 63) / 64) * rows * sizeof(float)));       // at most one range per 64-row chunk
         XQ_HIP(hipMalloc(&d->scr_na, rows * sizeof(float)));
+        if (const char* e = getenv("XQ_DEBUG_PTRS")) if (e[0] == '1')
+            fprintf(stderr, "[xq] screening buffers: P1 %p P2 %p R %p ab %p na %p params %p acts %p\n", (void*)d->scr_p1, (void*)d->scr_p2, (void*)d->scr_R,
+                    (void*)d->scr_ab, (void*)d->scr_na, (void*)d->params[0], (void*)d->tacts[0]);
         // candidate counters: one pair per refine block (32 samples); the totals of the array it replaces are carried on the host
         if (d->scr_stats) {
             unsigned long long sums[2];
@@ -1833,8 +1836,10 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
         // it: 0.197 -> 0.207 ms)
         {
             ProfScope ps(d, "qmax_refine", 2.0 * n * Hl * 3, 12.0 * G * n + 4.0 * n * Hl, true);      // one launch: its own start / stop events
-            const size_t lds = (size_t)G * kRefineSamples * (sizeof(uint32_t) + sizeof(uint16_t));
             const dim3 grid((n + kRefineSamples - 1) / kRefineSamples);
+            // one block per CU and K = 256: room in LDS for the staged pass of qmax_refine2_kernel (whole groups that many samples ask for)
+            const bool stage = scr_new && Hl == 256 && (int)grid.x <= d->ncu;
+            const size_t lds = refine_cand_words((int)G) * sizeof(uint32_t) + refine_wlist_bytes((int)G) + (stage ? refine_stage_bytes() : 0);
             auto launch = [&](auto kern) {
                 hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, ps.start(), ps.stop(), 0, d->scr_p1, d->scr_p2, G, n, ldp, touts[nl - 2], Hl,
                                       d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, d->scr_wmax, parity, d->zmax, d->scr_stats);
@@ -1854,10 +1859,16 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
                     T.gamma = (float)d->gamma;
                     T.dtop = d->deltas[lt]; T.dsc = d->dsc; T.act = d->act_mb; T.qsa = d->qsa; T.yv = d->yv; T.lossv = d->lossv;
                 }
+                // whole groups of qmax_refine2_kernel: 2 = the popular ones through LDS when the launch has room for it, 1 = all of them four per
+                // round trip from global memory (XQ_REFINE_WHOLE=1: A/B knob, same bits)
+                static const bool whole_staged = [] { const char* e = getenv("XQ_REFINE_WHOLE"); return !(e && e[0] == '1'); }();
+                const int whole_mode = (whole_staged && stage) ? 2 : 1;
                 auto launch2 = [&](auto kern) {
+                    static bool granted = false;          // per instantiation: the staged pass asks for ~145 KB of dynamic LDS
+                    if (!granted) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); granted = true; }
                     hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, ps.start(), ps.stop(), 0, d->scr_R, scr_ranges, scr_gpr, d->scr_p1, d->scr_p2, G, n,
                                           ldp, d->scr_na, touts[nl - 2], Hl, d->wl(sel_net, nl - 1), d->bl(sel_net, nl - 1), NO, d->scr_wmax, parity, d->zmax,
-                                          d->scr_stats, T);
+                                          d->scr_stats, T, whole_mode);
                 };
                 if (td_fused) launch2(qmax_refine2_kernel<256, true>);
                 else if (Hl == 256) launch2(qmax_refine2_kernel<256>); else launch2(qmax_refine2_kernel<512>);

@@ -6,6 +6,7 @@
 // the self-play path.  HBM traffic per game and ply: board 48 B + meta 16 B read and written,
 // 360 B of Q-values read, one transition record (48+48+4+4+1 B) written.
 #include "xq_internal.h"
+#include <hip/hip_ext.h>
 #include "xq_rules.hip.h"
 
 #include <algorithm>
@@ -415,7 +416,7 @@ static EnvParams base_params(xq_env* e) {
 }
 
 int env_selfplay_launch(xq_env* e, const float* q90_dev, int q_stride, uint32_t eps_u32, xq_step_result* results_dev,
-                        xq_replay* replay, hipStream_t on, const QSource* qs) {
+                        xq_replay* replay, hipStream_t on, const QSource* qs, hipEvent_t ev_start, hipEvent_t ev_stop) {
     EnvParams P = base_params(e);
     P.q90 = q90_dev;
     P.q_stride = q_stride;
@@ -433,7 +434,8 @@ int env_selfplay_launch(xq_env* e, const float* q90_dev, int q_stride, uint32_t 
     }
     const int blocks = (e->n + 3) / 4;
     if (replay != nullptr) XQ_TRY(replay_writer_begin(replay, on ? on : e->stream));    // (costs nothing when the ring's users share this stream)
-    hipLaunchKernelGGL(env_kernel<MODE_SELFPLAY>, dim3(blocks), dim3(256), 0, on ? on : e->stream, P);
+    if (ev_start || ev_stop) hipExtLaunchKernelGGL(env_kernel<MODE_SELFPLAY>, dim3(blocks), dim3(256), 0, on ? on : e->stream, ev_start, ev_stop, 0, P);
+    else hipLaunchKernelGGL(env_kernel<MODE_SELFPLAY>, dim3(blocks), dim3(256), 0, on ? on : e->stream, P);
     XQ_HIP(hipGetLastError());
     if (replay != nullptr) {
         replay->write_pos = (replay->write_pos + e->n) % replay->dev.capacity;

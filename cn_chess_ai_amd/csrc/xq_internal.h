@@ -250,6 +250,7 @@ int replay_per_sample(xq_replay* r, int batch, hipStream_t on);
 
 // env-side launchers used by the trainer
 int env_selfplay_launch(xq_env* env, const float* q90_dev, int q_stride, uint32_t eps_u32, xq_step_result* results_dev,
-                        xq_replay* replay, hipStream_t on = nullptr, const QSource* qs = nullptr);
+                        xq_replay* replay, hipStream_t on = nullptr, const QSource* qs = nullptr, hipEvent_t ev_start = nullptr,
+                        hipEvent_t ev_stop = nullptr);      // ev_*: the kernel's own start / stop events (profiler, kernel-exact timing)
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 }  // namespace xq

@@ -216,19 +216,27 @@ struct TdFused {
     float gamma;
     float* dtop; float* dsc; int32_t* act; float* qsa; float* yv; float* lossv;
 };
+// 32-bit words of the candidate list in qmax_refine2_kernel's dynamic LDS: G * 32 entries, and never less than the 32 KB its staged pass
+// parks a group's rows of W in
+__host__ __device__ inline size_t refine_cand_words(int G) { const size_t w = (size_t)G * 32; return w < 8192 ? 8192 : w; }
+// bytes of the whole-group list, and of the extra dynamic LDS of the staged pass (activation rows + the rows of two more groups), K = 256
+__host__ __device__ inline size_t refine_wlist_bytes(int G) { return ((size_t)G * 32 * sizeof(uint16_t) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t refine_stage_bytes() { return (size_t)3 * 32 * 256 * sizeof(float); }
 template <int KFIX, bool TD = false>
 __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restrict__ R, int ranges, int gpr /* groups per range */,
                                                            const float* __restrict__ P1, const float* __restrict__ P2, int G, int n, long long ldp,
                                                            const float* __restrict__ na_all, const float* __restrict__ a_last, int K,
                                                            const float* __restrict__ W, const float* __restrict__ bias, int NO,
                                                            unsigned* __restrict__ wm, int parity, float* __restrict__ zmax,
-                                                           unsigned long long* __restrict__ stats, const TdFused T) {
+                                                           unsigned long long* __restrict__ stats, const TdFused T, int whole_mode) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cand[];            // [G * 32]: sample | row << 5
-    uint16_t* wlist = reinterpret_cast<uint16_t*>(cand + (size_t)G * kRefineSamples);    // [G * 32]: sample | group << 5
+    uint16_t* wlist = reinterpret_cast<uint16_t*>(cand + refine_cand_words(G));          // [G * 32]: sample | group << 5
     __shared__ float sv[8][32];
     __shared__ float thr[32];
     __shared__ int best[32];
     __shared__ int cnt, nexp;
+    __shared__ unsigned gbits[256];     // per group: the samples of the block that ask for it as a whole group (G <= 256: see stage_ok)
+    __shared__ unsigned long long gpop[4];      // per wave: the groups tid that >= 8 samples ask for
     const int tid = (int)threadIdx.x;
     const int sl = tid & 31, phase = tid >> 5;
     const int ql = tid & 15, quarter = tid >> 4;
@@ -240,6 +248,8 @@ __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restri
     unsigned long long st_pairs = 0, st_whole = 0;   // candidate counters: [block][2] running totals, one writer per slot (stream order)
     if (tid == 0) { st_pairs = stats[2 * blockIdx.x]; st_whole = stats[2 * blockIdx.x + 1]; }
     if (tid < 32) best[tid] = (int)0x80000000;
+    const bool stage_ok = KFIX > 0 && G <= 256;
+    gbits[tid] = 0u;                    // (ordered before the scan below by the barriers in between)
     // TD: lanes 0..7 of each wave hold action / reward / done / output bias of the wave's eight samples; zq[i] = Q(s,a) before the tanh
     const int td_lane = tid & 63, td_w = tid >> 6;
     int td_a = -1; float td_r = 0.f, td_bo = 0.f; bool td_dn = false;
@@ -285,15 +295,20 @@ __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restri
         for (int r = phase; r < ranges; r += 8) {
             if (R[(long long)r * ldp + bc] < t) continue;        // no group of this range reaches the threshold
             const int g0 = r * gpr, g1 = min(G, g0 + gpr);
-            for (int g = g0; g < g1; g += 4) {                   // four independent loads in flight
-                float v[4];
+            // the groups of a range sixteen at a time, all loads in flight, then the second-largest values of the groups that reach the
+            // threshold, again all in flight: two round trips per range instead of one per four groups plus one per hit.  (A net whose
+            // per-range maxima all lie within the bound of each other — some fresh nets do, for a whole run — scans every range of every
+            // sample: that kernel read 65 us instead of 27 with four loads in flight.)
+            for (int g = g0; g < g1; g += 16) {
+                float v[16], v2[16];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = P1[(long long)min(g + u, g1 - 1) * ldp + bc];
+                for (int u = 0; u < 16; ++u) v[u] = P1[(long long)min(g + u, g1 - 1) * ldp + bc];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 16; ++u) v2[u] = (g + u < g1 && v[u] >= t) ? P2[(long long)(g + u) * ldp + bc] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
                     if (g + u < g1 && v[u] >= t) {
-                        const float v2 = P2[(long long)(g + u) * ldp + bc];
-                        if (v2 >= t) wlist[atomicAdd(&nexp, 1)] = (uint16_t)(sl | ((g + u) << 5));
+                        if (v2[u] >= t) { wlist[atomicAdd(&nexp, 1)] = (uint16_t)(sl | ((g + u) << 5)); if (stage_ok) atomicOr(&gbits[g + u], 1u << sl); }
                         else cand[atomicAdd(&cnt, 1)] = (uint32_t)sl | ((uint32_t)screen_row(g + u, (int)(__builtin_bit_cast(uint32_t, v[u]) & 31u)) << 5);
                     }
                 }
@@ -322,18 +337,131 @@ __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restri
             if (live[r] && ql == 0 && z[r] == z[r]) atomicMax(&best[s2[r]], float_order_key(z[r]));   // (a NaN output never wins: fmaxf semantics)
         }
     }
-    for (int e = 0; e < wholes; ++e) {                           // a whole group: its 32 rows over the 16 quarters, one round
-        const int ent = wlist[e];
-        const int s2 = ent & 31, g = ent >> 5;
-        float zb = kColmaxPadBias;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int row = screen_row(g, quarter + 16 * r);
-            const int rc = min(row, NO - 1);
-            const float z = quarter_sum(quarter_dot<KFIX>(a_last + (long long)(b0 + s2) * K, W + (long long)rc * K, K, ql)) + bias[rc];
-            if (row < NO) zb = fmaxf(zb, z);
+    // Whole groups that MANY samples of the block ask for (>= 8 of 32; nets whose two largest outputs of a sample sit in ONE group within the
+    // bound of each other — the trained rows 0..95 in about a fifth of the runs from time-seeded weights — ask for the same group for nearly
+    // every sample): the group's 32 rows of W are staged into LDS once (the candidate list's space: the round of single rows is over) and
+    // every sample of that group takes them from there, instead of 32 KB through the texture path per sample (262 MB per launch: the kernel
+    // read 55-65 us instead of 27 and the step 0.205 instead of 0.173 ms, tools/facade_rep.sh).  Same dots, same order inside a dot, same bits.
+    // whole_mode 2 (the host grants it when the launch has one block per CU and K = 256): the block's dynamic LDS has room for the 32 activation
+    // rows of its samples and the rows of W of THREE groups (refine_stage_bytes); everything the popular groups need then arrives in ONE round
+    // trip and every dot reads LDS.  The loops above and below cost a dependent round trip per four groups: ~3 us each beside the select
+    // chain, 24 us for 26 groups per block; this pass: ~6 us.
+    const bool staged_pass = stage_ok && KFIX == 256 && wholes >= 8 && whole_mode == 2;
+    if (staged_pass) {
+        float* Wt0 = reinterpret_cast<float*>(cand);                                                          // [32][256]
+        float* At = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(wlist) + refine_wlist_bytes(G));   // [32][256], then W tiles 1, 2
+        {   // which groups: one ballot per wave over "thread tid's group has >= 8 samples"
+            const unsigned long long m = __ballot(__popc(gbits[tid]) >= 8);
+            if ((tid & 63) == 0) gpop[tid >> 6] = m;
         }
-        if (ql == 0) atomicMax(&best[s2], float_order_key(zb));
+        __syncthreads();                                         // (also: every thread has left the candidate list)
+        unsigned long long gm[4] = {gpop[0], gpop[1], gpop[2], gpop[3]};       // block-uniform
+        bool a_staged = false;
+        for (;;) {
+            int gs[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                gs[u] = -1;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv)
+                    if (gs[u] < 0 && gm[wv]) { gs[u] = wv * 64 + __builtin_ctzll(gm[wv]); gm[wv] &= gm[wv] - 1; }
+            }
+            if (gs[0] < 0) break;
+            // two round trips (16 x 16 bytes per thread in flight each): the activation rows (first sweep) and the rows of up to three groups,
+            // with this thread's biases
+            float bj[3][2];
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) bj[u][r] = gs[u] >= 0 ? bias[min(screen_row(gs[u], quarter + 16 * r), NO - 1)] : 0.f;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float4 ra[4], rw0[4], rw1[4], rw2[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = (half * 4 + q) * 256 + tid, j = i >> 6, c = i & 63;       // float4 i of a [32][256] tile
+                    // (unconditional loads — a group that is not there reads group gs[0]'s rows again — so that the arrays stay in registers)
+                    ra[q] = *reinterpret_cast<const float4*>(a_last + (long long)min(b0 + j, n - 1) * K + 4 * c);
+                    rw0[q] = *reinterpret_cast<const float4*>(W + (long long)min(screen_row(gs[0], j), NO - 1) * K + 4 * c);
+                    rw1[q] = *reinterpret_cast<const float4*>(W + (long long)min(screen_row(gs[1] >= 0 ? gs[1] : gs[0], j), NO - 1) * K + 4 * c);
+                    rw2[q] = *reinterpret_cast<const float4*>(W + (long long)min(screen_row(gs[2] >= 0 ? gs[2] : gs[0], j), NO - 1) * K + 4 * c);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = (half * 4 + q) * 256 + tid;
+                    if (!a_staged) reinterpret_cast<float4*>(At)[i] = ra[q];
+                    if (gs[0] >= 0) reinterpret_cast<float4*>(Wt0)[i] = rw0[q];
+                    if (gs[1] >= 0) reinterpret_cast<float4*>(At + 1 * 32 * 256)[i] = rw1[q];
+                    if (gs[2] >= 0) reinterpret_cast<float4*>(At + 2 * 32 * 256)[i] = rw2[q];
+                }
+            }
+            a_staged = true;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (gs[u] < 0) continue;
+                const float* Wt = u == 0 ? Wt0 : At + u * 32 * 256;
+                unsigned left = gbits[gs[u]];                    // block-uniform
+                while (left) {
+                    const int s2 = __builtin_ctz(left);
+                    left &= left - 1;
+                    float zb = kColmaxPadBias;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const int j = quarter + 16 * r;
+                        const float z = quarter_sum(quarter_dot<KFIX>(At + s2 * 256, Wt + j * 256, K, ql)) + bj[u][r];
+                        if (screen_row(gs[u], j) < NO) zb = fmaxf(zb, z);
+                    }
+                    if (ql == 0) atomicMax(&best[s2], float_order_key(zb));
+                }
+            }
+            __syncthreads();                                     // before the next sweep overwrites the tiles
+        }
+    }
+    // whole groups: the 32 rows of a group over the 16 quarters — FOUR groups per round trip, all their loads in flight (as many registers as
+    // the round of single rows above).  One group per round trip made this loop the longest thing in the step for nets whose two largest
+    // outputs of a sample sit in one group within the bound of each other (the trained rows 0..95 of some runs: a whole group for nearly every
+    // sample, 32 round trips per block — the kernel read 55-65 us instead of 27, the step 0.205 instead of 0.173 ms, tools/facade_queues.sh).
+    if (staged_pass) {
+        for (int e = 0; e < wholes; ++e) {                       // what the staged pass left: groups that few samples ask for
+            const int ent = wlist[e];
+            const int s2 = ent & 31, g = ent >> 5;
+            if (__popc(gbits[g]) >= 8) continue;                 // block-uniform
+            float zb = kColmaxPadBias;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = screen_row(g, quarter + 16 * r);
+                const int rc = min(row, NO - 1);
+                const float z = quarter_sum(quarter_dot<KFIX>(a_last + (long long)(b0 + s2) * K, W + (long long)rc * K, K, ql)) + bias[rc];
+                if (row < NO) zb = fmaxf(zb, z);
+            }
+            if (ql == 0) atomicMax(&best[s2], float_order_key(zb));
+        }
+    } else
+    for (int e0 = 0; e0 < wholes; e0 += 4) {
+        float zz[4][2];
+        int s2[4], gq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ent = wlist[min(e0 + u, wholes - 1)];
+            s2[u] = ent & 31; gq[u] = ent >> 5;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int rc = min(screen_row(gq[u], quarter + 16 * r), NO - 1);
+                zz[u][r] = quarter_dot<KFIX>(a_last + (long long)(b0 + s2[u]) * K, W + (long long)rc * K, K, ql);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float zb = kColmaxPadBias;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = screen_row(gq[u], quarter + 16 * r);
+                const float z = quarter_sum(zz[u][r]) + bias[min(row, NO - 1)];
+                if (row < NO) zb = fmaxf(zb, z);
+            }
+            if (ql == 0 && e0 + u < wholes) atomicMax(&best[s2[u]], float_order_key(zb));
+        }
     }
     __syncthreads();
     if (tid < 32 && ok) zmax[b] = float_from_key(best[sl]);

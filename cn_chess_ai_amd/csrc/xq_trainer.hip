@@ -178,8 +178,9 @@ static int collect_impl(xq_trainer* t) {
         t->replay->size = 0;
     }
     Profiler* p = dqn_profiler(t->dqn);
-    const int h = p->begin("env_selfplay_step", s);
-    XQ_TRY(env_selfplay_launch(t->env, q90, stride, t->eps_u32, nullptr, t->replay, on, &qs));
+    const int h = p->begin("env_selfplay_step", s, true);       // one kernel: timed by its own start / stop events
+    XQ_TRY(env_selfplay_launch(t->env, q90, stride, t->eps_u32, nullptr, t->replay, on, &qs, h >= 0 ? p->recs[h].a : nullptr,
+                               h >= 0 ? p->recs[h].b : nullptr));
     // algorithmic HBM bytes per game and ply: board+meta in/out (2*(48+16)), Q row 360, transition 48+48+4+4+1
     p->end(h, s, 0.0, (double)t->env->n * (2.0 * (48 + 16) + 360 + 105));
     t->env_steps += (uint64_t)t->env->n;

@@ -72,10 +72,11 @@ int main(int argc, char** argv) {
         if (json) {
             std::printf("{\"entry_point\": \"xq::ChessAI::train(%d)\", \"parallel_games\": %d, \"replay_capacity\": %d, \"minibatch\": %d, "
                         "\"episodes_reported\": %d, \"episodes_finished\": %llu, \"env_steps\": %llu, \"updates\": %llu, "
-                        "\"loop_seconds\": %.6f, \"train_call_seconds\": %.6f, \"env_steps_per_s\": %.1f, \"updates_per_s\": %.1f}\n",
+                        "\"loop_seconds\": %.6f, \"train_call_seconds\": %.6f, \"env_steps_per_s\": %.1f, \"updates_per_s\": %.1f, "
+                        "\"screened_steps\": %llu, \"guard_fallbacks\": %llu, \"candidate_groups_per_sample\": %.3f, \"whole_groups_per_sample\": %.3f}\n",
                         episodes, parallel, replay, minibatch, games, (unsigned long long)st.episodes, (unsigned long long)st.envSteps,
                         (unsigned long long)st.updates, st.seconds, s, st.seconds > 0 ? st.envSteps / st.seconds : 0.0,
-                        st.seconds > 0 ? st.updates / st.seconds : 0.0);
+                        st.seconds > 0 ? st.updates / st.seconds : 0.0, (unsigned long long)st.screenedSteps, (unsigned long long)st.guardFallbacks, st.candidateGroupsPerSample, st.wholeGroupsPerSample);
             return 0;
         }
         std::printf("%d episodes in %.2f s (%.0f episodes/s), mean captured material red %.1f black %.1f, model -> %s\n", games, s,

@@ -507,7 +507,11 @@ public:
     void setPrefillRandomPlies(int n) { prefillPlies_ = n; }
     // what the last batched train() did: plies played by this process, updates, episodes finished, wall seconds of the loop
     // (from the first iteration queued to the last one finished, model saves included)
-    struct TrainStats { uint64_t envSteps = 0, updates = 0, episodes = 0; double seconds = 0; };
+    // screenedSteps / guardFallbacks: TD steps that found max_a' Q(s',a') by exact screening, and how often the screen's guard sent a run of
+    // 512 steps to the full fp32 product instead (a net whose outputs lie within the bf16 bound of each other — typical of some fresh nets)
+    struct TrainStats { uint64_t envSteps = 0, updates = 0, episodes = 0; double seconds = 0; uint64_t screenedSteps = 0, guardFallbacks = 0;
+                        double candidateGroupsPerSample = 0, wholeGroupsPerSample = 0; };   // (sample, 32-output group) pairs the screen left for fp32
+                                                                                           // re-evaluation per sample; those re-evaluated as whole groups
     TrainStats lastTrainStats() const { return stats_; }
     // data-parallel train(): this process is rank comm->rank() of comm->world(); its batched games take the id range
     // [rank * parallelGames, (rank + 1) * parallelGames) and every update all-reduces the gradients over RCCL (nullptr = off)
@@ -597,6 +601,14 @@ private:
         uint64_t eps = 0;
         check(xq_trainer_counters(t, &stats_.envSteps, &stats_.updates, &eps));
         stats_.episodes = eps;
+        {
+            uint64_t q[4] = {0, 0, 0, 0}; int hold = 0;
+            check(xq_dqn_qmax_stats(td, q));
+            check(xq_dqn_qmax_guard(td, &stats_.guardFallbacks, &hold));
+            stats_.screenedSteps = q[0];
+            stats_.candidateGroupsPerSample = q[1] ? (double)q[2] / (double)q[1] : 0.0;
+            stats_.wholeGroupsPerSample = q[1] ? (double)q[3] / (double)q[1] : 0.0;
+        }
         dqn->setParameters(w, b);
         dqn->updateTargetNetwork();
     }

@@ -577,6 +577,43 @@ def test_online_td_next_state_chain_derived_and_direct(xq):
     env.close(); d.close()
 
 
+def test_screened_qmax_when_one_group_holds_the_two_largest_outputs(xq):
+    """The regime about a fifth of the runs from time-seeded weights train into (tools/whole_seed_scan.py): the trained rows dominate and the two
+    largest outputs of nearly every sample sit in ONE 32-row group within the bf16 bound of each other, so the screen asks for that WHOLE group
+    for nearly every sample.  qmax_refine2_kernel then stages the group's rows of W and the block's activation rows in LDS (one block per CU,
+    K = 256).  Rows 0..31 = one base row + perturbations of a bf16 rounding step, lifted above the rest by their bias; 8192 samples."""
+    from cn_chess_ai_amd import _capi
+    sizes = CFG2_NET
+    n = 8192
+    env = xq.VecEnv(n, seed=6)
+    for _ in range(7):
+        env.selfplay_step(None)
+    S, _ = env.get_state()
+    res = env.selfplay_step(None)
+    S2, _ = env.get_state()
+    A = (res["action"] % 90).astype(np.int32)
+    R = np.zeros(n, np.float32)
+    D = np.zeros(n, np.uint8)
+    d, w, b = make_net(xq, sizes, seed=21)
+    rng = np.random.default_rng(3)
+    wt = w.copy(); bt = b.copy()
+    nw_out = 8100 * 256
+    base = wt[-nw_out:-nw_out + 256].copy()
+    for r in range(32):
+        wt[len(wt) - nw_out + r * 256: len(wt) - nw_out + (r + 1) * 256] = base * (1.0 + 2.0 ** -9 * rng.standard_normal(256))
+    bt[len(bt) - 8100: len(bt) - 8100 + 32] += 0.75
+    d.set_params(wt, bt, net=1)
+    d.set_qmax_mode(_capi.QMAX_FULL)
+    _, y_full = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+    d.set_qmax_mode(_capi.QMAX_SCREENED)
+    _, y_scr = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+    steps, samples, pairs, whole = d.qmax_stats()
+    assert steps == 1 and samples == n
+    assert whole >= 0.9 * n, (pairs, whole)                      # the regime the test is named after
+    assert np.abs(y_full - y_scr).max() < 2e-6
+
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("sizes", [CFG2_NET, (1260, 512, 512, 512, 8100)])
 def test_screen_shadow_follows_every_parameter_change(xq, sizes):

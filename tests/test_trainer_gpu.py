@@ -458,7 +458,7 @@ def test_timing_knobs_do_not_change_a_bit(xq):
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "knob_probe.py")
     got = {}
-    for knob in ("", "XQ_EVENT_SYSFENCE=1", "XQ_FORK_STOP_EVENT=0", "XQ_SGD_SCALAR=1", "XQ_SCREEN_XCD=0", "XQ_SCREEN_XCD=1", "XQ_TAIL_GRAD_EARLY=1"):
+    for knob in ("", "XQ_EVENT_SYSFENCE=1", "XQ_FORK_STOP_EVENT=0", "XQ_SGD_SCALAR=1", "XQ_SCREEN_XCD=0", "XQ_SCREEN_XCD=1", "XQ_TAIL_GRAD_EARLY=1", "XQ_REFINE_WHOLE=1"):
         env = dict(os.environ)
         if knob:
             k, v = knob.split("=")
