@@ -114,6 +114,9 @@ struct xq_dqn {
     bool scr_guard_pending = false;
     unsigned long long scr_guard_samples = 0;          // scr_host_samples when the pending copy was queued
     unsigned long long scr_guard_queued_at = 0;        // scr_host_steps when it was queued
+    bool scr_stage_whole = false;                      // the last counter window showed whole groups for many samples: the refine kernel is
+                                                       // launched with the LDS of its staged pass (145 KB: otherwise it would keep the select
+                                                       // chain's blocks off its CUs for nothing — +3 us per step, same-box A/B)
     unsigned long long scr_seen[3] = {0, 0, 0};        // samples, pairs, whole groups at the last evaluation
     int scr_hold = 0;                                  // > 0: that many TD steps still run the full product
     unsigned long long scr_fallbacks = 0;
@@ -1742,6 +1745,10 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
                 d->scr_hold = kScreenHoldSteps;
                 d->scr_fallbacks += 1;
             }
+            if (ds > 0) {                                // whole groups per sample over the window, with hysteresis
+                const double share = (double)(h[1] - d->scr_seen[2]) / ds;
+                if (share > 0.25) d->scr_stage_whole = true; else if (share < 0.10) d->scr_stage_whole = false;
+            }
             d->scr_seen[0] = d->scr_guard_samples; d->scr_seen[1] = h[0]; d->scr_seen[2] = h[1];
         }
         if (d->scr_hold > 0) { --d->scr_hold; screened = false; }
@@ -1838,7 +1845,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             ProfScope ps(d, "qmax_refine", 2.0 * n * Hl * 3, 12.0 * G * n + 4.0 * n * Hl, true);      // one launch: its own start / stop events
             const dim3 grid((n + kRefineSamples - 1) / kRefineSamples);
             // one block per CU and K = 256: room in LDS for the staged pass of qmax_refine2_kernel (whole groups that many samples ask for)
-            const bool stage = scr_new && Hl == 256 && (int)grid.x <= d->ncu;
+            const bool stage = scr_new && Hl == 256 && (int)grid.x <= d->ncu && d->scr_stage_whole;
             const size_t lds = refine_cand_words((int)G) * sizeof(uint32_t) + refine_wlist_bytes((int)G) + (stage ? refine_stage_bytes() : 0);
             auto launch = [&](auto kern) {
                 hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, ps.start(), ps.stop(), 0, d->scr_p1, d->scr_p2, G, n, ldp, touts[nl - 2], Hl,

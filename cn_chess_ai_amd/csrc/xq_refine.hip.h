@@ -418,50 +418,22 @@ __global__ __launch_bounds__(256) void qmax_refine2_kernel(const float* __restri
             __syncthreads();                                     // before the next sweep overwrites the tiles
         }
     }
-    // whole groups: the 32 rows of a group over the 16 quarters — FOUR groups per round trip, all their loads in flight (as many registers as
-    // the round of single rows above).  One group per round trip made this loop the longest thing in the step for nets whose two largest
-    // outputs of a sample sit in one group within the bound of each other (the trained rows 0..95 of some runs: a whole group for nearly every
-    // sample, 32 round trips per block — the kernel read 55-65 us instead of 27, the step 0.205 instead of 0.173 ms, tools/facade_queues.sh).
-    if (staged_pass) {
-        for (int e = 0; e < wholes; ++e) {                       // what the staged pass left: groups that few samples ask for
-            const int ent = wlist[e];
-            const int s2 = ent & 31, g = ent >> 5;
-            if (__popc(gbits[g]) >= 8) continue;                 // block-uniform
-            float zb = kColmaxPadBias;
+    // whole groups that the staged pass did not take (few samples ask for them, or the launch has no room for the pass): the 32 rows of a
+    // group over the 16 quarters, one group per round trip.  (Four groups per round trip, measured: no faster in the regime that has many of
+    // them — that loop is a chain of round trips whatever is in flight — and 86 more registers, which cost the usual step 1.5 us.)
+    for (int e = 0; e < wholes; ++e) {
+        const int ent = wlist[e];
+        const int s2 = ent & 31, g = ent >> 5;
+        if (staged_pass && __popc(gbits[g]) >= 8) continue;      // block-uniform
+        float zb = kColmaxPadBias;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int row = screen_row(g, quarter + 16 * r);
-                const int rc = min(row, NO - 1);
-                const float z = quarter_sum(quarter_dot<KFIX>(a_last + (long long)(b0 + s2) * K, W + (long long)rc * K, K, ql)) + bias[rc];
-                if (row < NO) zb = fmaxf(zb, z);
-            }
-            if (ql == 0) atomicMax(&best[s2], float_order_key(zb));
+        for (int r = 0; r < 2; ++r) {
+            const int row = screen_row(g, quarter + 16 * r);
+            const int rc = min(row, NO - 1);
+            const float z = quarter_sum(quarter_dot<KFIX>(a_last + (long long)(b0 + s2) * K, W + (long long)rc * K, K, ql)) + bias[rc];
+            if (row < NO) zb = fmaxf(zb, z);
         }
-    } else
-    for (int e0 = 0; e0 < wholes; e0 += 4) {
-        float zz[4][2];
-        int s2[4], gq[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int ent = wlist[min(e0 + u, wholes - 1)];
-            s2[u] = ent & 31; gq[u] = ent >> 5;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int rc = min(screen_row(gq[u], quarter + 16 * r), NO - 1);
-                zz[u][r] = quarter_dot<KFIX>(a_last + (long long)(b0 + s2[u]) * K, W + (long long)rc * K, K, ql);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float zb = kColmaxPadBias;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int row = screen_row(gq[u], quarter + 16 * r);
-                const float z = quarter_sum(zz[u][r]) + bias[min(row, NO - 1)];
-                if (row < NO) zb = fmaxf(zb, z);
-            }
-            if (ql == 0 && e0 + u < wholes) atomicMax(&best[s2[u]], float_order_key(zb));
-        }
+        if (ql == 0) atomicMax(&best[s2], float_order_key(zb));
     }
     __syncthreads();
     if (tid < 32 && ok) zmax[b] = float_from_key(best[sl]);
