@@ -131,6 +131,7 @@ PROTOTYPES = {
     "xq_dqn_set_l0_derive": [_vp, _i],
     "xq_dqn_set_td_tail": [_vp, _i],
     "xq_dqn_set_l0_grad_mode": [_vp, _i],
+    "xq_dqn_set_refine_stage": [_vp, _i],
     "xq_dqn_set_exchange_overlap": [_vp, _i],
     "xq_dqn_calibrate_exchange": [_vp, _d, _pd, _pi],
     "xq_dqn_exchange_calibration": [_vp, _pi, _pd, _pd, _pi],

@@ -114,6 +114,7 @@ struct xq_dqn {
     bool scr_guard_pending = false;
     unsigned long long scr_guard_samples = 0;          // scr_host_samples when the pending copy was queued
     unsigned long long scr_guard_queued_at = 0;        // scr_host_steps when it was queued
+    int refine_stage = -1;                             // xq_dqn_set_refine_stage: -1 by the counters (scr_stage_whole), 0 never, 1 whenever it fits
     bool scr_stage_whole = false;                      // the last counter window showed whole groups for many samples: the refine kernel is
                                                        // launched with the LDS of its staged pass (145 KB: otherwise it would keep the select
                                                        // chain's blocks off its CUs for nothing — +3 us per step, same-box A/B)
@@ -1271,6 +1272,12 @@ int xq_dqn_set_l0_grad_mode(xq_dqn* d, int mode) {
     return XQ_OK;
 }
 
+int xq_dqn_set_refine_stage(xq_dqn* d, int mode) {
+    if (!d || mode < -1 || mode > 1) return fail(XQ_ERR_INVALID_ARGUMENT, "xq_dqn_set_refine_stage: -1 (by the screen's counters), 0 (never) or 1 (whenever the launch has room)");
+    d->refine_stage = mode;
+    return XQ_OK;
+}
+
 int xq_dqn_set_td_tail(xq_dqn* d, int on) {
     if (!d) return fail(XQ_ERR_INVALID_ARGUMENT, "null dqn");
     d->td_tail = on != 0;
@@ -1845,7 +1852,7 @@ static int td_grads_impl(xq_dqn* d, const uint32_t* boards, const uint32_t* next
             ProfScope ps(d, "qmax_refine", 2.0 * n * Hl * 3, 12.0 * G * n + 4.0 * n * Hl, true);      // one launch: its own start / stop events
             const dim3 grid((n + kRefineSamples - 1) / kRefineSamples);
             // one block per CU and K = 256: room in LDS for the staged pass of qmax_refine2_kernel (whole groups that many samples ask for)
-            const bool stage = scr_new && Hl == 256 && (int)grid.x <= d->ncu && d->scr_stage_whole;
+            const bool stage = scr_new && Hl == 256 && (int)grid.x <= d->ncu && (d->refine_stage > 0 || (d->refine_stage < 0 && d->scr_stage_whole));
             const size_t lds = refine_cand_words((int)G) * sizeof(uint32_t) + refine_wlist_bytes((int)G) + (stage ? refine_stage_bytes() : 0);
             auto launch = [&](auto kern) {
                 hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, d->cur, ps.start(), ps.stop(), 0, d->scr_p1, d->scr_p2, G, n, ldp, touts[nl - 2], Hl,

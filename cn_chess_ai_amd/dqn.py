@@ -230,6 +230,15 @@ def _set_l0_grad_mode(self, mode):
 DQN.set_l0_grad_mode = _set_l0_grad_mode
 
 
+def _set_refine_stage(self, mode):
+    """Exact screening, whole groups that many samples of a block share: -1 = through LDS while the screen's counters show many of them (default),
+    0 = never, 1 = whenever the launch has room.  Same bits either way."""
+    call("xq_dqn_set_refine_stage", self._h, int(mode))
+
+
+DQN.set_refine_stage = _set_refine_stage
+
+
 def _set_exchange_overlap(self, mode):
     """Data-parallel step: -1 auto, 0 select chain beside the gradient kernels, 1 beside the all-reduce (hides the exchange)."""
     call("xq_dqn_set_exchange_overlap", self._h, int(mode))

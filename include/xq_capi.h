@@ -299,6 +299,12 @@ int xq_dqn_set_td_tail(xq_dqn* d, int on);
  * the vector ALU.  Same value up to the summation order (both within a few fp32 ulp of an fp64 evaluation).  Measured at 8192 x 256
  * (round 5): 17 against 37 us alone, the headline step 0.1755 against 0.1833 ms. */
 int xq_dqn_set_l0_grad_mode(xq_dqn* d, int mode);
+/* Exact screening, second pass: groups whose two largest screened values both reach the threshold are re-evaluated WHOLE (32 rows).  Nets whose
+ * trained rows dominate can ask for one such group for nearly every sample; the refine kernel then serves the groups that many samples of a block
+ * share from LDS (activation rows of the block + the rows of up to three groups staged in one sweep; 145 KB of LDS, so only for launches of at most
+ * one block per CU and a 256-wide last hidden layer).  mode -1 (default): on while the screen's own counters — read back every 32 screened steps —
+ * show more than 0.25 whole groups per sample, off below 0.10; 0: never; 1: whenever the launch has room.  A speed switch: same bits either way. */
+int xq_dqn_set_refine_stage(xq_dqn* d, int mode);
 /* XQ_QMAX_*: how the TD step finds max_a' Q(s',a').  XQ_QMAX_SCREENED applies to fp32 nets with XQ_TD_ONLINE_NET / XQ_TD_TARGET_NET
  * whose last hidden width is a multiple of 64 and whose product is large enough for the persistent GEMM (>= 512 tiles of 128 x 128);
  * every other case silently keeps the full fp32 product.  Guard: every 32 screened steps the candidate counters are read back

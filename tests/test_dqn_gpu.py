@@ -509,6 +509,10 @@ def test_screened_qmax_degenerate_outputs(xq):
     _, _, pairs, whole = d.qmax_stats()
     assert np.abs(y_full - y_scr).max() < 2e-6
     assert pairs >= 250 * n and whole >= 200 * n
+    d.set_refine_stage(1)                                               # every group popular: 85 sweeps of the staged pass per block
+    _, y_staged = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+    d.set_refine_stage(-1)
+    assert np.array_equal(y_staged, y_scr)
     # guard: a net like this one is detected from the counters of the first 32 screened steps and the steps after the next check
     # boundary run the full product — same results, and the screened-step counter stops
     # (the counters queued behind screened step 32 are evaluated at screened step 64: the fallback step depends on the step count only)
@@ -606,11 +610,30 @@ def test_screened_qmax_when_one_group_holds_the_two_largest_outputs(xq):
     d.set_qmax_mode(_capi.QMAX_FULL)
     _, y_full = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
     d.set_qmax_mode(_capi.QMAX_SCREENED)
-    _, y_scr = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+    ys = {}
+    for stage in (0, 1):                                         # whole groups from global memory / the popular ones through LDS
+        d.set_refine_stage(stage)
+        _, ys[stage] = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
     steps, samples, pairs, whole = d.qmax_stats()
-    assert steps == 1 and samples == n
-    assert whole >= 0.9 * n, (pairs, whole)                      # the regime the test is named after
-    assert np.abs(y_full - y_scr).max() < 2e-6
+    assert steps == 2 and samples == 2 * n
+    assert whole >= 0.9 * 2 * n, (pairs, whole)                  # the regime the test is named after
+    assert np.array_equal(ys[0], ys[1])                          # same dots, same order inside a dot: same bits
+    assert np.abs(y_full - ys[1]).max() < 2e-6
+    # a block whose samples ask for MORE than three popular groups (two sweeps of the staged pass) and for unpopular ones beside them: rows
+    # 32..127 join the tie, so groups 0..3 are whole for every sample; then only every fourth sample's action row differs — nothing to do with
+    # the maximum, the targets must not move
+    for r in range(32, 128):
+        wt[len(wt) - nw_out + r * 256: len(wt) - nw_out + (r + 1) * 256] = base * (1.0 + 2.0 ** -9 * rng.standard_normal(256))
+    bt[len(bt) - 8100 + 32: len(bt) - 8100 + 128] += 0.75
+    d.set_params(wt, bt, net=1)
+    d.set_qmax_mode(_capi.QMAX_FULL)
+    _, y_full = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+    d.set_qmax_mode(_capi.QMAX_SCREENED)
+    for stage in (0, 1):
+        d.set_refine_stage(stage)
+        _, ys[stage] = d.td_update(S, S2, A, R, D, td_net=1, mode=0, learning_rate=0.0, grad_scale=1.0)
+    assert np.array_equal(ys[0], ys[1])
+    assert np.abs(y_full - ys[1]).max() < 2e-6
 
 
 
